@@ -1,0 +1,530 @@
+"""CPU oracle for the SURFGAN_3D `pgan` G+D training step.  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain PyTorch-CPU restatement (fp64 by default, fp32 on request) of the
+reference's TF1 graph for the hot path.  Only `tests/`, `__graft_entry__.smoke()` and
+`bench.py`'s `cpu_baseline` leg may import it; the product (`saragan_amd/`) never does.
+
+PARITY PINNING.  The reference ships no golden vectors or known-answer tests for this path
+(SURVEY.md section 4), and its TF1 code cannot run here (no tensorflow).  The oracle is pinned by
+  (1) the parameter counts the reference logged in SURFGAN_3D/out.txt:28-80 (tests/test_oracle_kat.py),
+  (2) outputs of the reference's own importable PyTorch modules (pgan_pytorch/network_dict.py,
+      pgan_pytorch/loss.py) run in the build container by oracle/make_golden.py and committed as
+      tests/golden/ref_*.npz: Discriminator forward / input-gradient / gradient penalty,
+      phase-1 Generator, EqualizedConv3d, EqualizedLinear, ChannelNormalization, Upsample, AvgPool3d,
+  (3) an independent numpy loop restatement of tf.nn.conv3d (DHWIO, SAME) in oracle/conv_numpy.py.
+The TF-only arithmetic (tf.train.AdamOptimizer, tf.train.ExponentialMovingAverage, the (1,2,3)-axis
+GP of loss.py:140) has no runnable reference here: for those rows parity is "unpinned" and follows
+the published TF1 update rules restated in SURVEY.md Appendix B.
+
+All citations are relative to /root/reference/SURFGAN_3D unless stated otherwise.
+Parameters live in a dict keyed by the TF variable names, weights in the TF
+layouts: conv DHWIO [kD,kH,kW,Cin,Cout], dense [in,out].  Activations are NCDHW like the reference.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+
+# ----------------------------------------------------------------------------------------------
+# networks/ops.py
+# ----------------------------------------------------------------------------------------------
+def k_rule(x: int) -> int:
+    """networks/ops.py:25-29 legacy per-dimension kernel rule."""
+    return 1 if x < 3 else 3
+
+
+def calculate_gain(activation: str, param=None) -> float:
+    """networks/ops.py:60-77."""
+    linear_fns = ['linear', 'conv1d', 'conv2d', 'conv3d', 'conv_transpose1d', 'conv_transpose2d',
+                  'conv_transpose3d']
+    if activation in linear_fns or activation == 'sigmoid':
+        return 1.0
+    if activation == 'tanh':
+        return 5.0 / 3
+    if activation == 'relu':
+        return math.sqrt(2.0)
+    if activation == 'leaky_relu':
+        assert param is not None
+        if (not isinstance(param, bool) and isinstance(param, int)) or isinstance(param, float):
+            return math.sqrt(2.0 / (1 + param ** 2))
+        raise ValueError("negative_slope {} not a valid number".format(param))
+    raise ValueError("Unsupported nonlinearity {}".format(activation))
+
+
+def runtime_coef(shape: Sequence[int], activation: str, param=None, lrmul: float = 1.0) -> float:
+    """networks/ops.py:111-116: he_std * lrmul with fan_in = prod(shape[:-1])."""
+    fan_in = float(np.prod(shape[:-1]))
+    return calculate_gain(activation, param) / math.sqrt(fan_in) * lrmul
+
+
+def conv3d(x: torch.Tensor, w: torch.Tensor, activation: str, param=None) -> torch.Tensor:
+    """networks/ops.py:147-150.  w: raw variable, DHWIO.  tf.nn.conv3d stride 1 'SAME' NCDHW is a
+    cross-correlation with zero padding k//2 per side for odd k."""
+    kd, kh, kw = w.shape[:3]
+    assert kd % 2 == 1 and kh % 2 == 1 and kw % 2 == 1, "SAME == k//2 only for odd kernels"
+    wt = (w * runtime_coef(w.shape, activation, param)).permute(4, 3, 0, 1, 2)
+    return F.conv3d(x, wt, padding=(kd // 2, kh // 2, kw // 2))
+
+
+def dense(x: torch.Tensor, w: torch.Tensor, activation: str, param=None) -> torch.Tensor:
+    """networks/ops.py:139-144.  Flatten is C-major of NCDHW (tf.reshape of an NCDHW tensor)."""
+    if x.dim() > 2:
+        x = x.reshape(x.shape[0], -1)
+    return x @ (w * runtime_coef(w.shape, activation, param))
+
+
+def apply_bias(x: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """networks/ops.py:130-136 (lrmul = 1)."""
+    if x.dim() == 2:
+        return x + b
+    return x + b.reshape(1, -1, 1, 1, 1)
+
+
+class _LeakyReluRef(torch.autograd.Function):
+    """networks/ops.py:167-182: y = max(x, a x); dx = where(y >= 0, dy, a dy) (subgradient 1 at 0),
+    and the same mask again for the second-order term."""
+
+    @staticmethod
+    def forward(ctx, x, a):
+        y = torch.maximum(x, x * a)
+        ctx.save_for_backward(y)
+        ctx.a = a
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return _LeakyReluMask.apply(dy, y, ctx.a), None
+
+
+class _LeakyReluMask(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, y, a):
+        ctx.save_for_backward(y)
+        ctx.a = a
+        return torch.where(y >= 0, dy, dy * a)
+
+    @staticmethod
+    def backward(ctx, ddx):
+        (y,) = ctx.saved_tensors
+        return _LeakyReluMask.apply(ddx, y, ctx.a), None, None
+
+
+def leaky_relu(x: torch.Tensor, alpha_lr: float = 0.2) -> torch.Tensor:
+    return _LeakyReluRef.apply(x, alpha_lr)
+
+
+def act(x: torch.Tensor, activation: str, param=None) -> torch.Tensor:
+    """networks/ops.py:185-192."""
+    if activation == 'leaky_relu':
+        assert param is not None
+        return leaky_relu(x, param)
+    if activation == 'linear':
+        return x
+    raise ValueError(f"Unknown activation {activation}")
+
+
+def pixel_norm(x: torch.Tensor, epsilon: float = 1e-8) -> torch.Tensor:
+    """networks/ops.py:308-310."""
+    return x * torch.rsqrt(torch.mean(x * x, dim=1, keepdim=True) + epsilon)
+
+
+def upscale3d(x: torch.Tensor, factor: int = 2) -> torch.Tensor:
+    """networks/ops.py:250-262,276-289: nearest-neighbour x2 (tile + batch_to_space); the custom
+    gradient (8 * avg-pool = sum-pool) is what autograd derives for repeat_interleave."""
+    if factor == 1:
+        return x
+    return x.repeat_interleave(factor, 2).repeat_interleave(factor, 3).repeat_interleave(factor, 4)
+
+
+def downscale3d(x: torch.Tensor, factor: int = 2) -> torch.Tensor:
+    """networks/ops.py:265-273,292-305: avg_pool3d k=s=2 VALID."""
+    if factor == 1:
+        return x
+    return F.avg_pool3d(x, factor)
+
+
+def minibatch_stddev_layer(x: torch.Tensor, group_size: int = 4) -> torch.Tensor:
+    """networks/ops.py:313-325 (disabled in pgan: pgan/discriminator.py:50)."""
+    g = min(group_size, x.shape[0])
+    s = x.shape
+    y = x.reshape(g, -1, s[1], s[2], s[3], s[4])
+    y = y - y.mean(dim=0, keepdim=True)
+    y = (y * y).mean(dim=0)
+    y = torch.sqrt(y + 1e-8)
+    y = y.mean(dim=[1, 2, 3, 4], keepdim=True)
+    y = y.repeat(g, 1, s[2], s[3], s[4])
+    return torch.cat([x, y], dim=1)
+
+
+def alpha_update(alpha: float, mixing_nimg: int, starting_alpha: float, batch_size: int,
+                 global_size: int) -> float:
+    """networks/ops.py:4-23 (fp32 variable arithmetic)."""
+    if mixing_nimg == 0:
+        return 0.0
+    num_steps = mixing_nimg // (batch_size * global_size)
+    upd = np.float32(starting_alpha / num_steps)
+    return float(max(np.float32(alpha) - upd, np.float32(0)))
+
+
+def num_filters(phase: int, base_shape: Sequence[int], size: str) -> int:
+    """networks/ops.py:201-236."""
+    lists = {
+        'xxs': [256, 256, 64, 32, 16, 8, 4, 2], 'xs': [256, 256, 64, 64, 32, 16, 8, 4],
+        's': [512, 512, 128, 128, 64, 32, 16, 8], 'm': [1024, 1024, 256, 256, 128, 64, 32, 16],
+        'l': [2048, 2048, 512, 512, 256, 128, 64, 32],
+        'xl': [4096, 4096, 1024, 1024, 512, 256, 128, 64],
+        'xxl': [8192, 8192, 2048, 1024, 1024, 512, 256, 128]}
+    if size not in lists:
+        raise ValueError(f"Unknown size: {size}")
+    current_dim = [2 ** (phase - 1) * d for d in base_shape[1:]]
+    log_product = np.log2(np.prod(current_dim))
+    reference_log = [4 + n * 3 for n in range(0, 7)]
+    index = int(np.argmin(np.abs(np.array(reference_log) - log_product)))
+    return lists[size][index]
+
+
+def preset_specs(size: str, base_shape: Sequence[int], num_phases: int):
+    """filter_spec / kernel_spec that reproduce the legacy presets (SURVEY section 8 header):
+    fs[l-1] = [F_l, F_l], ks[l-1] = [k, k] with k per dim = 1 if dim < 3 else 3 (ops.py:25-29)."""
+    fs, ks = [], []
+    for l in range(1, num_phases + 1):
+        f = num_filters(l, base_shape, size)
+        fs.append([f, f])
+        dims = [d * 2 ** (l - 1) for d in base_shape[1:]]
+        kk = [k_rule(d) for d in dims]
+        ks.append([kk, kk])
+    return ks, fs
+
+
+# ----------------------------------------------------------------------------------------------
+# networks/pgan/{generator,discriminator}.py
+# ----------------------------------------------------------------------------------------------
+def _spec(spec, phase_i, layer_i):
+    """pgan/generator.py:4-24 / pgan/discriminator.py:3-23: ValueError on missing entries."""
+    if phase_i >= len(spec):
+        raise ValueError
+    if layer_i >= len(spec[phase_i]):
+        raise ValueError
+    return spec[phase_i][layer_i]
+
+
+def variable_shapes(phase: int, base_shape: Sequence[int], latent_dim: int, kernel_spec, filter_spec
+                    ) -> Dict[str, Tuple[int, ...]]:
+    """Names and shapes of the trainable variables the reference creates at `phase`
+    (pgan/generator.py:79-98, pgan/discriminator.py:76-107, ops.py:118,131)."""
+    ch = base_shape[0]
+    v0 = int(np.prod(base_shape[1:]))
+    fs, ks = filter_spec, kernel_spec
+    out: Dict[str, Tuple[int, ...]] = {}
+    g = 'generator/'
+    out[g + 'generator_in/dense/weight'] = (latent_dim, v0 * _spec(fs, 0, 0))
+    out[g + 'generator_in/dense/bias'] = (v0 * _spec(fs, 0, 0),)
+    out[g + 'generator_in/conv/weight'] = (*_spec(ks, 0, 1), _spec(fs, 0, 0), _spec(fs, 0, 1))
+    out[g + 'generator_in/conv/bias'] = (_spec(fs, 0, 1),)
+    c_prev = _spec(fs, 0, 1)
+    for i in range(2, phase + 1):
+        if i == phase:
+            out[g + f'to_rgb_{phase - 1}/weight'] = (1, 1, 1, c_prev, ch)
+            out[g + f'to_rgb_{phase - 1}/bias'] = (ch,)
+        out[g + f'generator_block_{i}/conv_1/weight'] = (*_spec(ks, i - 1, 0), c_prev, _spec(fs, i - 1, 0))
+        out[g + f'generator_block_{i}/conv_1/bias'] = (_spec(fs, i - 1, 0),)
+        out[g + f'generator_block_{i}/conv_2/weight'] = (*_spec(ks, i - 1, 1), _spec(fs, i - 1, 0),
+                                                        _spec(fs, i - 1, 1))
+        out[g + f'generator_block_{i}/conv_2/bias'] = (_spec(fs, i - 1, 1),)
+        c_prev = _spec(fs, i - 1, 1)
+    out[g + f'to_rgb_{phase}/weight'] = (1, 1, 1, c_prev, ch)
+    out[g + f'to_rgb_{phase}/bias'] = (ch,)
+
+    d = 'discriminator/'
+    out[d + f'from_rgb_{phase}/weight'] = (1, 1, 1, ch, _spec(fs, phase - 1, 1))
+    out[d + f'from_rgb_{phase}/bias'] = (_spec(fs, phase - 1, 1),)
+    c_in = _spec(fs, phase - 1, 1)
+    for i in reversed(range(2, phase + 1)):
+        out[d + f'discriminator_block_{i}/conv_1/weight'] = (*_spec(ks, i - 1, 1), c_in, _spec(fs, i - 1, 0))
+        out[d + f'discriminator_block_{i}/conv_1/bias'] = (_spec(fs, i - 1, 0),)
+        out[d + f'discriminator_block_{i}/conv_2/weight'] = (*_spec(ks, i - 1, 0), _spec(fs, i - 1, 0),
+                                                            _spec(fs, i - 2, 1))
+        out[d + f'discriminator_block_{i}/conv_2/bias'] = (_spec(fs, i - 2, 1),)
+        c_in = _spec(fs, i - 2, 1)
+        if i == phase:
+            out[d + f'from_rgb_{phase - 1}/weight'] = (1, 1, 1, ch, _spec(fs, phase - 2, 1))
+            out[d + f'from_rgb_{phase - 1}/bias'] = (_spec(fs, phase - 2, 1),)
+    out[d + 'discriminator_out/weight'] = (*_spec(ks, 0, 1), c_in, _spec(fs, 0, 0))
+    out[d + 'discriminator_out/bias'] = (_spec(fs, 0, 0),)
+    out[d + 'discriminator_out/dense_1/weight'] = (v0 * _spec(fs, 0, 0), latent_dim)
+    out[d + 'discriminator_out/dense_1/bias'] = (latent_dim,)
+    out[d + 'discriminator_out/dense_2/weight'] = (latent_dim, 1)
+    out[d + 'discriminator_out/dense_2/bias'] = (1,)
+    return out
+
+
+def init_params(phase, base_shape, latent_dim, kernel_spec, filter_spec, seed=0,
+                dtype=torch.float64, bias_std: float = 0.0) -> Params:
+    """weight ~ N(0,1) (ops.py:118-119, lrmul 1), bias zeros (ops.py:131).  `bias_std` > 0 draws
+    non-zero biases so that parity tests exercise the bias path."""
+    gen = torch.Generator().manual_seed(seed)
+    p: Params = {}
+    for name, shape in variable_shapes(phase, base_shape, latent_dim, kernel_spec, filter_spec).items():
+        if name.endswith('weight'):
+            p[name] = torch.randn(shape, generator=gen, dtype=torch.float64).to(dtype)
+        else:
+            p[name] = (torch.randn(shape, generator=gen, dtype=torch.float64) * bias_std).to(dtype)
+    return p
+
+
+def generator(p: Params, z, alpha, phase, base_shape, activation, kernel_spec, filter_spec,
+              param=None, conditioning=None):
+    """pgan/generator.py:74-103 (+ generator_in :26-45, generator_block :48-71)."""
+    if conditioning is not None:
+        raise NotImplementedError()
+    g = 'generator/'
+    fs = filter_spec
+    x = dense(z, p[g + 'generator_in/dense/weight'], activation, param)
+    x = act(apply_bias(x, p[g + 'generator_in/dense/bias']), activation, param)
+    x = x.reshape(-1, _spec(fs, 0, 0), *base_shape[1:])
+    x = conv3d(x, p[g + 'generator_in/conv/weight'], activation, param)
+    x = pixel_norm(act(apply_bias(x, p[g + 'generator_in/conv/bias']), activation, param))
+    x_upsample = None
+    for i in range(2, phase + 1):
+        if i == phase:
+            t = conv3d(x, p[g + f'to_rgb_{phase - 1}/weight'], 'linear')
+            x_upsample = upscale3d(apply_bias(t, p[g + f'to_rgb_{phase - 1}/bias']))
+        b = g + f'generator_block_{i}/'
+        x = upscale3d(x)
+        x = conv3d(x, p[b + 'conv_1/weight'], activation, param)
+        x = pixel_norm(act(apply_bias(x, p[b + 'conv_1/bias']), activation, param))
+        x = conv3d(x, p[b + 'conv_2/weight'], activation, param)
+        x = pixel_norm(act(apply_bias(x, p[b + 'conv_2/bias']), activation, param))
+    x_out = apply_bias(conv3d(x, p[g + f'to_rgb_{phase}/weight'], 'linear'), p[g + f'to_rgb_{phase}/bias'])
+    if x_upsample is not None:
+        x_out = alpha * x_upsample + (1 - alpha) * x_out
+    return x_out
+
+
+def discriminator(p: Params, x, alpha, phase, latent_dim, activation, kernel_spec, filter_spec,
+                  param=None, conditioning=None):
+    """pgan/discriminator.py:71-108 (+ discriminator_block :25-45, discriminator_out :48-68)."""
+    if conditioning is not None:
+        raise NotImplementedError()
+    d = 'discriminator/'
+    x_downscale = x
+    x = conv3d(x, p[d + f'from_rgb_{phase}/weight'], activation, param)
+    x = act(apply_bias(x, p[d + f'from_rgb_{phase}/bias']), activation, param)
+    for i in reversed(range(2, phase + 1)):
+        b = d + f'discriminator_block_{i}/'
+        x = conv3d(x, p[b + 'conv_1/weight'], activation, param)
+        x = act(apply_bias(x, p[b + 'conv_1/bias']), activation, param)
+        x = conv3d(x, p[b + 'conv_2/weight'], activation, param)
+        x = act(apply_bias(x, p[b + 'conv_2/bias']), activation, param)
+        x = downscale3d(x)
+        if i == phase:
+            t = conv3d(downscale3d(x_downscale), p[d + f'from_rgb_{phase - 1}/weight'], activation, param)
+            t = act(apply_bias(t, p[d + f'from_rgb_{phase - 1}/bias']), activation, param)
+            x = alpha * t + (1 - alpha) * x
+    x = conv3d(x, p[d + 'discriminator_out/weight'], activation, param)
+    x = act(apply_bias(x, p[d + 'discriminator_out/bias']), activation, param)
+    x = dense(x, p[d + 'discriminator_out/dense_1/weight'], activation, param)
+    x = act(apply_bias(x, p[d + 'discriminator_out/dense_1/bias']), activation, param)
+    x = dense(x, p[d + 'discriminator_out/dense_2/weight'], 'linear')
+    return apply_bias(x, p[d + 'discriminator_out/dense_2/bias'])
+
+
+# ----------------------------------------------------------------------------------------------
+# networks/loss.py  (all randomness is injected: TF and torch RNG streams cannot be matched)
+# ----------------------------------------------------------------------------------------------
+def _softplus(x):
+    return F.softplus(x)
+
+
+def forward_simultaneous(p: Params, real, z, noise_real, noise_fake, gamma, alpha, phase, base_shape,
+                         latent_dim, kernel_spec, filter_spec, activation, leakiness, loss_fn,
+                         gp_weight, noise_stddev):
+    """networks/loss.py:101-165, including quirk Q1: slopes reduce over axes (1,2,3) of the 5-D
+    gradient, so slopes has shape [N, W] (loss.py:140)."""
+    net = dict(phase=phase, activation=activation, kernel_spec=kernel_spec, filter_spec=filter_spec,
+               param=leakiness)
+    gen_sample = generator(p, z, alpha, base_shape=base_shape, **net)
+    real_n = real + noise_real * noise_stddev
+    fake_n = gen_sample + noise_fake * noise_stddev
+    disc_fake_d = discriminator(p, fake_n.detach(), alpha, latent_dim=latent_dim, **net)
+    disc_real = discriminator(p, real_n, alpha, latent_dim=latent_dim, **net)
+    interpolates = (gamma * real_n + (1 - gamma) * fake_n.detach()).requires_grad_(True)
+    d_int = discriminator(p, interpolates, alpha, latent_dim=latent_dim, **net)
+    (gradients,) = torch.autograd.grad(d_int.sum(), interpolates, create_graph=True)
+    slopes = torch.sqrt(torch.sum(gradients * gradients, dim=(1, 2, 3)))
+    disc_fake_g = discriminator(p, fake_n, alpha, latent_dim=latent_dim, **net)
+    if loss_fn == 'wgan':
+        gp_loss = gp_weight * (slopes - 1) ** 2
+        disc_loss = disc_fake_d - disc_real
+        drift_loss = 1e-3 * disc_real ** 2
+        disc_loss = torch.mean(disc_loss + gp_loss + drift_loss)
+        gen_loss = -torch.mean(disc_fake_g)
+    elif loss_fn == 'logistic':
+        gp_loss = gp_weight * torch.mean(slopes ** 2)
+        disc_loss = torch.mean(_softplus(disc_fake_d)) + torch.mean(_softplus(-disc_real))
+        disc_loss = disc_loss + gp_loss
+        gen_loss = torch.mean(_softplus(-disc_fake_g))
+    else:
+        raise ValueError(f"Unknown loss function: {loss_fn}")
+    return gen_loss, disc_loss, gp_loss, gen_sample
+
+
+def forward_discriminator(p: Params, real, z, noise_real, noise_fake, gamma, alpha, phase, base_shape,
+                          latent_dim, kernel_spec, filter_spec, activation, leakiness, loss_fn,
+                          gp_weight, noise_stddev):
+    """networks/loss.py:42-98 (alternate mode; GP reduces over (1,2,3,4): loss.py:79)."""
+    net = dict(phase=phase, activation=activation, kernel_spec=kernel_spec, filter_spec=filter_spec,
+               param=leakiness)
+    gen_sample = generator(p, z, alpha, base_shape=base_shape, **net)
+    real_n = real + noise_real * noise_stddev
+    fake_n = gen_sample + noise_fake * noise_stddev
+    disc_fake_d = discriminator(p, fake_n.detach(), alpha, latent_dim=latent_dim, **net)
+    disc_real = discriminator(p, real_n, alpha, latent_dim=latent_dim, **net)
+    interpolates = (gamma * real_n + (1 - gamma) * fake_n.detach()).requires_grad_(True)
+    d_int = discriminator(p, interpolates, alpha, latent_dim=latent_dim, **net)
+    (gradients,) = torch.autograd.grad(d_int.sum(), interpolates, create_graph=True)
+    slopes = torch.sqrt(torch.sum(gradients * gradients, dim=(1, 2, 3, 4)))
+    if loss_fn == 'wgan':
+        gp_loss = gp_weight * (slopes - 1) ** 2
+        # [N,1] + [N] broadcasts to [N,N] in TF exactly as it does here (loss.py:82-86).
+        disc_loss = torch.mean((disc_fake_d - disc_real) + gp_loss + 1e-3 * disc_real ** 2)
+    elif loss_fn == 'logistic':
+        gp_loss = gp_weight * torch.mean(slopes ** 2)
+        disc_loss = torch.mean(_softplus(disc_fake_d)) + torch.mean(_softplus(-disc_real)) + gp_loss
+    else:
+        raise ValueError(f"Unknown loss function: {loss_fn}")
+    return disc_loss, gp_loss
+
+
+def forward_generator(p: Params, real, z, noise_real, noise_fake, alpha, phase, base_shape, latent_dim,
+                      kernel_spec, filter_spec, activation, leakiness, loss_fn, noise_stddev):
+    """networks/loss.py:4-39."""
+    net = dict(phase=phase, activation=activation, kernel_spec=kernel_spec, filter_spec=filter_spec,
+               param=leakiness)
+    gen_sample = generator(p, z, alpha, base_shape=base_shape, **net)
+    fake_n = gen_sample + noise_fake * noise_stddev
+    disc_fake_g = discriminator(p, fake_n, alpha, latent_dim=latent_dim, **net)
+    if loss_fn == 'wgan':
+        gen_loss = -torch.mean(disc_fake_g)
+    elif loss_fn == 'logistic':
+        gen_loss = torch.mean(_softplus(-disc_fake_g))
+    else:
+        raise ValueError(f"Unknown loss function: {loss_fn}")
+    return gen_sample, gen_loss
+
+
+# ----------------------------------------------------------------------------------------------
+# optimization.py / ExtendedEMA.py / third-party update rules
+# ----------------------------------------------------------------------------------------------
+class TFAdam:
+    """tf.train.AdamOptimizer(lr, beta1, beta2, epsilon=1e-8) as called at optimization.py:16,28:
+    lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t * m / (sqrt(v) + eps)."""
+
+    def __init__(self, beta1=0.0, beta2=0.9, epsilon=1e-8):
+        self.b1, self.b2, self.eps = beta1, beta2, epsilon
+        self.t = 0
+        self.m: Params = {}
+        self.v: Params = {}
+
+    def apply(self, params: Params, grads: Dict[str, torch.Tensor], lr: float):
+        self.t += 1
+        lr_t = lr * math.sqrt(1 - self.b2 ** self.t) / (1 - self.b1 ** self.t)
+        for name, g in grads.items():
+            if name not in self.m:
+                self.m[name] = torch.zeros_like(params[name])
+                self.v[name] = torch.zeros_like(params[name])
+            self.m[name] = self.b1 * self.m[name] + (1 - self.b1) * g
+            self.v[name] = self.b2 * self.v[name] + (1 - self.b2) * g * g
+            params[name] = params[name] - lr_t * self.m[name] / (torch.sqrt(self.v[name]) + self.eps)
+
+
+def clip_by_global_norm(grads: Dict[str, torch.Tensor], clip_norm: float = 1.0):
+    """tf.clip_by_global_norm (optimization.py:66-67): g * clip / max(global_norm, clip)."""
+    gn = torch.sqrt(sum((g * g).sum() for g in grads.values()))
+    scale = clip_norm / max(float(gn), clip_norm)
+    return {k: g * scale for k, g in grads.items()}, gn
+
+
+def ema_update(shadow: Params, params: Params, decay: float):
+    """tf.train.ExponentialMovingAverage without num_updates / zero_debias (ExtendedEMA.py:11-19):
+    shadow -= (1-decay) * (shadow - theta)."""
+    for k in params:
+        shadow[k] = shadow[k] - (1 - decay) * (shadow[k] - params[k])
+
+
+def lr_update(intra_phase_step: int, steps_per_phase: int, lr_max: float, lr_increase, lr_decrease,
+              lr_rise_niter, lr_decay_niter) -> float:
+    """optimization.py:227-296.  Returns the fp32 value assigned to the lr variable."""
+    lr = np.float32(lr_max)
+    if lr_increase or lr_decrease:
+        a = np.float32(lr_max / 100)
+        if lr_increase == 'linear':
+            if intra_phase_step < lr_rise_niter:
+                lr = np.float32(intra_phase_step / lr_rise_niter) * np.float32(lr_max)
+        elif lr_increase == 'exponential':
+            if intra_phase_step < lr_rise_niter:
+                b_rise = np.float32(np.log(100) / lr_rise_niter)
+                lr = a * np.exp(b_rise * np.float32(intra_phase_step), dtype=np.float32)
+        if lr_decrease:
+            step_decay_start = steps_per_phase - lr_decay_niter
+            remaining = steps_per_phase - intra_phase_step
+            if lr_decrease == 'linear':
+                if intra_phase_step > step_decay_start:
+                    lr = np.float32(remaining / lr_decay_niter) * np.float32(lr_max)
+            elif lr_decrease == 'exponential':
+                if intra_phase_step > step_decay_start:
+                    b_decay = np.float32(np.log(100) / lr_decay_niter)
+                    lr = a * np.exp(b_decay * np.float32(remaining), dtype=np.float32)
+    return float(lr)
+
+
+def split_vars(p: Params):
+    gen = [k for k in p if k.startswith('generator/')]
+    disc = [k for k in p if k.startswith('discriminator/')]
+    return gen, disc
+
+
+def step_simultaneous(p: Params, adam_g: TFAdam, adam_d: TFAdam, shadow: Optional[Params], rnd: dict,
+                      real, alpha, cfg: dict, g_lr: float, d_lr: float, freeze: Optional[Sequence[str]] = None,
+                      ema_beta: float = 0.99, g_clipping=False, d_clipping=False, world_grads=None):
+    """One `simultaneous` optimisation step (optimization.py:128-163,
+    optuna_objective.py:463-467): both gradients at the pre-step weights, freeze = names that are
+    NOT updated (the previous phase's variables while mixing, Q4).  Returns the fetches and grads."""
+    work = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    gen_loss, disc_loss, gp_loss, gen_sample = forward_simultaneous(
+        work, real, rnd['z'], rnd['noise_real'], rnd['noise_fake'], rnd['gamma'], alpha, **cfg)
+    gnames, dnames = split_vars(work)
+    if freeze is not None:
+        fz = set(freeze)
+        gnames = [k for k in gnames if k not in fz]
+        dnames = [k for k in dnames if k not in fz]
+    g_grads = torch.autograd.grad(gen_loss, [work[k] for k in gnames], retain_graph=True)
+    d_grads = torch.autograd.grad(disc_loss, [work[k] for k in dnames])
+    g_grads = dict(zip(gnames, [g.detach() for g in g_grads]))
+    d_grads = dict(zip(dnames, [g.detach() for g in d_grads]))
+    if g_clipping:
+        g_grads, _ = clip_by_global_norm(g_grads)
+    if d_clipping:
+        d_grads, _ = clip_by_global_norm(d_grads)
+    adam_g.apply(p, g_grads, g_lr)
+    adam_d.apply(p, d_grads, d_lr)
+    if shadow is not None:
+        ema_update(shadow, p, ema_beta)
+    return dict(gen_loss=gen_loss.detach(), disc_loss=disc_loss.detach(), gp_loss=gp_loss.detach(),
+                gen_sample=gen_sample.detach(), g_grads=g_grads, d_grads=d_grads)
+
+
+def draw_randomness(n, latent_dim, img_shape, seed, dtype=torch.float64):
+    """The four random tensors of loss.py:116-133, drawn from a seeded torch generator."""
+    gen = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=gen, dtype=torch.float64).to(dtype)
+    return dict(z=r(n, latent_dim), noise_real=r(n, *img_shape), noise_fake=r(n, *img_shape),
+                gamma=torch.rand(n, 1, 1, 1, 1, generator=gen, dtype=torch.float64).to(dtype))

@@ -1,0 +1,176 @@
+"""CPU tests that pin oracle/pgan_oracle.py: the out.txt parameter-count KAT, the fixtures produced by
+running the reference's own PyTorch modules (tests/golden/ref_*.npz, oracle/make_golden.py), and the
+independent numpy conv restatement."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pgan_oracle as O
+from oracle.conv_numpy import conv3d_same_dhwio
+from tests import refmap
+
+T = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_param_count_kat_out_txt():
+    """SURFGAN_3D/out.txt:28-29,40-41,52-53,64-65,79-80 (xs, latent 512, base (1,1,4,4), k-rule kernels)."""
+    base_shape = (1, 1, 4, 4)
+    ks, fs = O.preset_specs('xs', base_shape, 8)
+    want_g = [2691585, 3872002, 4424898, 4646018, 4728994]
+    want_d = [2688769, 3869441, 4422337, 4643265, 4726241]
+    want_nvars = {1: 14, 2: 26, 3: 34, 4: 42}
+    for phase in range(1, 6):
+        shapes = O.variable_shapes(phase, base_shape, 512, ks, fs)
+        g = sum(int(np.prod(s)) for k, s in shapes.items() if k.startswith('generator/'))
+        d = sum(int(np.prod(s)) for k, s in shapes.items() if k.startswith('discriminator/'))
+        assert (g, d) == (want_g[phase - 1], want_d[phase - 1])
+        if phase in want_nvars:
+            assert len(shapes) == want_nvars[phase]
+
+
+def test_num_filters_presets():
+    assert [O.num_filters(l, (1, 1, 4, 4), 's') for l in range(1, 8)] == [512, 512, 128, 128, 64, 32, 16]
+    with pytest.raises(ValueError):
+        O.num_filters(1, (1, 1, 4, 4), 'huge')
+
+
+def test_conv_matches_numpy_restatement():
+    rng = np.random.default_rng(0)
+    for k in ((3, 3, 3), (1, 3, 3), (1, 1, 1)):
+        x = rng.standard_normal((2, 3, 3, 4, 5))
+        w = rng.standard_normal((*k, 3, 4))
+        ref = conv3d_same_dhwio(x, w * O.runtime_coef(w.shape, 'leaky_relu', 0.2))
+        got = O.conv3d(T(x), T(w), 'leaky_relu', 0.2).numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_reference_eqconv3d(golden_dir):
+    for name in ('ref_eqconv3d.npz', 'ref_eqconv3d_133.npz', 'ref_genblock_stage1.npz'):
+        g = load(golden_dir, name)
+        leak = float(g['leak'])
+        w = T(refmap.oidhw_to_dhwio(g['weight_oidhw']))
+        x = T(g['x'])
+        if name == 'ref_genblock_stage1.npz':
+            y = O.conv3d(O.upscale3d(x), w, 'leaky_relu', leak)
+            y = O.pixel_norm(O.act(O.apply_bias(y, T(g['bias'])), 'leaky_relu', leak))
+        else:
+            y = O.apply_bias(O.conv3d(x, w, 'leaky_relu', leak), T(g['bias']))
+        np.testing.assert_allclose(y.numpy(), g['y'], rtol=1e-11, atol=1e-12)
+
+
+def test_reference_eqlinear_and_simple_ops(golden_dir):
+    g = load(golden_dir, 'ref_eqlinear.npz')
+    y = O.apply_bias(O.dense(T(g['x']), T(g['weight_oi'].T), 'leaky_relu', float(g['leak'])), T(g['bias']))
+    np.testing.assert_allclose(y.numpy(), g['y'], rtol=1e-12, atol=1e-12)
+    g = load(golden_dir, 'ref_simple_ops.npz')
+    x = T(g['x'])
+    np.testing.assert_allclose(O.pixel_norm(x).numpy(), g['channel_norm'], rtol=1e-12)
+    np.testing.assert_array_equal(O.upscale3d(x).numpy(), g['upsample'])
+    np.testing.assert_allclose(O.downscale3d(T(g['x2'])).numpy(), g['avgpool'], rtol=1e-12)
+    np.testing.assert_allclose(O.leaky_relu(x, float(g['leak'])).numpy(), g['lrelu'], rtol=1e-12)
+
+
+@pytest.mark.parametrize('phase', [1, 2, 3])
+def test_reference_discriminator(golden_dir, phase):
+    """Whole D (pgan_pytorch/network_dict.py:176-255) forward, input gradient, WGAN-GP value
+    (pgan_pytorch/loss.py:7-27) and the GP's parameter gradients (double backward)."""
+    g = load(golden_dir, f'ref_discriminator_p{phase}.npz')
+    leak, alpha = float(g['leak']), float(g['alpha'])
+    p_np, gpgrads = refmap.discriminator_params(g, phase)
+    p = {k: T(v).requires_grad_(True) for k, v in p_np.items()}
+    fs = refmap.ref_filter_spec(int(g['base_dim']), int(g['num_phases']))
+    ks = [[[3, 3, 3], [3, 3, 3]]] * int(g['num_phases'])
+    kw = dict(phase=phase, latent_dim=int(g['latent']), activation='leaky_relu', kernel_spec=ks,
+              filter_spec=fs, param=leak)
+    x = T(g['real']).requires_grad_(True)
+    out = O.discriminator(p, x, alpha, **kw)
+    np.testing.assert_allclose(out.detach().numpy(), g['out'], rtol=1e-10, atol=1e-12)
+    (gin,) = torch.autograd.grad(out.sum(), x)
+    np.testing.assert_allclose(gin.numpy(), g['grad_in'], rtol=1e-10, atol=1e-13)
+    gamma = T(g['gamma'])
+    xi = (gamma * T(g['real']) + (1 - gamma) * T(g['fake'])).requires_grad_(True)
+    (gr,) = torch.autograd.grad(O.discriminator(p, xi, alpha, **kw).sum(), xi, create_graph=True)
+    slopes = torch.sqrt((gr * gr).sum(dim=(1, 2, 3, 4)))
+    gp = 10 * ((slopes - 1) ** 2).mean()
+    np.testing.assert_allclose(float(gp.detach()), float(g['gp']), rtol=1e-10)
+    names = list(gpgrads.keys())
+    grads = torch.autograd.grad(gp, [p[k] for k in names], allow_unused=True)
+    for k, gg in zip(names, grads):
+        ref = gpgrads[k]
+        got = np.zeros_like(ref) if gg is None else gg.numpy()
+        np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-12, err_msg=k)
+
+
+def test_reference_generator_phase1(golden_dir):
+    g = load(golden_dir, 'ref_generator_p1.npz')
+    p = {k: T(v) for k, v in refmap.generator_p1_params(g).items()}
+    bd = int(g['base_dim'])
+    out = O.generator(p, T(g['z']), 0.0, 1, (1, 1, 4, 4), 'leaky_relu', [[[3, 3, 3], [3, 3, 3]]],
+                      [[bd, bd]], param=float(g['leak']))
+    np.testing.assert_allclose(out.numpy(), g['out'], rtol=1e-10, atol=1e-12)
+
+
+def test_leaky_relu_reference_gradients():
+    x = torch.tensor([-2.0, 0.0, 3.0], dtype=torch.float64, requires_grad=True)
+    y = O.leaky_relu(x, 0.2)
+    (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+    assert gx.tolist() == [0.2, 1.0, 1.0]        # subgradient at 0 is 1 (ops.py:177, quirk Q6)
+    dy = torch.ones(3, dtype=torch.float64, requires_grad=True)
+    gx2 = O._LeakyReluMask.apply(dy, y.detach(), 0.2)
+    (ddy,) = torch.autograd.grad(gx2.sum(), dy)
+    assert ddy.tolist() == [0.2, 1.0, 1.0]
+
+
+def test_alpha_and_lr_schedules():
+    a = 1.0
+    for _ in range(4):
+        a = O.alpha_update(a, 64, 1.0, 8, 2)
+    assert a == 0.0
+    assert O.alpha_update(0.7, 0, 1.0, 8, 2) == 0.0
+    assert abs(O.alpha_update(1.0, 128, 1.0, 8, 2) - 0.875) < 1e-7
+    kw = dict(steps_per_phase=1000, lr_max=1e-3, lr_rise_niter=100, lr_decay_niter=200)
+    assert O.lr_update(50, lr_increase=None, lr_decrease=None, **kw) == pytest.approx(1e-3)
+    assert O.lr_update(50, lr_increase='linear', lr_decrease=None, **kw) == pytest.approx(5e-4, rel=1e-6)
+    assert O.lr_update(0, lr_increase='exponential', lr_decrease=None, **kw) == pytest.approx(1e-5, rel=1e-6)
+    assert O.lr_update(900, lr_increase='linear', lr_decrease='linear', **kw) == pytest.approx(5e-4, rel=1e-6)
+    assert O.lr_update(1000, lr_increase=None, lr_decrease='exponential', **kw) == pytest.approx(1e-5, rel=1e-6)
+    assert O.lr_update(500, lr_increase='linear', lr_decrease='exponential', **kw) == pytest.approx(1e-3)
+
+
+def test_tf_adam_rule():
+    p = {'w': torch.tensor([1.0, -2.0], dtype=torch.float64)}
+    g = {'w': torch.tensor([0.5, -0.25], dtype=torch.float64)}
+    opt = O.TFAdam(0.0, 0.9)
+    opt.apply(p, g, 1e-3)
+    # t=1, b1=0: m=g, v=0.1 g^2, lr_t = lr*sqrt(0.1)
+    want = np.array([1.0, -2.0]) - 1e-3 * np.sqrt(0.1) * np.array([0.5, -0.25]) / (
+        np.sqrt(0.1 * np.array([0.25, 0.0625])) + 1e-8)
+    np.testing.assert_allclose(p['w'].numpy(), want, rtol=1e-14)
+
+
+@pytest.mark.parametrize('name', ['oracle_step_p1_wgan_a000.npz', 'oracle_step_p2_wgan_a060.npz',
+                                  'oracle_step_p3_logistic_a025.npz', 'oracle_step_p3_wgan_a000.npz'])
+def test_oracle_step_fixture_replays_in_fp32(golden_dir, name):
+    """The committed fp64 master fixtures replay through the oracle in fp32 within fp32 tolerance:
+    this is the same comparison the GPU parity tests make with the HIP path in place of the replay."""
+    from tests.stepfix import load_step_fixture
+    fx = load_step_fixture(os.path.join(golden_dir, name), torch.float32)
+    p = {k: v.clone() for k, v in fx['p0'].items()}
+    adam_g, adam_d = O.TFAdam(0.0, 0.9), O.TFAdam(0.0, 0.9)
+    shadow = {k: v.clone() for k, v in p.items()}
+    res = O.step_simultaneous(p, adam_g, adam_d, shadow, fx['rnd'], fx['real'], fx['alpha'], fx['cfg'],
+                              1e-3, 1e-3, freeze=fx['freeze'])
+    np.testing.assert_allclose(float(res['gen_loss']), float(fx['gen_loss']), rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(float(res['disc_loss']), float(fx['disc_loss']), rtol=2e-4, atol=1e-5)
+    np.testing.assert_allclose(res['gen_sample'].numpy(), fx['gen_sample'].numpy(), rtol=1e-3, atol=1e-5)
+    for k, v in fx['dg'].items():
+        ref = v.numpy()
+        np.testing.assert_allclose(res['d_grads'][k].numpy(), ref, rtol=5e-3, atol=1e-4 * np.abs(ref).max() + 1e-7)
+    for k in [k for k in (fx['freeze'] or []) if k in p]:
+        np.testing.assert_array_equal(p[k].numpy(), fx['p0'][k].numpy())

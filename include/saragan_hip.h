@@ -1,0 +1,156 @@
+/*
+ * saragan_hip.h -- C ABI of libsaragan_hip.so: the MI355X (gfx950) kernels behind the SURFGAN_3D
+ * `pgan` generator + discriminator training step.
+ *
+ * The reference (sara-nl/saraGAN) has no FFI on this path: its boundary is Python calling TensorFlow-1
+ * ops (SURFGAN_3D/networks/ops.py).  Each entry point below replaces the TF op(s) named in its
+ * comment; INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain C: pointers, sizes and small POD structs only; no torch / HIP types in signatures
+ *    (`sg_stream_t` is a hipStream_t passed as void*; NULL = the default stream);
+ *  - every buffer is caller-owned DEVICE memory; no entry point allocates, frees or synchronises;
+ *    kernels are enqueued on the stream given; entry points are re-entrant (no global mutable state
+ *    except the opt-in profiler, sg_prof_*);
+ *  - activations are NDHWC (channels-last 3-D): element (n,d,h,w,c) at (((n*D+d)*H+h)*W+w)*C+c.
+ *    A 2-D image batch is D == 1.  dtype SG_F32 or SG_BF16 (storage AND MFMA input type; accumulation
+ *    is always f32);
+ *  - weights stay in the reference's layouts: conv DHWIO [kD][kH][kW][Cin][Cout] f32
+ *    (networks/ops.py:148), dense [in][out] f32 (networks/ops.py:142); the equalised-LR runtime
+ *    coefficient (networks/ops.py:111-122) is an argument, applied when packing;
+ *  - return value: 0 on success, a negative SG_E* code for bad arguments, or a positive hipError_t.
+ */
+#ifndef SARAGAN_HIP_H
+#define SARAGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sg_stream_t;
+
+typedef enum { SG_F32 = 0, SG_BF16 = 1 } sg_dtype;
+
+enum {
+  SG_OK = 0,
+  SG_EINVAL = -1,      /* bad shape / null pointer / unsupported combination */
+  SG_EWORKSPACE = -2,  /* workspace too small */
+  SG_EALIGN = -3       /* pointer not 16-byte aligned */
+};
+
+/* Geometry of one stride-1 'SAME' convolution (tf.nn.conv3d at networks/ops.py:150).
+ * (d,h,w) is the OUTPUT extent.  If `upsample_in` != 0 the input tensor is half resolution
+ * ((d/2,h/2,w/2), all even) and is read through a nearest-neighbour x2 gather, i.e. the kernel
+ * computes conv3d(upscale3d(x)) (networks/ops.py:276-289 + :147-150) without materialising it. */
+typedef struct {
+  int32_t n, d, h, w;
+  int32_t cin, cout;
+  int32_t kd, kh, kw; /* odd */
+  int32_t upsample_in;
+} sg_conv_shape;
+
+/* Epilogue fused into sg_conv3d_fwd (apply_bias + act + pixel_norm: networks/ops.py:130-136,167-192,308-310). */
+typedef struct {
+  const float* bias;   /* [cout] or NULL */
+  int32_t act;         /* 0 = linear, 1 = leaky_relu */
+  float slope;         /* leaky_relu negative slope */
+  int32_t pixel_norm;  /* 1: y *= rsqrt(mean_c(y^2)+eps); requires cout <= 128 */
+  float eps;
+  float* pn_scale;     /* optional [n*d*h*w] f32: the per-voxel rsqrt factor (saved for backward) */
+} sg_conv_epilogue;
+
+const char* sg_version(void);
+const char* sg_error_string(int code);
+
+/* ---- conv3d / dense (networks/ops.py:139-150) -------------------------------------------------- */
+/* Bytes of the MFMA-fragment-ordered weight image sg_conv3d_pack_weights writes. */
+size_t sg_conv3d_packed_bytes(const sg_conv_shape* s, sg_dtype dt);
+/* wp <- coef * w, cast to dt, in fragment order.  transpose_flip != 0 packs the weights of the
+ * data-gradient convolution instead: w is then [kD][kH][kW][s->cout][s->cin] and is mirrored in
+ * (kD,kH,kW) and transposed in (I,O) (what tf's Conv3DBackpropInputV2 computes for stride 1). */
+int sg_conv3d_pack_weights(const float* w_dhwio, float coef, int transpose_flip, void* wp,
+                           const sg_conv_shape* s, sg_dtype dt, sg_stream_t st);
+/* y = epilogue(conv3d(x, wp)).  x: [n,d,h,w,cin] (or half-res if upsample_in), y: [n,d,h,w,cout]. */
+int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_conv_shape* s,
+                  const sg_conv_epilogue* ep, sg_dtype dt, sg_stream_t st);
+/* dw[kD][kH][kW][cin][cout] (f32) = coef * sum_v x[v+tap] (x) dy[v]   (tf Conv3DBackpropFilterV2).
+ * workspace: sg_conv3d_wgrad_workspace() bytes, contents irrelevant on entry. */
+size_t sg_conv3d_wgrad_workspace(const sg_conv_shape* s, sg_dtype dt);
+int sg_conv3d_wgrad(const void* x, const void* dy, float* dw_dhwio, float coef, void* workspace,
+                    size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st);
+
+/* ---- elementwise / reductions over NDHWC -------------------------------------------------------- */
+/* y = act(x + bias[c])                       (apply_bias + act, networks/ops.py:130-136,185-192) */
+int sg_bias_act_fwd(const void* x, const float* bias, void* y, int64_t nvox, int32_t c, int32_t act,
+                    float slope, sg_dtype dt, sg_stream_t st);
+/* dx = (y >= 0 ? dy : slope*dy) (mask from the OUTPUT, networks/ops.py:177); y == NULL: dx = dy.
+ * dbias (optional, [c] f32, overwritten) = sum_v dx.  workspace >= sg_bias_act_bwd_workspace(c). */
+size_t sg_bias_act_bwd_workspace(int32_t c);
+int sg_bias_act_bwd(const void* dy, const void* y, void* dx, float* dbias, void* workspace, int64_t nvox,
+                    int32_t c, float slope, sg_dtype dt, sg_stream_t st);
+/* y = x * rsqrt(mean_c(x^2) + eps); scale (optional, [nvox] f32) receives the rsqrt factor.
+ * (pixel_norm, networks/ops.py:308-310) */
+int sg_pixel_norm_fwd(const void* x, void* y, float* scale, int64_t nvox, int32_t c, float eps,
+                      sg_dtype dt, sg_stream_t st);
+/* dx = scale * (dy - y * mean_c(dy*y)),  y = forward OUTPUT, scale = forward rsqrt factor. */
+int sg_pixel_norm_bwd(const void* dy, const void* y, const float* scale, void* dx, int64_t nvox,
+                      int32_t c, sg_dtype dt, sg_stream_t st);
+/* y[n,2d,2h,2w,c] = gain * x[n,d,h,w,c] nearest-neighbour    (upscale3d / avg_unpool3d, ops.py:250-262) */
+int sg_upscale2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
+                 float gain, sg_dtype dt, sg_stream_t st);
+/* y[n,d/2,h/2,w/2,c] = gain * sum of the 2x2x2 block; gain = 1/8 is downscale3d (ops.py:265-273),
+ * gain = 1 is the gradient of upscale3d (ops.py:284).  (d,h,w) = INPUT extent, all even. */
+int sg_downscale2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
+                   float gain, sg_dtype dt, sg_stream_t st);
+/* out = wa*a + wb*b     (fade-in lerp pgan/generator.py:100-101, pgan/discriminator.py:105; b may be NULL) */
+int sg_axpby(const void* a, const void* b, void* out, float wa, float wb, int64_t numel, sg_dtype dt,
+             sg_stream_t st);
+/* out = x + stddev * N(0,1), counter-based Philox4x32-10 keyed by (seed, element index)
+ * (instance noise, networks/loss.py:122-123). */
+int sg_add_noise(const void* x, void* out, float stddev, uint64_t seed, uint64_t offset, int64_t numel,
+                 sg_dtype dt, sg_stream_t st);
+/* out[n*w_extent + w] = sum_{d,h,c} g[n,d,h,w,c]^2   (the reduce_sum of networks/loss.py:140, quirk Q1:
+ * axes (1,2,3) of NCDHW = c,d,h).  out f32 [n*w], overwritten. */
+int sg_sumsq_ndhwc_keep_w(const void* g, float* out, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
+                          sg_dtype dt, sg_stream_t st);
+/* minibatch_stddev_layer (networks/ops.py:313-325): y[n,d,h,w,c+1] = concat(x, stat[n % (n/group)]) with
+ * stat[m] = mean_{c,d,h,w} sqrt(var_group(x) + 1e-8), group = min(group_size, n), n % group == 0.
+ * workspace: (n/group) floats. */
+int sg_minibatch_stddev_fwd(const void* x, void* y, float* workspace, int32_t n, int64_t vox_per_sample,
+                            int32_t c, int32_t group_size, sg_dtype dt, sg_stream_t st);
+/* dtype conversion between f32 and bf16 buffers (dst dtype = dt_dst). */
+int sg_cast(const void* src, sg_dtype dt_src, void* dst, sg_dtype dt_dst, int64_t numel, sg_stream_t st);
+
+/* ---- optimiser (optimization.py:16,28 tf.train.AdamOptimizer; ExtendedEMA.py:56-59) ------------ */
+/* Fused TF-formulation Adam + EMA over one contiguous f32 range:
+ *   m = b1*m + (1-b1)*g*gscale; v = b2*v + (1-b2)*(g*gscale)^2; p -= lr_t * m / (sqrt(v) + eps);
+ *   if (ema) ema -= (1-ema_decay)*(ema - p)
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller.  g NULL => EMA only. */
+int sg_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t numel, float lr_t,
+                float b1, float b2, float eps, float gscale, float ema_decay, sg_stream_t st);
+/* out[i] = sum of squares of segment i (offsets[i]..offsets[i+1]) of a flat f32 buffer
+ * (tf.norm per gradient + tf.clip_by_global_norm, optimization.py:66-71).  offsets: DEVICE int64[nseg+1]. */
+int sg_segment_sumsq(const float* flat, const int64_t* offsets, float* out, int32_t nseg, sg_stream_t st);
+
+/* ---- opt-in kernel timing (used by bench.py's roofline leg) ------------------------------------- */
+/* When enabled, every sg_conv3d_fwd / sg_conv3d_wgrad launch is bracketed by hipEvents on its stream.
+ * sg_prof_collect synchronises those events and returns, per kind (0 = conv fwd, 1 = wgrad) and per
+ * distinct shape, the launch count, total milliseconds and algorithmic FLOPs. */
+typedef struct {
+  int32_t kind;
+  sg_conv_shape shape;
+  int32_t dtype;
+  int64_t launches;
+  double total_ms;
+  double flops_per_launch;
+} sg_prof_entry;
+int sg_prof_enable(int on);
+int sg_prof_collect(sg_prof_entry* out, int32_t max_entries, int32_t* n_entries);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SARAGAN_HIP_H */

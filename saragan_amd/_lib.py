@@ -1,0 +1,86 @@
+"""ctypes binding of libsaragan_hip.so (C ABI: include/saragan_hip.h).  No fallback: if the shared
+library is missing or a call fails, the product path raises."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsaragan_hip.so')
+
+SG_F32, SG_BF16 = 0, 1
+
+
+class ConvShape(C.Structure):
+    _fields_ = [('n', C.c_int32), ('d', C.c_int32), ('h', C.c_int32), ('w', C.c_int32),
+                ('cin', C.c_int32), ('cout', C.c_int32),
+                ('kd', C.c_int32), ('kh', C.c_int32), ('kw', C.c_int32), ('upsample_in', C.c_int32)]
+
+
+class ConvEpilogue(C.Structure):
+    _fields_ = [('bias', C.c_void_p), ('act', C.c_int32), ('slope', C.c_float), ('pixel_norm', C.c_int32),
+                ('eps', C.c_float), ('pn_scale', C.c_void_p)]
+
+
+class ProfEntry(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('shape', ConvShape), ('dtype', C.c_int32), ('launches', C.c_int64),
+                ('total_ms', C.c_double), ('flops_per_launch', C.c_double)]
+
+
+_p, _i32, _i64, _f, _u64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
+_SHP = C.POINTER(ConvShape)
+
+# name -> (restype, argtypes); every symbol include/saragan_hip.h declares
+SIGNATURES = {
+    'sg_version': (C.c_char_p, []),
+    'sg_error_string': (C.c_char_p, [C.c_int]),
+    'sg_conv3d_packed_bytes': (_sz, [_SHP, C.c_int]),
+    'sg_conv3d_pack_weights': (C.c_int, [_p, _f, C.c_int, _p, _SHP, C.c_int, _p]),
+    'sg_conv3d_fwd': (C.c_int, [_p, _p, _p, _SHP, C.POINTER(ConvEpilogue), C.c_int, _p]),
+    'sg_conv3d_wgrad_workspace': (_sz, [_SHP, C.c_int]),
+    'sg_conv3d_wgrad': (C.c_int, [_p, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
+    'sg_bias_act_fwd': (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _f, C.c_int, _p]),
+    'sg_bias_act_bwd_workspace': (_sz, [_i32]),
+    'sg_bias_act_bwd': (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _f, C.c_int, _p]),
+    'sg_pixel_norm_fwd': (C.c_int, [_p, _p, _p, _i64, _i32, _f, C.c_int, _p]),
+    'sg_pixel_norm_bwd': (C.c_int, [_p, _p, _p, _p, _i64, _i32, C.c_int, _p]),
+    'sg_upscale2x': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
+    'sg_downscale2x': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
+    'sg_axpby': (C.c_int, [_p, _p, _p, _f, _f, _i64, C.c_int, _p]),
+    'sg_add_noise': (C.c_int, [_p, _p, _f, _u64, _u64, _i64, C.c_int, _p]),
+    'sg_sumsq_ndhwc_keep_w': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, C.c_int, _p]),
+    'sg_minibatch_stddev_fwd': (C.c_int, [_p, _p, _p, _i32, _i64, _i32, _i32, C.c_int, _p]),
+    'sg_cast': (C.c_int, [_p, C.c_int, _p, C.c_int, _i64, _p]),
+    'sg_adam_ema': (C.c_int, [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p]),
+    'sg_segment_sumsq': (C.c_int, [_p, _p, _p, _i32, _p]),
+    'sg_prof_enable': (C.c_int, [C.c_int]),
+    'sg_prof_collect': (C.c_int, [C.POINTER(ProfEntry), _i32, C.POINTER(_i32)]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (once) and declares every prototype.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f'{LIB_PATH} not found: build it with `python -m saragan_amd.build` (hipcc, gfx950). '
+            'There is no CPU or PyTorch fallback for the HIP path.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class SgError(RuntimeError):
+    pass
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().sg_error_string(int(rc)).decode()
+        raise SgError(f'{what}: {msg} (code {rc})')

@@ -1,0 +1,180 @@
+// Shared device/host helpers for the gfx950 kernels of libsaragan_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/saragan_hip.h"
+
+typedef __bf16 bf16_t;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+#define SG_LAUNCH_CHECK()                          \
+  do {                                             \
+    hipError_t e__ = hipGetLastError();            \
+    if (e__ != hipSuccess) return (int)e__;        \
+  } while (0)
+
+static inline hipStream_t sg_st(sg_stream_t s) { return (hipStream_t)s; }
+static inline size_t sg_esize(sg_dtype dt) { return dt == SG_BF16 ? 2 : 4; }
+static inline bool sg_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---- exact unsigned division by a small runtime constant (x < 2^16, d < 2^16) -------------------
+struct sg_fastdiv {
+  uint32_t d, m;
+};
+static inline __host__ __device__ sg_fastdiv sg_make_fastdiv(uint32_t d) {
+  sg_fastdiv f;
+  f.d = d;
+  f.m = d <= 1 ? 0u : (uint32_t)((0x100000000ull + d - 1) / d);
+  return f;
+}
+__device__ __forceinline__ uint32_t sg_div(uint32_t x, sg_fastdiv f) {
+  return f.d <= 1 ? x : __umulhi(x, f.m);
+}
+
+template <typename T>
+struct sg_traits;
+template <>
+struct sg_traits<float> {
+  static constexpr int CH = 8;  // elements per 32-byte K chunk
+  __device__ static __forceinline__ float to_f(float v) { return v; }
+  __device__ static __forceinline__ float from_f(float v) { return v; }
+};
+template <>
+struct sg_traits<bf16_t> {
+  static constexpr int CH = 16;
+  __device__ static __forceinline__ float to_f(bf16_t v) { return (float)v; }
+  __device__ static __forceinline__ bf16_t from_f(float v) { return (bf16_t)v; }
+};
+
+// One 32-byte K chunk = (A 16 B/lane) x (B 16 B/lane): bf16 -> one 32x32x16 MFMA, f32 -> four 32x32x2.
+// Within a chunk, lane half h owns elements [h*CH/2, (h+1)*CH/2) of the chunk for both operands.
+template <typename T>
+__device__ __forceinline__ f32x16 sg_mfma_chunk(u32x4 a, u32x4 b, f32x16 c);
+template <>
+__device__ __forceinline__ f32x16 sg_mfma_chunk<bf16_t>(u32x4 a, u32x4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
+                                                 c, 0, 0, 0);
+}
+template <>
+__device__ __forceinline__ f32x16 sg_mfma_chunk<float>(u32x4 a, u32x4 b, f32x16 c) {
+  f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0], bf[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1], bf[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[2], bf[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[3], bf[3], c, 0, 0, 0);
+  return c;
+}
+
+// Tile geometry shared by the conv forward and weight-gradient kernels.  A block owns TN x TD x TH x TW
+// output voxels and stages their (TD+2PD) x (TH+2PH) x (TW+2PW) input halo per sample in LDS.
+struct sg_tile_geom {
+  int32_t N, D, H, W;      // output extent
+  int32_t TN, TD, TH, TW;  // tile extent
+  int32_t nTn, nTd, nTh, nTw;
+  int32_t PD, PH, PW;      // halo per side
+  int32_t HD, HH, HW;      // halo-tile extent
+  int32_t ups;             // 1: input tensor is half resolution (nearest x2 gather)
+  sg_fastdiv fTW, fTH, fTD;        // tile-voxel decomposition
+  sg_fastdiv fHW, fHH, fHD;        // halo-voxel decomposition
+  sg_fastdiv fnTw, fnTh, fnTd;     // block -> tile decomposition
+};
+
+static inline int sg_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+static inline int sg_pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+
+// Picks the tile (powers of two clipped to the extent, TW <= 32, at most `bm` voxels) that stages the
+// fewest halo voxels over the whole tensor; small volumes fold batch samples into the tile (TN > 1).
+static inline sg_tile_geom sg_make_geom(const sg_conv_shape* s, int bm) {
+  sg_tile_geom g;
+  g.N = s->n; g.D = s->d; g.H = s->h; g.W = s->w;
+  g.PD = s->kd / 2; g.PH = s->kh / 2; g.PW = s->kw / 2;
+  double best = 1e300;
+  int bd = 1, bh = 1, bw = 1;
+  const int mw = sg_pow2ceil(s->w) < 32 ? sg_pow2ceil(s->w) : 32;
+  for (int tw = mw; tw >= 1; tw >>= 1)
+    for (int th = 1; th <= sg_pow2ceil(s->h) && tw * th <= bm; th <<= 1)
+      for (int td = 1; td <= sg_pow2ceil(s->d) && tw * th * td <= bm; td <<= 1) {
+        const int cw = tw < s->w ? tw : s->w, chh = th < s->h ? th : s->h, cd = td < s->d ? td : s->d;
+        const double tiles = (double)sg_cdiv(s->w, cw) * sg_cdiv(s->h, chh) * sg_cdiv(s->d, cd);
+        const double halo = (double)(cw + 2 * g.PW) * (chh + 2 * g.PH) * (cd + 2 * g.PD);
+        // staged voxels + a per-tile cost that favours full tiles (fixed barrier/epilogue overhead)
+        const double score = tiles * (halo + 0.25 * bm) - 1e-3 * cw;
+        if (score < best) { best = score; bd = cd; bh = chh; bw = cw; }
+      }
+  g.TW = bw; g.TH = bh; g.TD = bd;
+  int rem = bm / (g.TW * g.TH * g.TD); if (rem < 1) rem = 1;
+  g.TN = s->n < rem ? s->n : rem;
+  g.nTn = sg_cdiv(s->n, g.TN); g.nTd = sg_cdiv(s->d, g.TD);
+  g.nTh = sg_cdiv(s->h, g.TH); g.nTw = sg_cdiv(s->w, g.TW);
+  g.HD = g.TD + 2 * g.PD; g.HH = g.TH + 2 * g.PH; g.HW = g.TW + 2 * g.PW;
+  g.ups = s->upsample_in ? 1 : 0;
+  g.fTW = sg_make_fastdiv(g.TW); g.fTH = sg_make_fastdiv(g.TH); g.fTD = sg_make_fastdiv(g.TD);
+  g.fHW = sg_make_fastdiv(g.HW); g.fHH = sg_make_fastdiv(g.HH); g.fHD = sg_make_fastdiv(g.HD);
+  g.fnTw = sg_make_fastdiv(g.nTw); g.fnTh = sg_make_fastdiv(g.nTh); g.fnTd = sg_make_fastdiv(g.nTd);
+  return g;
+}
+
+struct sg_tile_origin {
+  int32_t n0, d0, h0, w0;
+};
+
+// tile index (< 2^16 per fastdiv contract is checked on the host) -> tile origin
+__device__ __forceinline__ sg_tile_origin sg_tile_of(const sg_tile_geom& g, uint32_t t) {
+  sg_tile_origin o;
+  uint32_t q = sg_div(t, g.fnTw);
+  o.w0 = (int)(t - q * g.nTw) * g.TW;
+  uint32_t q2 = sg_div(q, g.fnTh);
+  o.h0 = (int)(q - q2 * g.nTh) * g.TH;
+  uint32_t q3 = sg_div(q2, g.fnTd);
+  o.d0 = (int)(q2 - q3 * g.nTd) * g.TD;
+  o.n0 = (int)q3 * g.TN;
+  return o;
+}
+
+// Stages channels [c0, c0 + nb*16/sizeof(T)) of the tile's input halo into LDS rows of `rs` bytes
+// (row = halo voxel, zero outside the volume / beyond cin).  16-byte pieces; `vec_ok` says that
+// cin*sizeof(T) is a multiple of 16 so that global 16-byte loads are aligned.
+template <typename T>
+__device__ __forceinline__ void sg_stage_halo(char* lds, int rs, const T* __restrict__ x, const sg_tile_geom& g,
+                                              const sg_tile_origin& o, int cin, int c0, int npieces,
+                                              sg_fastdiv fnp, bool vec_ok, int tid, int nthreads) {
+  constexpr int EPP = 16 / (int)sizeof(T);  // elements per 16-byte piece
+  const int hv = g.TN * g.HD * g.HH * g.HW;
+  const int total = hv * npieces;
+  const int Di = g.ups ? (g.D >> 1) : g.D, Hi = g.ups ? (g.H >> 1) : g.H, Wi = g.ups ? (g.W >> 1) : g.W;
+  for (int it = tid; it < total; it += nthreads) {
+    uint32_t v = sg_div((uint32_t)it, fnp);
+    int piece = it - (int)v * npieces;
+    uint32_t q = sg_div(v, g.fHW);
+    int hw = (int)(v - q * g.HW);
+    uint32_t q2 = sg_div(q, g.fHH);
+    int hh = (int)(q - q2 * g.HH);
+    uint32_t q3 = sg_div(q2, g.fHD);
+    int hd = (int)(q2 - q3 * g.HD);
+    int n = o.n0 + (int)q3;
+    int d = o.d0 + hd - g.PD, h = o.h0 + hh - g.PH, w = o.w0 + hw - g.PW;
+    u32x4 val = {0u, 0u, 0u, 0u};
+    const int c = c0 + piece * EPP;
+    if (n < g.N && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W &&
+        c < cin) {
+      if (g.ups) { d >>= 1; h >>= 1; w >>= 1; }
+      const T* src = x + ((((int64_t)n * Di + d) * Hi + h) * Wi + w) * (int64_t)cin + c;
+      if (vec_ok && c + EPP <= cin) {
+        val = *reinterpret_cast<const u32x4*>(src);
+      } else {
+        T tmp[EPP];
+#pragma unroll
+        for (int e = 0; e < EPP; ++e) tmp[e] = (c + e < cin) ? src[e] : sg_traits<T>::from_f(0.f);
+        val = *reinterpret_cast<u32x4*>(tmp);
+      }
+    }
+    *reinterpret_cast<u32x4*>(lds + (size_t)v * rs + piece * 16) = val;
+  }
+}

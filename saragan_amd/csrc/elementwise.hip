@@ -1,0 +1,634 @@
+// HBM-bound NDHWC kernels of the pgan step (gfx950): bias + LeakyReLU, pixel-norm, nearest x2 up / 2x2x2 sum
+// down, fade-in lerp, instance noise, the per-(n,w) gradient-penalty reduction, minibatch-stddev, casts.
+// Reference ops: SURFGAN_3D/networks/ops.py:130-136,167-192,250-325; networks/loss.py:122-123,140.
+// All of them move 16 bytes per lane per access (8 bf16 / 4 f32) when the channel count allows it and
+// fall back to element-wise access otherwise.
+#include "common.h"
+
+namespace {
+
+template <typename T>
+struct Piece {
+  static constexpr int E = 16 / (int)sizeof(T);
+  float v[E];
+  __device__ __forceinline__ void load(const T* p) {
+    u32x4 raw = *reinterpret_cast<const u32x4*>(p);
+    const T* t = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+    for (int e = 0; e < E; ++e) v[e] = sg_traits<T>::to_f(t[e]);
+  }
+  __device__ __forceinline__ void store(T* p) const {
+    u32x4 raw;
+    T* t = reinterpret_cast<T*>(&raw);
+#pragma unroll
+    for (int e = 0; e < E; ++e) t[e] = sg_traits<T>::from_f(v[e]);
+    *reinterpret_cast<u32x4*>(p) = raw;
+  }
+};
+
+inline int grid_for(int64_t items, int per_block = 256, int cap = 2048) {
+  int64_t b = (items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > cap) b = cap;
+  return (int)b;
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ void bias_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias, T* __restrict__ y,
+                                    int64_t nvox, int c, int act, float slope) {
+  constexpr int E = Piece<T>::E;
+  const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  if (VEC) {
+    const int P = c / E;
+    const int64_t total = nvox * P;
+    for (int64_t i = tid0; i < total; i += stride) {
+      const int c0 = (int)(i % P) * E;
+      Piece<T> p;
+      p.load(x + i * E);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        float v = p.v[e] + (bias ? bias[c0 + e] : 0.f);
+        p.v[e] = act ? fmaxf(v, v * slope) : v;
+      }
+      p.store(y + i * E);
+    }
+  } else {
+    const int64_t total = nvox * c;
+    for (int64_t i = tid0; i < total; i += stride) {
+      float v = sg_traits<T>::to_f(x[i]) + (bias ? bias[(int)(i % c)] : 0.f);
+      y[i] = sg_traits<T>::from_f(act ? fmaxf(v, v * slope) : v);
+    }
+  }
+}
+
+// dx = mask(y) * dy, per-block partial channel sums of dx -> part[block][c].  Thread t of a block owns
+// channel piece (t % P) (P | 256) so partial sums stay in registers; rows are strided by 256/P.
+template <typename T>
+__global__ __launch_bounds__(256) void bias_act_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                               T* __restrict__ dx, float* __restrict__ part,
+                                                               int64_t nvox, int c, float slope) {
+  constexpr int E = Piece<T>::E;
+  __shared__ float red[256 * E];
+  const int P = c / E;            // divides 256
+  const int rows = 256 / P;       // voxel rows per block step
+  const int p = threadIdx.x % P, rr = threadIdx.x / P;
+  float s[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) s[e] = 0.f;
+  for (int64_t v = (int64_t)blockIdx.x * rows + rr; v < nvox; v += (int64_t)gridDim.x * rows) {
+    const int64_t off = v * c + (int64_t)p * E;
+    Piece<T> g;
+    g.load(dy + off);
+    if (y) {
+      Piece<T> yy;
+      yy.load(y + off);
+#pragma unroll
+      for (int e = 0; e < E; ++e) g.v[e] = yy.v[e] >= 0.f ? g.v[e] : g.v[e] * slope;
+    }
+    if (dx) g.store(dx + off);
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[e] += g.v[e];
+  }
+  if (part) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) red[threadIdx.x * E + e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < P) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        float t = 0.f;
+        for (int k = 0; k < rows; ++k) t += red[(k * P + threadIdx.x) * E + e];
+        part[(int64_t)blockIdx.x * c + threadIdx.x * E + e] = t;
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void bias_act_bwd_scalar_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
+                                           float* __restrict__ part, int64_t nvox, int c, float slope) {
+  // generic fallback: one thread per channel column segment; correct for any c, not tuned
+  const int64_t rows_per_block = (nvox + gridDim.x - 1) / gridDim.x;
+  const int64_t v0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t v1 = v0 + rows_per_block < nvox ? v0 + rows_per_block : nvox;
+  for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+    float s = 0.f;
+    for (int64_t v = v0; v < v1; ++v) {
+      float g = sg_traits<T>::to_f(dy[v * c + ch]);
+      if (y) g = sg_traits<T>::to_f(y[v * c + ch]) >= 0.f ? g : g * slope;
+      if (dx) dx[v * c + ch] = sg_traits<T>::from_f(g);
+      s += g;
+    }
+    if (part) part[(int64_t)blockIdx.x * c + ch] = s;
+  }
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int nb, int c) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ch >= c) return;
+  float s = 0.f;
+  for (int b = 0; b < nb; ++b) s += part[(int64_t)b * c + ch];
+  out[ch] = s;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pixel norm: a team of TP lanes (power of two <= 64) owns one voxel; up to 4 pieces per lane.
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a, const T* __restrict__ yv,
+                                                         const float* __restrict__ scale_in, T* __restrict__ out,
+                                                         float* __restrict__ scale_out, int64_t nvox, int c, int tp,
+                                                         float eps) {
+  constexpr int E = Piece<T>::E;
+  const int P = c / E;
+  const int lane_t = threadIdx.x % tp;
+  const int teams = blockDim.x / tp;
+  const float inv_c = 1.f / (float)c;
+  for (int64_t v = (int64_t)blockIdx.x * teams + threadIdx.x / tp; v < nvox; v += (int64_t)gridDim.x * teams) {
+    Piece<T> pa[4], py[4];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = lane_t + k * tp;
+      if (p < P) {
+        pa[k].load(a + v * c + (int64_t)p * E);
+        if (BWD) {
+          py[k].load(yv + v * c + (int64_t)p * E);
+#pragma unroll
+          for (int e = 0; e < E; ++e) s += pa[k].v[e] * py[k].v[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < E; ++e) s += pa[k].v[e] * pa[k].v[e];
+        }
+      }
+    }
+    for (int m = tp >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m);
+    if (BWD) {
+      const float sc = scale_in[v];
+      const float mean = s * inv_c;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int p = lane_t + k * tp;
+        if (p < P) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) pa[k].v[e] = sc * (pa[k].v[e] - py[k].v[e] * mean);
+          pa[k].store(out + v * c + (int64_t)p * E);
+        }
+      }
+    } else {
+      const float sc = rsqrtf(s * inv_c + eps);
+      if (scale_out && lane_t == 0) scale_out[v] = sc;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int p = lane_t + k * tp;
+        if (p < P) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) pa[k].v[e] *= sc;
+          pa[k].store(out + v * c + (int64_t)p * E);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, bool BWD>
+__global__ void pixel_norm_scalar_kernel(const T* __restrict__ a, const T* __restrict__ yv,
+                                         const float* __restrict__ scale_in, T* __restrict__ out,
+                                         float* __restrict__ scale_out, int64_t nvox, int c, float eps) {
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int ch = 0; ch < c; ++ch) {
+      float av = sg_traits<T>::to_f(a[v * c + ch]);
+      s += BWD ? av * sg_traits<T>::to_f(yv[v * c + ch]) : av * av;
+    }
+    if (BWD) {
+      const float sc = scale_in[v], mean = s / (float)c;
+      for (int ch = 0; ch < c; ++ch)
+        out[v * c + ch] = sg_traits<T>::from_f(
+            sc * (sg_traits<T>::to_f(a[v * c + ch]) - sg_traits<T>::to_f(yv[v * c + ch]) * mean));
+    } else {
+      const float sc = rsqrtf(s / (float)c + eps);
+      if (scale_out) scale_out[v] = sc;
+      for (int ch = 0; ch < c; ++ch) out[v * c + ch] = sg_traits<T>::from_f(sg_traits<T>::to_f(a[v * c + ch]) * sc);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ void upscale2x_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int d, int h, int w, int c,
+                                 float gain) {
+  constexpr int E = VEC ? Piece<T>::E : 1;
+  const int P = c / E;
+  const int64_t total = (int64_t)n * (2 * d) * (2 * h) * (2 * w) * P;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i % P);
+    int64_t q = i / P;
+    const int ow = (int)(q % (2 * w)); q /= 2 * w;
+    const int oh = (int)(q % (2 * h)); q /= 2 * h;
+    const int od = (int)(q % (2 * d));
+    const int nn = (int)(q / (2 * d));
+    const int64_t src = ((((int64_t)nn * d + (od >> 1)) * h + (oh >> 1)) * w + (ow >> 1)) * c + (int64_t)p * E;
+    if (VEC) {
+      Piece<T> pc;
+      pc.load(x + src);
+      if (gain != 1.f) {
+#pragma unroll
+        for (int e = 0; e < Piece<T>::E; ++e) pc.v[e] *= gain;
+      }
+      pc.store(y + i * E);
+    } else {
+      y[i] = sg_traits<T>::from_f(sg_traits<T>::to_f(x[src]) * gain);
+    }
+  }
+}
+
+template <typename T, bool VEC>
+__global__ void downscale2x_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int d, int h, int w, int c,
+                                   float gain) {
+  constexpr int E = VEC ? Piece<T>::E : 1;
+  const int P = c / E;
+  const int od = d / 2, oh = h / 2, ow = w / 2;
+  const int64_t total = (int64_t)n * od * oh * ow * P;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i % P);
+    int64_t q = i / P;
+    const int xw = (int)(q % ow); q /= ow;
+    const int xh = (int)(q % oh); q /= oh;
+    const int xd = (int)(q % od);
+    const int nn = (int)(q / od);
+    float s[Piece<T>::E];
+#pragma unroll
+    for (int e = 0; e < Piece<T>::E; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t src =
+          ((((int64_t)nn * d + (2 * xd + (k >> 2))) * h + (2 * xh + ((k >> 1) & 1))) * w + (2 * xw + (k & 1))) * c +
+          (int64_t)p * E;
+      if (VEC) {
+        Piece<T> pc;
+        pc.load(x + src);
+#pragma unroll
+        for (int e = 0; e < Piece<T>::E; ++e) s[e] += pc.v[e];
+      } else {
+        s[0] += sg_traits<T>::to_f(x[src]);
+      }
+    }
+    if (VEC) {
+      Piece<T> o;
+#pragma unroll
+      for (int e = 0; e < Piece<T>::E; ++e) o.v[e] = s[e] * gain;
+      o.store(y + i * E);
+    } else {
+      y[i] = sg_traits<T>::from_f(s[0] * gain);
+    }
+  }
+}
+
+template <typename T>
+__global__ void axpby_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, float wa,
+                             float wb, int64_t numel) {
+  constexpr int E = Piece<T>::E;
+  const int64_t nv = numel / E;
+  const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = tid0; i < nv; i += stride) {
+    Piece<T> pa, pb;
+    pa.load(a + i * E);
+    if (b) {
+      pb.load(b + i * E);
+#pragma unroll
+      for (int e = 0; e < E; ++e) pa.v[e] = wa * pa.v[e] + wb * pb.v[e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < E; ++e) pa.v[e] = wa * pa.v[e];
+    }
+    pa.store(out + i * E);
+  }
+  for (int64_t i = nv * E + tid0; i < numel; i += stride) {
+    float v = wa * sg_traits<T>::to_f(a[i]) + (b ? wb * sg_traits<T>::to_f(b[i]) : 0.f);
+    out[i] = sg_traits<T>::from_f(v);
+  }
+}
+
+// Philox4x32-10 (Salmon et al. 2011), counter = element index / 4, key = seed.
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int rnd = 0; rnd < 10; ++rnd) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+template <typename T>
+__global__ void add_noise_kernel(const T* __restrict__ x, T* __restrict__ out, float stddev, uint64_t seed,
+                                 uint64_t offset, int64_t numel) {
+  const int64_t ngroups = (numel + 3) / 4;
+  for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t ctr = (uint64_t)gi + offset;
+    uint32_t r[4];
+    philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+    float z[4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {  // Box-Muller on two uniform pairs
+      const float u1 = ((float)r[2 * k] + 1.0f) * 2.3283064365386963e-10f;  // (0,1]
+      const float u2 = (float)r[2 * k + 1] * 2.3283064365386963e-10f;
+      const float rad = sqrtf(-2.f * __logf(u1));
+      float sn, cs;
+      __sincosf(6.283185307179586f * u2, &sn, &cs);
+      z[2 * k] = rad * cs;
+      z[2 * k + 1] = rad * sn;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t i = gi * 4 + k;
+      if (i < numel) out[i] = sg_traits<T>::from_f(sg_traits<T>::to_f(x[i]) + stddev * z[k]);
+    }
+  }
+}
+
+// out[n*W + w] += sum over a slab of (d,h) rows and all channels of g^2; threads run along w (coalesced).
+template <typename T>
+__global__ void sumsq_keep_w_kernel(const T* __restrict__ g, float* __restrict__ out, int n, int dh, int w, int c,
+                                    int rows_per_block) {
+  const int nn = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(dh, r0 + rows_per_block);
+  for (int ww = threadIdx.x; ww < w; ww += blockDim.x) {
+    float s = 0.f;
+    for (int rr = r0; rr < r1; ++rr) {
+      const T* p = g + (((int64_t)nn * dh + rr) * w + ww) * c;
+      for (int ch = 0; ch < c; ++ch) {
+        const float v = sg_traits<T>::to_f(p[ch]);
+        s += v * v;
+      }
+    }
+    atomicAdd(out + (int64_t)nn * w + ww, s);
+  }
+}
+
+// minibatch stddev, stage 1: stat[m] = mean over (vox, c) of sqrt(var over the group + 1e-8)
+template <typename T>
+__global__ __launch_bounds__(256) void mbstd_stat_kernel(const T* __restrict__ x, float* __restrict__ stat, int group,
+                                                         int mgroups, int64_t per_sample) {
+  __shared__ float red[256];
+  const int m = blockIdx.y;
+  float s = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * blockDim.x) {
+    float mean = 0.f;
+    for (int gidx = 0; gidx < group; ++gidx) mean += sg_traits<T>::to_f(x[((int64_t)gidx * mgroups + m) * per_sample + i]);
+    mean /= (float)group;
+    float var = 0.f;
+    for (int gidx = 0; gidx < group; ++gidx) {
+      const float dlt = sg_traits<T>::to_f(x[((int64_t)gidx * mgroups + m) * per_sample + i]) - mean;
+      var += dlt * dlt;
+    }
+    s += sqrtf(var / (float)group + 1e-8f);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) {
+    if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(stat + m, red[0] / (float)per_sample);
+}
+
+template <typename T>
+__global__ void mbstd_concat_kernel(const T* __restrict__ x, const float* __restrict__ stat, T* __restrict__ y, int n,
+                                    int64_t vox, int c, int mgroups) {
+  const int64_t total = (int64_t)n * vox * (c + 1);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ch = (int)(i % (c + 1));
+    const int64_t v = i / (c + 1);
+    const int nn = (int)(v / vox);
+    y[i] = ch < c ? x[v * c + ch] : sg_traits<T>::from_f(stat[nn % mgroups]);
+  }
+}
+
+template <typename S, typename D>
+__global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t numel) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = sg_traits<D>::from_f(sg_traits<S>::to_f(src[i]));
+}
+
+int team_size(int P) {
+  int tp = 1;
+  while (tp < P && tp < 64) tp <<= 1;
+  return tp;
+}
+
+}  // namespace
+
+#define SG_DISPATCH(dt, CALL_BF16, CALL_F32) \
+  do {                                       \
+    if ((dt) == SG_BF16) { CALL_BF16; }      \
+    else if ((dt) == SG_F32) { CALL_F32; }   \
+    else return SG_EINVAL;                   \
+  } while (0)
+
+extern "C" int sg_bias_act_fwd(const void* x, const float* bias, void* y, int64_t nvox, int32_t c, int32_t act,
+                               float slope, sg_dtype dt, sg_stream_t st) {
+  if (!x || !y || nvox < 1 || c < 1) return SG_EINVAL;
+  hipStream_t hs = sg_st(st);
+  const int E = dt == SG_BF16 ? 8 : 4;
+  const bool vec = (c % E == 0) && sg_aligned16(x) && sg_aligned16(y);
+  const int64_t items = vec ? nvox * (c / E) : nvox * c;
+  const int blocks = grid_for(items);
+#define L(T, V) hipLaunchKernelGGL((bias_act_fwd_kernel<T, V>), dim3(blocks), dim3(256), 0, hs, (const T*)x, bias, (T*)y, nvox, c, act, slope)
+  if (vec) SG_DISPATCH(dt, L(bf16_t, true), L(float, true));
+  else SG_DISPATCH(dt, L(bf16_t, false), L(float, false));
+#undef L
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+static const int kBwdBlocks = 512;
+extern "C" size_t sg_bias_act_bwd_workspace(int32_t c) { return (size_t)kBwdBlocks * (size_t)(c > 0 ? c : 0) * sizeof(float); }
+
+extern "C" int sg_bias_act_bwd(const void* dy, const void* y, void* dx, float* dbias, void* workspace, int64_t nvox,
+                               int32_t c, float slope, sg_dtype dt, sg_stream_t st) {
+  if (!dy || nvox < 1 || c < 1 || (!dx && !dbias)) return SG_EINVAL;
+  if (dbias && !workspace) return SG_EINVAL;
+  hipStream_t hs = sg_st(st);
+  const int E = dt == SG_BF16 ? 8 : 4;
+  const int P = c / E;
+  const bool vec = (c % E == 0) && P <= 256 && (256 % P == 0) && sg_aligned16(dy) && (!y || sg_aligned16(y)) &&
+                   (!dx || sg_aligned16(dx));
+  float* part = dbias ? reinterpret_cast<float*>(workspace) : nullptr;
+  int blocks;
+  if (vec) {
+    const int rows = 256 / P;
+    blocks = grid_for(nvox, rows, kBwdBlocks);
+#define L(T) hipLaunchKernelGGL((bias_act_bwd_vec_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)dy, (const T*)y, (T*)dx, part, nvox, c, slope)
+    SG_DISPATCH(dt, L(bf16_t), L(float));
+#undef L
+  } else {
+    blocks = grid_for(nvox, 64, kBwdBlocks);
+#define L(T) hipLaunchKernelGGL((bias_act_bwd_scalar_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)dy, (const T*)y, (T*)dx, part, nvox, c, slope)
+    SG_DISPATCH(dt, L(bf16_t), L(float));
+#undef L
+  }
+  SG_LAUNCH_CHECK();
+  if (dbias) {
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, hs, part, dbias, blocks, c);
+    SG_LAUNCH_CHECK();
+  }
+  return SG_OK;
+}
+
+template <bool BWD>
+static int pixel_norm_launch(const void* a, const void* yv, const float* scale_in, void* out, float* scale_out,
+                             int64_t nvox, int32_t c, float eps, sg_dtype dt, hipStream_t hs) {
+  const int E = dt == SG_BF16 ? 8 : 4;
+  const int P = c / E;
+  const bool vec = (c % E == 0) && P <= 256 && sg_aligned16(a) && sg_aligned16(out) && (!yv || sg_aligned16(yv));
+  if (vec) {
+    const int tp = team_size(P);
+    const int teams = 256 / tp;
+    const int blocks = grid_for(nvox, teams, 4096);
+#define L(T) hipLaunchKernelGGL((pixel_norm_kernel<T, BWD>), dim3(blocks), dim3(256), 0, hs, (const T*)a, (const T*)yv, scale_in, (T*)out, scale_out, nvox, c, tp, eps)
+    SG_DISPATCH(dt, L(bf16_t), L(float));
+#undef L
+  } else {
+    const int blocks = grid_for(nvox);
+#define L(T) hipLaunchKernelGGL((pixel_norm_scalar_kernel<T, BWD>), dim3(blocks), dim3(256), 0, hs, (const T*)a, (const T*)yv, scale_in, (T*)out, scale_out, nvox, c, eps)
+    SG_DISPATCH(dt, L(bf16_t), L(float));
+#undef L
+  }
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_pixel_norm_fwd(const void* x, void* y, float* scale, int64_t nvox, int32_t c, float eps,
+                                 sg_dtype dt, sg_stream_t st) {
+  if (!x || !y || nvox < 1 || c < 1) return SG_EINVAL;
+  return pixel_norm_launch<false>(x, nullptr, nullptr, y, scale, nvox, c, eps, dt, sg_st(st));
+}
+
+extern "C" int sg_pixel_norm_bwd(const void* dy, const void* y, const float* scale, void* dx, int64_t nvox,
+                                 int32_t c, sg_dtype dt, sg_stream_t st) {
+  if (!dy || !y || !scale || !dx || nvox < 1 || c < 1) return SG_EINVAL;
+  return pixel_norm_launch<true>(dy, y, scale, dx, nullptr, nvox, c, 0.f, dt, sg_st(st));
+}
+
+extern "C" int sg_upscale2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
+                            float gain, sg_dtype dt, sg_stream_t st) {
+  if (!x || !y || n < 1 || d < 1 || h < 1 || w < 1 || c < 1) return SG_EINVAL;
+  hipStream_t hs = sg_st(st);
+  const int E = dt == SG_BF16 ? 8 : 4;
+  const bool vec = (c % E == 0) && sg_aligned16(x) && sg_aligned16(y);
+  const int64_t items = (int64_t)n * d * h * w * 8 * (vec ? c / E : c);
+  const int blocks = grid_for(items, 256, 4096);
+#define L(T, V) hipLaunchKernelGGL((upscale2x_kernel<T, V>), dim3(blocks), dim3(256), 0, hs, (const T*)x, (T*)y, n, d, h, w, c, gain)
+  if (vec) SG_DISPATCH(dt, L(bf16_t, true), L(float, true));
+  else SG_DISPATCH(dt, L(bf16_t, false), L(float, false));
+#undef L
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_downscale2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
+                              float gain, sg_dtype dt, sg_stream_t st) {
+  if (!x || !y || n < 1 || d < 2 || h < 2 || w < 2 || c < 1 || ((d | h | w) & 1)) return SG_EINVAL;
+  hipStream_t hs = sg_st(st);
+  const int E = dt == SG_BF16 ? 8 : 4;
+  const bool vec = (c % E == 0) && sg_aligned16(x) && sg_aligned16(y);
+  const int64_t items = (int64_t)n * (d / 2) * (h / 2) * (w / 2) * (vec ? c / E : c);
+  const int blocks = grid_for(items, 256, 4096);
+#define L(T, V) hipLaunchKernelGGL((downscale2x_kernel<T, V>), dim3(blocks), dim3(256), 0, hs, (const T*)x, (T*)y, n, d, h, w, c, gain)
+  if (vec) SG_DISPATCH(dt, L(bf16_t, true), L(float, true));
+  else SG_DISPATCH(dt, L(bf16_t, false), L(float, false));
+#undef L
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_axpby(const void* a, const void* b, void* out, float wa, float wb, int64_t numel, sg_dtype dt,
+                        sg_stream_t st) {
+  if (!a || !out || numel < 1) return SG_EINVAL;
+  if (!sg_aligned16(a) || !sg_aligned16(out) || (b && !sg_aligned16(b))) return SG_EALIGN;
+  hipStream_t hs = sg_st(st);
+  const int E = dt == SG_BF16 ? 8 : 4;
+  const int blocks = grid_for(numel / E + 1);
+#define L(T) hipLaunchKernelGGL((axpby_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)a, (const T*)b, (T*)out, wa, wb, numel)
+  SG_DISPATCH(dt, L(bf16_t), L(float));
+#undef L
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_add_noise(const void* x, void* out, float stddev, uint64_t seed, uint64_t offset, int64_t numel,
+                            sg_dtype dt, sg_stream_t st) {
+  if (!x || !out || numel < 1) return SG_EINVAL;
+  hipStream_t hs = sg_st(st);
+  const int blocks = grid_for((numel + 3) / 4);
+#define L(T) hipLaunchKernelGGL((add_noise_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)x, (T*)out, stddev, seed, offset, numel)
+  SG_DISPATCH(dt, L(bf16_t), L(float));
+#undef L
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_sumsq_ndhwc_keep_w(const void* g, float* out, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
+                                     sg_dtype dt, sg_stream_t st) {
+  if (!g || !out || n < 1 || d < 1 || h < 1 || w < 1 || c < 1) return SG_EINVAL;
+  hipStream_t hs = sg_st(st);
+  hipError_t e = hipMemsetAsync(out, 0, (size_t)n * w * sizeof(float), hs);
+  if (e != hipSuccess) return (int)e;
+  const int dh = d * h;
+  int rows = (dh + 63) / 64;
+  if (rows < 1) rows = 1;
+  const int bx = (dh + rows - 1) / rows;
+  const int threads = w >= 256 ? 256 : (w >= 128 ? 128 : 64);
+#define L(T) hipLaunchKernelGGL((sumsq_keep_w_kernel<T>), dim3(bx, n), dim3(threads), 0, hs, (const T*)g, out, n, dh, w, c, rows)
+  SG_DISPATCH(dt, L(bf16_t), L(float));
+#undef L
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_minibatch_stddev_fwd(const void* x, void* y, float* workspace, int32_t n, int64_t vox_per_sample,
+                                       int32_t c, int32_t group_size, sg_dtype dt, sg_stream_t st) {
+  if (!x || !y || !workspace || n < 1 || vox_per_sample < 1 || c < 1 || group_size < 1) return SG_EINVAL;
+  const int group = group_size < n ? group_size : n;
+  if (n % group != 0) return SG_EINVAL;  // tf.reshape at networks/ops.py:317 fails likewise
+  const int mgroups = n / group;
+  hipStream_t hs = sg_st(st);
+  hipError_t e = hipMemsetAsync(workspace, 0, (size_t)mgroups * sizeof(float), hs);
+  if (e != hipSuccess) return (int)e;
+  const int64_t per_sample = vox_per_sample * c;
+  const int bx = grid_for(per_sample, 256, 256);
+#define L(T) hipLaunchKernelGGL((mbstd_stat_kernel<T>), dim3(bx, mgroups), dim3(256), 0, hs, (const T*)x, workspace, group, mgroups, per_sample)
+  SG_DISPATCH(dt, L(bf16_t), L(float));
+#undef L
+  SG_LAUNCH_CHECK();
+  const int blocks = grid_for((int64_t)n * vox_per_sample * (c + 1));
+#define L(T) hipLaunchKernelGGL((mbstd_concat_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)x, workspace, (T*)y, n, vox_per_sample, c, mgroups)
+  SG_DISPATCH(dt, L(bf16_t), L(float));
+#undef L
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_cast(const void* src, sg_dtype dt_src, void* dst, sg_dtype dt_dst, int64_t numel, sg_stream_t st) {
+  if (!src || !dst || numel < 1) return SG_EINVAL;
+  hipStream_t hs = sg_st(st);
+  const int blocks = grid_for(numel);
+  if (dt_src == SG_F32 && dt_dst == SG_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(blocks), dim3(256), 0, hs, (const float*)src, (bf16_t*)dst, numel);
+  else if (dt_src == SG_BF16 && dt_dst == SG_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(blocks), dim3(256), 0, hs, (const bf16_t*)src, (float*)dst, numel);
+  else if (dt_src == SG_F32 && dt_dst == SG_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), dim3(blocks), dim3(256), 0, hs, (const float*)src, (float*)dst, numel);
+  else if (dt_src == SG_BF16 && dt_dst == SG_BF16)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(blocks), dim3(256), 0, hs, (const bf16_t*)src, (bf16_t*)dst, numel);
+  else
+    return SG_EINVAL;
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}

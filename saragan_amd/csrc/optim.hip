@@ -1,0 +1,87 @@
+// Fused TF-formulation Adam + EMA over a flat f32 parameter range, and per-segment sum of squares
+// (gradient norms / global-norm clipping).  Reference: tf.train.AdamOptimizer as called at
+// SURFGAN_3D/optimization.py:16,28; tf.train.ExponentialMovingAverage via ExtendedEMA.py:56-59;
+// tf.norm / tf.clip_by_global_norm at optimization.py:66-71.  One pass: 5 reads + 4 writes of 4 B/param.
+#include "common.h"
+
+namespace {
+
+__global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, float* __restrict__ ema, int64_t numel, float lr_t, float b1,
+                                float b2, float eps, float gscale, float ema_decay) {
+  const int64_t nv = numel / 4;
+  const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  const float omd = 1.f - ema_decay;
+  for (int64_t i = tid0; i < nv; i += stride) {
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
+    if (g) {
+      const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i] * gscale;
+      f32x4 mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+      mm = b1 * mm + (1.f - b1) * gg;
+      vv = b2 * vv + (1.f - b2) * gg * gg;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) pp[e] -= lr_t * mm[e] / (sqrtf(vv[e]) + eps);
+      reinterpret_cast<f32x4*>(m)[i] = mm;
+      reinterpret_cast<f32x4*>(v)[i] = vv;
+      reinterpret_cast<f32x4*>(p)[i] = pp;
+    }
+    if (ema) {
+      f32x4 ee = reinterpret_cast<f32x4*>(ema)[i];
+      ee -= omd * (ee - pp);
+      reinterpret_cast<f32x4*>(ema)[i] = ee;
+    }
+  }
+  for (int64_t i = nv * 4 + tid0; i < numel; i += stride) {
+    float pp = p[i];
+    if (g) {
+      const float gg = g[i] * gscale;
+      const float mm = b1 * m[i] + (1.f - b1) * gg;
+      const float vv = b2 * v[i] + (1.f - b2) * gg * gg;
+      pp -= lr_t * mm / (sqrtf(vv) + eps);
+      m[i] = mm; v[i] = vv; p[i] = pp;
+    }
+    if (ema) ema[i] -= omd * (ema[i] - pp);
+  }
+}
+
+__global__ __launch_bounds__(256) void segment_sumsq_kernel(const float* __restrict__ flat,
+                                                            const int64_t* __restrict__ offsets,
+                                                            float* __restrict__ out) {
+  __shared__ float red[256];
+  const int seg = blockIdx.x;
+  const int64_t b = offsets[seg], e = offsets[seg + 1];
+  float s = 0.f;
+  for (int64_t i = b + threadIdx.x; i < e; i += 256) s += flat[i] * flat[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) {
+    if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[seg] = red[0];
+}
+
+}  // namespace
+
+extern "C" int sg_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t numel, float lr_t,
+                           float b1, float b2, float eps, float gscale, float ema_decay, sg_stream_t st) {
+  if (!p || numel < 1 || (g && (!m || !v)) || (!g && !ema)) return SG_EINVAL;
+  if (!sg_aligned16(p) || (g && (!sg_aligned16(g) || !sg_aligned16(m) || !sg_aligned16(v))) ||
+      (ema && !sg_aligned16(ema)))
+    return SG_EALIGN;
+  int64_t blocks = (numel / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, sg_st(st), p, g, m, v, ema, numel, lr_t,
+                     b1, b2, eps, gscale, ema_decay);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_segment_sumsq(const float* flat, const int64_t* offsets, float* out, int32_t nseg,
+                                sg_stream_t st) {
+  if (!flat || !offsets || !out || nseg < 1) return SG_EINVAL;
+  hipLaunchKernelGGL(segment_sumsq_kernel, dim3(nseg), dim3(256), 0, sg_st(st), flat, offsets, out);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}

@@ -1,0 +1,85 @@
+// hipEvent bracketing of conv launches; off by default.  The only global state of the library.
+#include "prof.h"
+#include <mutex>
+#include <vector>
+#include <string.h>
+
+namespace {
+struct Rec { int kind; sg_conv_shape shape; int dtype; hipEvent_t e0, e1; bool ok; };
+std::mutex g_mu;
+bool g_on = false;
+std::vector<Rec> g_recs;
+const char* kVersion = "saragan_hip 0.1 (gfx950)";
+}  // namespace
+
+bool sg_prof_on() { return g_on; }
+
+void sg_prof_begin(int kind, const sg_conv_shape* s, sg_dtype dt, hipStream_t st, int* slot) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  Rec r; r.kind = kind; r.shape = *s; r.dtype = (int)dt; r.ok = false;
+  if (hipEventCreate(&r.e0) != hipSuccess) { *slot = -1; return; }
+  if (hipEventCreate(&r.e1) != hipSuccess) { (void)hipEventDestroy(r.e0); *slot = -1; return; }
+  (void)hipEventRecord(r.e0, st);
+  g_recs.push_back(r);
+  *slot = (int)g_recs.size() - 1;
+}
+
+void sg_prof_end(int slot, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  bool ok = slot >= 0;
+  int idx = ok ? slot : -1 - slot;
+  if (idx < 0 || idx >= (int)g_recs.size()) return;
+  (void)hipEventRecord(g_recs[idx].e1, st);
+  g_recs[idx].ok = ok;
+}
+
+extern "C" const char* sg_version(void) { return kVersion; }
+
+extern "C" const char* sg_error_string(int code) {
+  switch (code) {
+    case SG_OK: return "ok";
+    case SG_EINVAL: return "invalid argument (shape, null pointer or unsupported combination)";
+    case SG_EWORKSPACE: return "workspace too small";
+    case SG_EALIGN: return "pointer not 16-byte aligned";
+    default: break;
+  }
+  if (code > 0) return hipGetErrorString((hipError_t)code);
+  return "unknown error";
+}
+
+extern "C" int sg_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_on = on != 0;
+  if (!g_on) {
+    for (auto& r : g_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    g_recs.clear();
+  }
+  return SG_OK;
+}
+
+extern "C" int sg_prof_collect(sg_prof_entry* out, int32_t max_entries, int32_t* n_entries) {
+  if (!out || !n_entries || max_entries < 0) return SG_EINVAL;
+  std::lock_guard<std::mutex> lk(g_mu);
+  int n = 0;
+  for (auto& r : g_recs) {
+    float ms = 0.f;
+    bool ok = r.ok && hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess;
+    (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    if (!ok) continue;
+    int j = 0;
+    for (; j < n; ++j)
+      if (out[j].kind == r.kind && out[j].dtype == r.dtype && memcmp(&out[j].shape, &r.shape, sizeof(sg_conv_shape)) == 0) break;
+    if (j == n) {
+      if (n >= max_entries) continue;
+      out[n].kind = r.kind; out[n].shape = r.shape; out[n].dtype = r.dtype; out[n].launches = 0; out[n].total_ms = 0;
+      const sg_conv_shape& s = r.shape;
+      out[n].flops_per_launch = 2.0 * s.n * s.d * s.h * s.w * (double)s.cin * s.cout * s.kd * s.kh * s.kw;
+      ++n;
+    }
+    out[j].launches += 1;
+    out[j].total_ms += ms;
+  }
+  g_recs.clear();
+  *n_entries = n;
+  return SG_OK;
+}

@@ -1,0 +1,489 @@
+"""Differentiable wrappers over the C ABI (include/saragan_hip.h): every op below launches a hand-written
+gfx950 kernel of libsaragan_hip.so on the current torch stream; torch only owns the device buffers and the
+autograd tape.  There is NO fallback: tensors must live on the GPU.
+
+Tensors keep the reference's logical NCDHW shape (SURFGAN_3D/networks/ops.py:150,273) but are stored
+channels-last (torch.channels_last_3d == NDHWC); 2-D tensors [N, F] are NDHWC with one voxel per sample.
+Each backward is itself built from these Functions, so second-order gradients (the gradient penalty of
+networks/loss.py:133-140 differentiates through D's data gradient) work.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import ConvEpilogue, ConvShape, check
+
+_DT = {torch.float32: _lib.SG_F32, torch.bfloat16: _lib.SG_BF16}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f'saragan_amd supports float32 and bfloat16 activations, got {t.dtype}')
+
+
+def _req_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('saragan_amd ops run on the GPU only (no CPU fallback); got a CPU tensor')
+
+
+def ndhwc(x):
+    """Returns x stored as NDHWC (5-D: channels_last_3d; 2-D: row-major)."""
+    if x.dim() == 5:
+        return x.contiguous(memory_format=torch.channels_last_3d)
+    if x.dim() == 2:
+        return x.contiguous()
+    raise ValueError(f'expected a [N,C,D,H,W] or [N,F] tensor, got shape {tuple(x.shape)}')
+
+
+def _dims(x):
+    """-> (n, c, d, h, w) of an NCDHW / [N,F] tensor."""
+    if x.dim() == 5:
+        n, c, d, h, w = x.shape
+        return n, c, d, h, w
+    n, c = x.shape
+    return n, c, 1, 1, 1
+
+
+def _empty_like_shape(x, c_out, spatial=None, dtype=None):
+    n, _, d, h, w = _dims(x)
+    if spatial is not None:
+        d, h, w = spatial
+    dtype = dtype or x.dtype
+    if x.dim() == 5:
+        return torch.empty((n, c_out, d, h, w), device=x.device, dtype=dtype, memory_format=torch.channels_last_3d)
+    return torch.empty((n, c_out), device=x.device, dtype=dtype)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+# ---------------------------------------------------------------------------------------------------
+# raw launches (no autograd)
+# ---------------------------------------------------------------------------------------------------
+def _shape(n, d, h, w, cin, cout, k, ups=False):
+    return ConvShape(n, d, h, w, cin, cout, k[0], k[1], k[2], 1 if ups else 0)
+
+
+def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel_norm=False, eps=1e-8,
+             want_scale=False):
+    """y = epilogue(conv3d(x, coef*w)) with w in DHWIO; `flip` selects the data-gradient weights."""
+    lib = _lib.load()
+    _req_cuda(x, w, bias)
+    x = ndhwc(x)
+    n, cx, d, h, wd = _dims(x)
+    if w.dim() == 2:
+        w = w.reshape(1, 1, 1, *w.shape)
+    kd, kh, kw, wi, wo = w.shape
+    cin, cout = (wo, wi) if flip else (wi, wo)
+    if cx != cin:
+        raise ValueError(f'conv3d: input has {cx} channels, weight expects {cin}')
+    if ups:
+        d, h, wd = 2 * d, 2 * h, 2 * wd
+    shp = _shape(n, d, h, wd, cin, cout, (kd, kh, kw), ups)
+    dt = _dt(x)
+    w32 = w.detach().contiguous().float()
+    wp = torch.empty(lib.sg_conv3d_packed_bytes(C.byref(shp), dt), device=x.device, dtype=torch.uint8)
+    st = _stream()
+    check(lib.sg_conv3d_pack_weights(_ptr(w32), float(coef), 1 if flip else 0, _ptr(wp), C.byref(shp), dt, st),
+          'sg_conv3d_pack_weights')
+    y = _empty_like_shape(x, cout, (d, h, wd))
+    scale = None
+    if pixel_norm and want_scale:
+        scale = torch.empty(n * d * h * wd, device=x.device, dtype=torch.float32)
+    b32 = bias.detach().contiguous().float() if bias is not None else None
+    ep = ConvEpilogue(_ptr(b32), 1 if act else 0, float(slope), 1 if pixel_norm else 0, float(eps), _ptr(scale))
+    check(lib.sg_conv3d_fwd(_ptr(x), _ptr(wp), _ptr(y), C.byref(shp), C.byref(ep), dt, st), 'sg_conv3d_fwd')
+    return y, scale
+
+
+def raw_wgrad(x, dy, k, coef, ups=False):
+    """dw[kd,kh,kw,cin,cout] (f32) = coef * sum_v x[v+tap] (x) dy[v]."""
+    lib = _lib.load()
+    _req_cuda(x, dy)
+    x, dy = ndhwc(x), ndhwc(dy)
+    if x.dtype != dy.dtype:
+        raise TypeError('wgrad: x and dy dtypes differ')
+    n, cin, _, _, _ = _dims(x)
+    n2, cout, d, h, w = _dims(dy)
+    shp = _shape(n, d, h, w, cin, cout, k, ups)
+    dt = _dt(x)
+    ws_bytes = lib.sg_conv3d_wgrad_workspace(C.byref(shp), dt)
+    ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
+    dw = torch.empty((k[0], k[1], k[2], cin, cout), device=x.device, dtype=torch.float32)
+    check(lib.sg_conv3d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), float(coef), _ptr(ws), ws_bytes, C.byref(shp), dt,
+                              _stream()), 'sg_conv3d_wgrad')
+    return dw
+
+
+def raw_bias_act_bwd(dy, y, slope, want_dx=True, want_db=False):
+    lib = _lib.load()
+    dy = ndhwc(dy)
+    n, c, d, h, w = _dims(dy)
+    nvox = n * d * h * w
+    y = ndhwc(y) if y is not None else None
+    dx = torch.empty_like(dy) if want_dx else None
+    db = ws = None
+    if want_db:
+        db = torch.empty(c, device=dy.device, dtype=torch.float32)
+        ws = torch.empty(lib.sg_bias_act_bwd_workspace(c), device=dy.device, dtype=torch.uint8)
+    check(lib.sg_bias_act_bwd(_ptr(dy), _ptr(y), _ptr(dx), _ptr(db), _ptr(ws), nvox, c, float(slope), _dt(dy),
+                              _stream()), 'sg_bias_act_bwd')
+    return dx, db
+
+
+# ---------------------------------------------------------------------------------------------------
+# autograd Functions
+# ---------------------------------------------------------------------------------------------------
+class _Conv(torch.autograd.Function):
+    """Plain conv3d / dense (networks/ops.py:139-150) or, with flip, its data gradient."""
+
+    @staticmethod
+    def forward(ctx, x, w, coef, flip, ups):
+        ctx.save_for_backward(x, w)
+        ctx.coef, ctx.flip, ctx.ups = coef, flip, ups
+        y, _ = raw_conv(x, w, coef, flip, ups)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gw = None
+        k = tuple(w.shape[:3]) if w.dim() == 5 else (1, 1, 1)
+        if ctx.needs_input_grad[0]:
+            gx = _Conv.apply(gy, w, ctx.coef, not ctx.flip, False)
+            if ctx.ups:
+                gx = _Down.apply(gx, 1.0)
+        if ctx.needs_input_grad[1]:
+            if ctx.flip:
+                if ctx.ups:
+                    raise NotImplementedError
+                gw = _Wgrad.apply(gy, x, k, ctx.coef, False)
+            else:
+                gw = _Wgrad.apply(x, gy, k, ctx.coef, ctx.ups)
+            gw = gw.reshape(w.shape)
+        return gx, gw, None, None, None
+
+
+class _Wgrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dy, k, coef, ups):
+        ctx.save_for_backward(x, dy)
+        ctx.k, ctx.coef, ctx.ups = k, coef, ups
+        return raw_wgrad(x, dy, k, coef, ups)
+
+    @staticmethod
+    def backward(ctx, gw):
+        x, dy = ctx.saved_tensors
+        if ctx.ups:
+            raise NotImplementedError('third-order gradient through a fused-upsample conv')
+        gx = gdy = None
+        if ctx.needs_input_grad[0]:
+            gx = _Conv.apply(dy, gw, ctx.coef, True, False)
+        if ctx.needs_input_grad[1]:
+            gdy = _Conv.apply(x, gw, ctx.coef, False, False)
+        return gx, gdy, None, None, None
+
+
+class _ConvBiasAct(torch.autograd.Function):
+    """conv3d -> apply_bias -> act [-> pixel_norm] in one kernel (networks/ops.py:130-150,185-192,308-310)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, coef, ups, act, slope, pixel_norm, eps):
+        y, scale = raw_conv(x, w, coef, False, ups, bias=b, act=act, slope=slope, pixel_norm=pixel_norm, eps=eps,
+                            want_scale=True)
+        ctx.save_for_backward(x, w, y, scale)
+        ctx.cfg = (coef, ups, act, slope, pixel_norm)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y, scale = ctx.saved_tensors
+        coef, ups, act, slope, pixel_norm = ctx.cfg
+        g = gy
+        if pixel_norm:
+            g = _PixelNormBwd.apply(g, y, scale)
+        want_db = ctx.has_b and ctx.needs_input_grad[2]
+        if act or want_db:
+            g, gb = _BiasActBwd.apply(g, y if act else None, slope, want_db)
+        else:
+            gb = None
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _Conv.apply(g, w, coef, True, False)
+            if ups:
+                gx = _Down.apply(gx, 1.0)
+        if ctx.needs_input_grad[1]:
+            k = tuple(w.shape[:3]) if w.dim() == 5 else (1, 1, 1)
+            gw = _Wgrad.apply(x, g, k, coef, ups).reshape(w.shape)
+        return gx, gw, (gb if want_db else None), None, None, None, None, None, None
+
+
+class _BiasActBwd(torch.autograd.Function):
+    """dx = where(y >= 0, dy, slope*dy) (networks/ops.py:177), db = sum_v dx.  Linear in dy: its own
+    backward is the same mask again (networks/ops.py:178)."""
+
+    @staticmethod
+    def forward(ctx, dy, y, slope, want_db):
+        dx, db = raw_bias_act_bwd(dy, y, slope, True, want_db)
+        ctx.save_for_backward(y)
+        ctx.slope = slope
+        if db is None:
+            db = dy.new_zeros(())
+        ctx.mark_non_differentiable(db)
+        return dx, db
+
+    @staticmethod
+    def backward(ctx, gdx, _gdb):
+        (y,) = ctx.saved_tensors
+        g, _ = _BiasActBwd.apply(gdx, y, ctx.slope, False)
+        return g, None, None, None
+
+
+class _BiasAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, b, act, slope):
+        lib = _lib.load()
+        _req_cuda(x, b)
+        x = ndhwc(x)
+        n, c, d, h, w = _dims(x)
+        y = torch.empty_like(x)
+        b32 = b.detach().contiguous().float() if b is not None else None
+        check(lib.sg_bias_act_fwd(_ptr(x), _ptr(b32), _ptr(y), n * d * h * w, c, 1 if act else 0, float(slope),
+                                  _dt(x), _stream()), 'sg_bias_act_fwd')
+        ctx.save_for_backward(y)
+        ctx.act, ctx.slope, ctx.has_b = act, slope, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        want_db = ctx.has_b and ctx.needs_input_grad[1]
+        g, gb = _BiasActBwd.apply(gy, y if ctx.act else None, ctx.slope, want_db)
+        return g, (gb if want_db else None), None, None
+
+
+class _PixelNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        lib = _lib.load()
+        _req_cuda(x)
+        x = ndhwc(x)
+        n, c, d, h, w = _dims(x)
+        y = torch.empty_like(x)
+        scale = torch.empty(n * d * h * w, device=x.device, dtype=torch.float32)
+        check(lib.sg_pixel_norm_fwd(_ptr(x), _ptr(y), _ptr(scale), n * d * h * w, c, float(eps), _dt(x), _stream()),
+              'sg_pixel_norm_fwd')
+        ctx.save_for_backward(y, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, scale = ctx.saved_tensors
+        return _PixelNormBwd.apply(gy, y, scale), None
+
+
+class _PixelNormBwd(torch.autograd.Function):
+    """dx = scale * (dy - y * mean_c(dy*y)).  Only the generator uses pixel_norm and nothing differentiates
+    its gradient a second time, so this node is once-differentiable."""
+
+    @staticmethod
+    def forward(ctx, gy, y, scale):
+        lib = _lib.load()
+        gy, y = ndhwc(gy), ndhwc(y)
+        n, c, d, h, w = _dims(gy)
+        dx = torch.empty_like(gy)
+        check(lib.sg_pixel_norm_bwd(_ptr(gy), _ptr(y), _ptr(scale), _ptr(dx), n * d * h * w, c, _dt(gy), _stream()),
+              'sg_pixel_norm_bwd')
+        return dx
+
+    @staticmethod
+    def backward(ctx, g):
+        raise NotImplementedError('second-order gradient through pixel_norm is not part of the pgan step')
+
+
+class _Up(torch.autograd.Function):
+    """y = gain * nearest_x2(x) (upscale3d / avg_unpool3d, networks/ops.py:250-262,276-289)."""
+
+    @staticmethod
+    def forward(ctx, x, gain):
+        lib = _lib.load()
+        _req_cuda(x)
+        x = ndhwc(x)
+        n, c, d, h, w = _dims(x)
+        y = _empty_like_shape(x, c, (2 * d, 2 * h, 2 * w))
+        check(lib.sg_upscale2x(_ptr(x), _ptr(y), n, d, h, w, c, float(gain), _dt(x), _stream()), 'sg_upscale2x')
+        ctx.gain = gain
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        return _Down.apply(gy, ctx.gain), None
+
+
+class _Down(torch.autograd.Function):
+    """y = gain * sum of each 2x2x2 block (gain 1/8: downscale3d, networks/ops.py:265-273,292-305)."""
+
+    @staticmethod
+    def forward(ctx, x, gain):
+        lib = _lib.load()
+        _req_cuda(x)
+        x = ndhwc(x)
+        n, c, d, h, w = _dims(x)
+        y = _empty_like_shape(x, c, (d // 2, h // 2, w // 2))
+        check(lib.sg_downscale2x(_ptr(x), _ptr(y), n, d, h, w, c, float(gain), _dt(x), _stream()), 'sg_downscale2x')
+        ctx.gain = gain
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        return _Up.apply(gy, ctx.gain), None
+
+
+class _Axpby(torch.autograd.Function):
+    """out = wa*a + wb*b (fade-in lerp, pgan/generator.py:100-101, pgan/discriminator.py:105)."""
+
+    @staticmethod
+    def forward(ctx, a, b, wa, wb):
+        lib = _lib.load()
+        _req_cuda(a, b)
+        a = ndhwc(a)
+        if b is not None:
+            b = ndhwc(b)
+            if b.shape != a.shape or b.dtype != a.dtype:
+                raise ValueError('lerp operands differ in shape or dtype')
+        out = torch.empty_like(a)
+        check(lib.sg_axpby(_ptr(a), _ptr(b), _ptr(out), float(wa), float(wb), a.numel(), _dt(a), _stream()),
+              'sg_axpby')
+        ctx.wa, ctx.wb, ctx.has_b = wa, wb, b is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ga = _Axpby.apply(g, None, ctx.wa, 0.0) if ctx.needs_input_grad[0] else None
+        gb = _Axpby.apply(g, None, ctx.wb, 0.0) if (ctx.has_b and ctx.needs_input_grad[1]) else None
+        return ga, gb, None, None
+
+
+class _AddNoise(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, stddev, seed, offset):
+        lib = _lib.load()
+        _req_cuda(x)
+        x = ndhwc(x)
+        out = torch.empty_like(x)
+        check(lib.sg_add_noise(_ptr(x), _ptr(out), float(stddev), int(seed), int(offset), x.numel(), _dt(x),
+                               _stream()), 'sg_add_noise')
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None, None
+
+
+class _SumsqKeepW(torch.autograd.Function):
+    """out[n, w] = sum_{c,d,h} g^2: tf.reduce_sum(tf.square(g), (1,2,3)) on NCDHW (networks/loss.py:140)."""
+
+    @staticmethod
+    def forward(ctx, g):
+        lib = _lib.load()
+        _req_cuda(g)
+        g = ndhwc(g)
+        n, c, d, h, w = _dims(g)
+        out = torch.empty((n, w), device=g.device, dtype=torch.float32)
+        check(lib.sg_sumsq_ndhwc_keep_w(_ptr(g), _ptr(out), n, d, h, w, c, _dt(g), _stream()),
+              'sg_sumsq_ndhwc_keep_w')
+        ctx.save_for_backward(g)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (g,) = ctx.saved_tensors
+        n, w = gout.shape
+        return (2.0 * gout.reshape(n, 1, 1, 1, w)).to(g.dtype) * g
+
+
+# ---------------------------------------------------------------------------------------------------
+# public functional API
+# ---------------------------------------------------------------------------------------------------
+def conv3d(x, w, coef=1.0, bias=None, act=False, slope=0.2, pixel_norm=False, eps=1e-8, upsample_in=False,
+           fuse=True):
+    """conv3d (+ optional fused nearest-x2 of the input, bias, LeakyReLU, pixel-norm)."""
+    if bias is None and not act and not pixel_norm:
+        return _Conv.apply(x, w, coef, False, upsample_in)
+    cout = w.shape[-1]
+    if fuse and (not pixel_norm or cout <= 128):
+        return _ConvBiasAct.apply(x, w, bias, coef, upsample_in, act, slope, pixel_norm, eps)
+    y = _Conv.apply(x, w, coef, False, upsample_in)
+    y = _BiasAct.apply(y, bias, act, slope)
+    return _PixelNorm.apply(y, eps) if pixel_norm else y
+
+
+def bias_act(x, bias, act=False, slope=0.2):
+    return _BiasAct.apply(x, bias, act, slope)
+
+
+def pixel_norm(x, eps=1e-8):
+    return _PixelNorm.apply(x, eps)
+
+
+def upscale2x(x, gain=1.0):
+    return _Up.apply(x, gain)
+
+
+def downscale2x(x, gain=0.125):
+    return _Down.apply(x, gain)
+
+
+def lerp(a, b, wa, wb):
+    return _Axpby.apply(a, b, wa, wb)
+
+
+def add_noise(x, stddev, seed, offset=0):
+    return _AddNoise.apply(x, stddev, seed, offset)
+
+
+def sumsq_keep_w(g):
+    return _SumsqKeepW.apply(g)
+
+
+def minibatch_stddev(x, group_size=4):
+    """networks/ops.py:313-325 (forward only: the layer is disabled in pgan, pgan/discriminator.py:50)."""
+    lib = _lib.load()
+    _req_cuda(x)
+    x = ndhwc(x)
+    n, c, d, h, w = _dims(x)
+    g = min(group_size, n)
+    if n % g != 0:
+        raise ValueError(f'minibatch_stddev_layer: batch {n} not divisible by group {g}')
+    y = _empty_like_shape(x, c + 1)
+    ws = torch.empty(n // g, device=x.device, dtype=torch.float32)
+    check(lib.sg_minibatch_stddev_fwd(_ptr(x), _ptr(y), _ptr(ws), n, d * h * w, c, group_size, _dt(x), _stream()),
+          'sg_minibatch_stddev_fwd')
+    return y
+
+
+def adam_ema_(p, g, m, v, ema, lr, beta1, beta2, step, eps=1e-8, gscale=1.0, ema_decay=0.99):
+    """In-place fused TF-Adam + EMA over flat f32 buffers."""
+    lib = _lib.load()
+    _req_cuda(p, g, m, v, ema)
+    lr_t = lr * math.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step) if g is not None else 0.0
+    check(lib.sg_adam_ema(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(ema), p.numel(), float(lr_t), float(beta1),
+                          float(beta2), float(eps), float(gscale), float(ema_decay), _stream()), 'sg_adam_ema')
+
+
+def segment_sumsq(flat, offsets_dev, nseg):
+    lib = _lib.load()
+    out = torch.empty(nseg, device=flat.device, dtype=torch.float32)
+    check(lib.sg_segment_sumsq(_ptr(flat), _ptr(offsets_dev), _ptr(out), nseg, _stream()), 'sg_segment_sumsq')
+    return out

@@ -1,0 +1,168 @@
+"""Mirror of SURFGAN_3D/networks/loss.py: forward_generator / forward_discriminator / forward_simultaneous with
+the reference's signatures and return tuples.  Random draws go through a RandomSource so that parity tests can
+inject z, both noise tensors and gamma (TF and torch RNG streams cannot be matched); by default z/gamma come from
+the torch CUDA generator and the instance noise from the library's Philox kernel (sg_add_noise)."""
+import torch
+import torch.nn.functional as TF
+
+from .. import functional as F
+from ..varstore import compute_dtype
+
+
+class RandomSource:
+    """Default randomness: device-side draws.  Counters make every call use fresh Philox offsets."""
+
+    def __init__(self, seed=0, device='cuda'):
+        self.seed = int(seed)
+        self.calls = 0
+        self.gen = torch.Generator(device=device).manual_seed(self.seed)
+
+    def latent(self, n, latent_dim, device):
+        return torch.randn(n, latent_dim, device=device, generator=self.gen)
+
+    def gamma(self, n, device):
+        return torch.rand(n, 1, 1, 1, 1, device=device, generator=self.gen)
+
+    def add_noise(self, x, stddev, tag):
+        self.calls += 1
+        return F.add_noise(x, stddev, self.seed, offset=self.calls << 40)
+
+
+class InjectedRandom(RandomSource):
+    """Replays stored tensors: keys z, noise_real, noise_fake, gamma (oracle.pgan_oracle.draw_randomness)."""
+
+    def __init__(self, tensors):
+        self.t = tensors
+
+    def latent(self, n, latent_dim, device):
+        return self.t['z'].to(device)
+
+    def gamma(self, n, device):
+        return self.t['gamma'].to(device)
+
+    def add_noise(self, x, stddev, tag):
+        noise = self.t[tag].to(x.device, x.dtype)
+        return F.lerp(x, noise.contiguous(memory_format=torch.channels_last_3d), 1.0, float(stddev))
+
+
+_RANDOM = {'src': None}
+
+
+def set_random_source(src):
+    _RANDOM['src'] = src
+
+
+def _rng(device):
+    if _RANDOM['src'] is None:
+        _RANDOM['src'] = RandomSource(0, device)
+    return _RANDOM['src']
+
+
+def _img(x):
+    """real images -> compute dtype, NDHWC."""
+    return x.to(compute_dtype()).contiguous(memory_format=torch.channels_last_3d)
+
+
+def forward_generator(generator, discriminator, real_image_input, latent_dim, alpha, phase, base_shape,
+                      kernel_spec, filter_spec, activation, leakiness, loss_fn, noise_stddev, is_reuse=False):
+    """networks/loss.py:4-39."""
+    rng = _rng(real_image_input.device)
+    z = rng.latent(real_image_input.shape[0], latent_dim, real_image_input.device)
+    gen_sample = generator(z, alpha, phase, base_shape, activation=activation, kernel_spec=kernel_spec,
+                           filter_spec=filter_spec, param=leakiness, is_reuse=is_reuse)
+    real_image_input = rng.add_noise(_img(real_image_input), noise_stddev, 'noise_real')  # drawn as in the reference
+    gen_sample_noisy = rng.add_noise(gen_sample, noise_stddev, 'noise_fake')
+    disc_fake_g = discriminator(gen_sample_noisy, alpha, phase, latent_dim=latent_dim, activation=activation,
+                                kernel_spec=kernel_spec, filter_spec=filter_spec, param=leakiness,
+                                is_reuse=is_reuse).float()
+    if loss_fn == 'wgan':
+        gen_loss = -torch.mean(disc_fake_g)
+    elif loss_fn == 'logistic':
+        gen_loss = torch.mean(TF.softplus(-disc_fake_g))
+    else:
+        raise ValueError(f"Unknown loss function: {loss_fn}")
+    return gen_sample, gen_loss
+
+
+def _gradient_slopes_sq(discriminator, interpolates, alpha, phase, latent_dim, activation, kernel_spec, filter_spec,
+                        leakiness, keep_w):
+    """d D(x)/dx at the interpolates with a differentiable graph (tf.gradients at loss.py:74-77 / :136-139),
+    then sum of squares over (c,d,h) [keep_w, quirk Q1] or over (c,d,h,w)."""
+    interpolates = interpolates.detach().requires_grad_(True)
+    d_int = discriminator(interpolates, alpha, phase, latent_dim=latent_dim, is_reuse=True, activation=activation,
+                          kernel_spec=kernel_spec, filter_spec=filter_spec, param=leakiness)
+    (gradients,) = torch.autograd.grad(d_int, interpolates, grad_outputs=torch.ones_like(d_int), create_graph=True)
+    ss = F.sumsq_keep_w(gradients)          # [N, W] f32
+    return ss if keep_w else ss.sum(dim=1)
+
+
+def forward_discriminator(generator, discriminator, real_image_input, latent_dim, alpha, phase, base_shape,
+                          kernel_spec, filter_spec, activation, leakiness, loss_fn, gp_weight, noise_stddev,
+                          is_reuse=False):
+    """networks/loss.py:42-98 (gradient penalty over axes (1,2,3,4), loss.py:79)."""
+    rng = _rng(real_image_input.device)
+    z = rng.latent(real_image_input.shape[0], latent_dim, real_image_input.device)
+    with torch.no_grad():   # every use of gen_sample in this function sits behind tf.stop_gradient
+        gen_sample = generator(z, alpha, phase, base_shape, activation=activation, kernel_spec=kernel_spec,
+                               filter_spec=filter_spec, param=leakiness, is_reuse=is_reuse)
+    real_image_input = rng.add_noise(_img(real_image_input), noise_stddev, 'noise_real')
+    gen_sample_noisy = rng.add_noise(gen_sample, noise_stddev, 'noise_fake')
+    net = dict(latent_dim=latent_dim, activation=activation, kernel_spec=kernel_spec, filter_spec=filter_spec,
+               param=leakiness)
+    disc_fake_d = discriminator(gen_sample_noisy.detach(), alpha, phase, **net).float()
+    disc_real = discriminator(real_image_input, alpha, phase, is_reuse=True, **net).float()
+    gamma = rng.gamma(real_image_input.shape[0], real_image_input.device).to(real_image_input.dtype)
+    interpolates = gamma * real_image_input + (1 - gamma) * gen_sample_noisy.detach()
+    slopes = torch.sqrt(_gradient_slopes_sq(discriminator, interpolates, alpha, phase, latent_dim, activation,
+                                            kernel_spec, filter_spec, leakiness, keep_w=False))
+    if loss_fn == 'wgan':
+        gradient_penalty = (slopes - 1) ** 2
+        gp_loss = gp_weight * gradient_penalty
+        disc_loss = disc_fake_d - disc_real
+        drift_loss = 1e-3 * disc_real ** 2
+        disc_loss = torch.mean(disc_loss + gp_loss + drift_loss)   # [N,1] + [N] broadcasts as in TF
+    elif loss_fn == 'logistic':
+        gradient_penalty = torch.mean(slopes ** 2)
+        gp_loss = gp_weight * gradient_penalty
+        disc_loss = torch.mean(TF.softplus(disc_fake_d)) + torch.mean(TF.softplus(-disc_real))
+        disc_loss = disc_loss + gp_loss
+    else:
+        raise ValueError(f"Unknown loss function: {loss_fn}")
+    return disc_loss, gp_loss
+
+
+def forward_simultaneous(generator, discriminator, real_image_input, latent_dim, alpha, phase, base_shape,
+                         kernel_spec, filter_spec, activation, leakiness, loss_fn, gp_weight, noise_stddev,
+                         conditioning=None):
+    """networks/loss.py:101-165, including quirk Q1 (slopes keeps the W axis: loss.py:140)."""
+    rng = _rng(real_image_input.device)
+    z = rng.latent(real_image_input.shape[0], latent_dim, real_image_input.device)
+    gen_sample = generator(z, alpha, phase, base_shape, activation=activation, kernel_spec=kernel_spec,
+                           filter_spec=filter_spec, param=leakiness, conditioning=conditioning)
+    real_image_input = rng.add_noise(_img(real_image_input), noise_stddev, 'noise_real')
+    gen_sample_noisy = rng.add_noise(gen_sample, noise_stddev, 'noise_fake')
+    net = dict(latent_dim=latent_dim, activation=activation, kernel_spec=kernel_spec, filter_spec=filter_spec,
+               param=leakiness, conditioning=conditioning)
+    disc_fake_d = discriminator(gen_sample_noisy.detach(), alpha, phase, **net).float()
+    disc_real = discriminator(real_image_input, alpha, phase, is_reuse=True, **net).float()
+    gamma = rng.gamma(real_image_input.shape[0], real_image_input.device).to(real_image_input.dtype)
+    interpolates = gamma * real_image_input + (1 - gamma) * gen_sample_noisy.detach()
+    slopes = torch.sqrt(_gradient_slopes_sq(discriminator, interpolates, alpha, phase, latent_dim, activation,
+                                            kernel_spec, filter_spec, leakiness, keep_w=True))
+    disc_fake_g = discriminator(gen_sample_noisy, alpha, phase, is_reuse=True, **net).float()
+    if loss_fn == 'wgan':
+        gradient_penalty = (slopes - 1) ** 2
+        gp_loss = gp_weight * gradient_penalty
+        disc_loss = disc_fake_d - disc_real
+        drift_loss = 1e-3 * disc_real ** 2
+        disc_loss = torch.mean(disc_loss + gp_loss + drift_loss)
+        gen_loss = -torch.mean(disc_fake_g)
+    elif loss_fn == 'logistic':
+        gradient_penalty = torch.mean(slopes ** 2)
+        gp_loss = gp_weight * gradient_penalty
+        disc_loss = torch.mean(TF.softplus(disc_fake_d)) + torch.mean(TF.softplus(-disc_real))
+        disc_loss = disc_loss + gp_loss
+        gen_loss = torch.mean(TF.softplus(-disc_fake_g))
+    else:
+        raise ValueError(f"Unknown loss function: {loss_fn}")
+    return gen_loss, disc_loss, gp_loss, gen_sample

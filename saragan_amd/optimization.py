@@ -1,0 +1,382 @@
+"""Mirror of SURFGAN_3D/optimization.py: get_optimizer, minimize_with_clipping, optimize_step (same argument
+order, same 20-tuple return order, optimization.py:221-224) and lr_update, for an eager runtime.
+
+The reference builds TF1 graph ops and runs them with `sess.run(fetches, feed_dict)`.  Here optimize_step
+returns lightweight handles bound to a StepGraph; `Session.run([...handles...], feed_dict={real_image_input:
+batch})` executes ONE pass of the hot path for exactly the requested fetches: forward (4 discriminator passes,
+gradient penalty), backward, gradient all-reduce (if the optimizer is wrapped by
+parallel.DistributedOptimizer), optional global-norm clipping, and the fused TF-Adam(+EMA) kernel."""
+import math
+
+import numpy as np
+import torch
+
+from . import functional as F
+from .networks.loss import forward_discriminator, forward_generator, forward_simultaneous
+from .networks.ops import Op, ScalarVariable
+from .networks.pgan.variables import pgan_variable_shapes
+from .varstore import current_store, use_store
+
+
+# ----------------------------------------------------------------------------------------------------
+# optimizers (tf.train.* as used at optimization.py:16-37)
+# ----------------------------------------------------------------------------------------------------
+class _Optimizer:
+    def __init__(self, learning_rate):
+        self.lr = learning_rate
+        self.t = 0
+        self.state = {}          # prefix -> dict of flat state buffers
+        self.distributed = None  # set by parallel.DistributedOptimizer
+
+    def lr_value(self):
+        return float(self.lr.eval()) if isinstance(self.lr, ScalarVariable) else float(self.lr)
+
+    def _slots(self, prefix, flat, names):
+        st = self.state.get(prefix)
+        if st is None or st['total'] != flat['total']:
+            st = {n: torch.zeros_like(flat['param']) for n in names}
+            st['total'] = flat['total']
+            self.state[prefix] = st
+        return st
+
+
+class AdamOptimizer(_Optimizer):
+    """tf.train.AdamOptimizer(learning_rate, beta1, beta2, epsilon=1e-8): SURVEY Appendix B."""
+
+    def __init__(self, learning_rate, beta1=0.9, beta2=0.999, epsilon=1e-8):
+        super().__init__(learning_rate)
+        self.beta1, self.beta2, self.epsilon = float(beta1), float(beta2), float(epsilon)
+
+    def apply(self, prefix, flat, ranges, gscale, ema_flat, ema_decay):
+        st = self._slots(prefix, flat, ('m', 'v'))
+        self.t += 1
+        lr = self.lr_value()
+        for (o, n) in ranges:
+            F.adam_ema_(flat['param'][o:o + n], flat['grad'][o:o + n], st['m'][o:o + n], st['v'][o:o + n],
+                        None if ema_flat is None else ema_flat[o:o + n], lr, self.beta1, self.beta2, self.t,
+                        self.epsilon, gscale, ema_decay)
+
+
+class GradientDescentOptimizer(_Optimizer):
+    """tf.train.GradientDescentOptimizer: p -= lr * g (sg_axpby on the flat f32 range)."""
+
+    def apply(self, prefix, flat, ranges, gscale, ema_flat, ema_decay):
+        self.t += 1
+        lr = self.lr_value()
+        for (o, n) in ranges:
+            p, g = flat['param'][o:o + n], flat['grad'][o:o + n]
+            F._lib.check(F._lib.load().sg_axpby(F._ptr(p), F._ptr(g), F._ptr(p), 1.0, -lr * gscale, n, F._lib.SG_F32,
+                                                F._stream()), 'sg_axpby')
+            if ema_flat is not None:
+                F.adam_ema_(p, None, None, None, ema_flat[o:o + n], 0.0, 0.0, 0.0, 1, ema_decay=ema_decay)
+
+
+def get_optimizer(d_lr, g_lr, args):
+    """optimization.py:6-45.  Adam and SGD are implemented on the HIP path; Momentum/Adadelta raise."""
+    def make(kind, lr, b1, b2):
+        if kind == 'Adam':
+            return AdamOptimizer(learning_rate=lr, beta1=b1, beta2=b2)
+        elif kind == 'SGD':
+            return GradientDescentOptimizer(learning_rate=lr)
+        elif kind in ('Adadelta', 'Momentum'):
+            raise NotImplementedError(f'optimizer {kind} has no HIP kernel yet (Adam is the reference default)')
+        print(f"ERROR: optimizer argument {kind} not recognized or implemented")
+        raise NotImplementedError
+    optimizer_gen = make(args.optimizer, g_lr, args.adam_beta1, args.adam_beta2)
+    optimizer_disc = make(args.d_optimizer, d_lr, args.d_adam_beta1, args.d_adam_beta2)
+    return optimizer_gen, optimizer_disc
+
+
+# ----------------------------------------------------------------------------------------------------
+# handles
+# ----------------------------------------------------------------------------------------------------
+class Placeholder:
+    """tf.placeholder(shape, dtype): key of feed_dict (optuna_objective.py:147)."""
+
+    def __init__(self, shape, dtype=torch.float32, name='real_image_input'):
+        self.shape, self.dtype, self.name = list(shape), dtype, name
+
+
+class Fetch:
+    def __init__(self, graph, key, net=None, freeze=False):
+        self.graph, self.key, self.net, self.freeze = graph, key, net, freeze
+
+    def __repr__(self):
+        return f'<Fetch {self.key}{"" if self.net is None else ":" + self.net}{"/freeze" if self.freeze else ""}>'
+
+
+class VarRef:
+    """What the reference's `variables` lists hold: something with a TF-style .name."""
+
+    def __init__(self, name):
+        self.name = name + ':0'
+        self.key = name
+
+    def __repr__(self):
+        return f'<Variable {self.name}>'
+
+
+def _key(v):
+    n = v if isinstance(v, str) else getattr(v, 'key', None) or v.name
+    return n[:-2] if n.endswith(':0') else n
+
+
+def minimize_with_clipping(optimizer, loss, var_list, clipping):
+    """optimization.py:47-75 -> (train_op, gradients, variables, max_norm) as deferred handles."""
+    graph = loss.graph
+    net = 'generator' if loss.key == 'gen_loss' else 'discriminator'
+    names = [_key(v) for v in var_list]
+    tid = graph.add_train(net, optimizer, names, clipping)
+    return (Fetch(graph, 'train', tid), Fetch(graph, 'gradients', tid), [VarRef(n) for n in names],
+            Fetch(graph, 'max_norm', tid))
+
+
+class StepGraph:
+    """Everything optimize_step was told, plus the machinery to execute it."""
+
+    def __init__(self, store, cfg):
+        self.store, self.cfg = store, cfg
+        self.trains = []       # dicts: net, optimizer, names, clipping
+        self.ema = None        # ExtendedEMA fused into the optimiser launches
+        self.last = {}
+        self.flat_ready = False
+        self.allreduce = None  # parallel.GradientAllReducer
+        self.world = 1
+
+    def add_train(self, net, optimizer, names, clipping):
+        self.trains.append(dict(net=net, optimizer=optimizer, names=names, clipping=bool(clipping)))
+        return len(self.trains) - 1
+
+    # -- flat buffers: frozen (previous-phase) variables first, new ones last -------------------------
+    def _ensure_flat(self):
+        if self.flat_ready:
+            return
+        fz = set(self.cfg['freeze_names'] or [])
+        for prefix in ('generator/', 'discriminator/'):
+            names = self.store.names(prefix)
+            order = [n for n in names if n in fz] + [n for n in names if n not in fz]
+            self.store.flatten(prefix, order)
+        self.flat_ready = True
+
+    def _ranges(self, prefix, names):
+        """Contiguous (offset, length) runs in the flat buffer covering `names` (padding included)."""
+        offs = self.store.flat[prefix]['offsets']
+        want = set(names)
+        runs, cur = [], None
+        for k, (o, n) in offs.items():
+            npad = (n + 3) // 4 * 4
+            if k in want:
+                if cur is not None and cur[0] + cur[1] == o:
+                    cur[1] += npad
+                else:
+                    if cur is not None:
+                        runs.append(tuple(cur))
+                    cur = [o, npad]
+        if cur is not None:
+            runs.append(tuple(cur))
+        return runs
+
+    # -- execution ----------------------------------------------------------------------------------
+    def run(self, fetches, feed):
+        c = self.cfg
+        self._ensure_flat()
+        train_ids = sorted({f.net for f in fetches if f.key in ('train', 'gradients', 'max_norm')})
+        want_train = {f.net for f in fetches if f.key == 'train'}
+        self._wanted = {(f.key, f.net) for f in fetches}
+        real = feed
+        out = {}
+        with use_store(self.store), torch.enable_grad():
+            alpha = float(c['alpha'].eval()) if isinstance(c['alpha'], ScalarVariable) else float(c['alpha'])
+            net_args = (c['latent_dim'], alpha, c['phase'], c['base_shape'], c['kernel_spec'], c['filter_spec'],
+                        c['activation'], c['leakiness'], c['loss_fn'])
+            if c['optim_strategy'] == 'simultaneous':
+                gen_loss, disc_loss, gp_loss, gen_sample = forward_simultaneous(
+                    c['generator'], c['discriminator'], real, *net_args, c['gp_weight'], c['noise_stddev'])
+                out.update(gen_loss=gen_loss, disc_loss=disc_loss, gp_loss=gp_loss, gen_sample=gen_sample)
+                pend = []
+                for tid in train_ids:           # both gradients at the pre-step weights (optimization.py:128-163)
+                    pend.append((tid, self._backward(tid, out)))
+                for tid, info in pend:
+                    self._finish(tid, info, out, apply=tid in want_train)
+            else:                               # alternate: D step, then G forward on the updated D
+                d_ids = [t for t in train_ids if self.trains[t]['net'] == 'discriminator']
+                g_ids = [t for t in train_ids if self.trains[t]['net'] == 'generator']
+                disc_loss, gp_loss = forward_discriminator(c['generator'], c['discriminator'], real, *net_args,
+                                                           c['gp_weight'], c['noise_stddev'])
+                out.update(disc_loss=disc_loss, gp_loss=gp_loss)
+                for tid in d_ids:
+                    self._finish(tid, self._backward(tid, out), out, apply=tid in want_train)
+                gen_sample, gen_loss = forward_generator(c['generator'], c['discriminator'], real, *net_args,
+                                                         c['noise_stddev'], is_reuse=True)
+                out.update(gen_sample=gen_sample, gen_loss=gen_loss)
+                for tid in g_ids:
+                    self._finish(tid, self._backward(tid, out), out, apply=tid in want_train)
+        self.last = out
+        res = []
+        for f in fetches:
+            if f.key in ('train',):
+                res.append(None)
+            elif f.key == 'gradients':
+                res.append(out[('gradients', f.net)])
+            elif f.key == 'max_norm':
+                res.append(out.get(('max_norm', f.net)))
+            else:
+                v = out[f.key]
+                res.append(v.detach() if torch.is_tensor(v) else v)
+        return res
+
+    def _backward(self, tid, out):
+        tr = self.trains[tid]
+        prefix = tr['net'] + '/'
+        flat = self.store.flat[prefix]
+        names = [n for n in tr['names'] if n in flat['offsets']]
+        ranges = self._ranges(prefix, names)
+        for (o, n) in ranges:
+            flat['grad'][o:o + n].zero_()
+        params = [self.store.vars[n] for n in names]
+        for p, n in zip(params, names):      # .grad views may have been replaced by autograd: re-point them
+            o, cnt = flat['offsets'][n]
+            p.grad = flat['grad'][o:o + cnt].view(p.shape)
+        loss = out['gen_loss'] if tr['net'] == 'generator' else out['disc_loss']
+        dist = tr['optimizer'].distributed
+        if dist is not None:
+            dist.begin(flat['grad'], ranges, params)
+        torch.autograd.backward(loss, inputs=params)
+        return dict(prefix=prefix, flat=flat, names=names, ranges=ranges, dist=dist)
+
+    def _finish(self, tid, info, out, apply):
+        tr = self.trains[tid]
+        flat, ranges, names = info['flat'], info['ranges'], info['names']
+        gscale = 1.0
+        if info['dist'] is not None:
+            info['dist'].finish()              # waits for the bucketed all-reduces (sum)
+            gscale = 1.0 / info['dist'].world_size
+        if tr['clipping'] or ('max_norm', tid) in self._wanted:
+            if 'bounds' not in tr:
+                offs = flat['offsets']
+                b = torch.tensor([[offs[n][0], offs[n][0] + offs[n][1]] for n in names], dtype=torch.int64)
+                tr['bounds'] = b.reshape(-1).to(flat['grad'].device)
+            # per-variable squared norms in ONE launch: offsets interleave [start_i, end_i); the odd segments
+            # are the alignment padding between variables and are dropped
+            sq = F.segment_sumsq(flat['grad'], tr['bounds'], tr['bounds'].numel() - 1)[0::2] * (gscale * gscale)
+            if tr['clipping']:                 # tf.clip_by_global_norm(gradients, 1.0), optimization.py:66-67
+                scale = 1.0 / torch.clamp(torch.sqrt(sq.sum()), min=1.0)
+                out[('max_norm', tid)] = torch.sqrt(sq).max() * scale
+                gscale = float(scale) * gscale
+            else:
+                out[('max_norm', tid)] = torch.sqrt(sq).max()
+        out[('gradients', tid)] = [self.store.vars[n].grad for n in names]
+        if apply:
+            ema_flat = self.ema.shadow_flat(info['prefix']) if self.ema is not None else None
+            ema_decay = self.ema.decay if self.ema is not None else 0.0
+            tr['optimizer'].apply(info['prefix'], flat, ranges, gscale, ema_flat, ema_decay)
+            if self.ema is not None:
+                self.ema.mark_updated(info['prefix'], ranges)
+
+
+def optimize_step(optimizer_gen, optimizer_disc, generator, discriminator, real_image_input, latent_dim, alpha, phase,
+                  base_shape, kernel_spec, filter_spec, activation, leakiness, loss_fn, gp_weight, optim_strategy,
+                  g_clipping, d_clipping, noise_stddev, freeze_vars=None):
+    """optimization.py:77-224: returns the same 20-tuple (handles for Session.run)."""
+    if optim_strategy not in ('simultaneous', 'alternate'):
+        raise ValueError("Unknown optim strategy ", optim_strategy)
+    if loss_fn not in ('wgan', 'logistic'):
+        raise ValueError(f"Unknown loss function: {loss_fn}")
+    store = current_store()
+    shapes = pgan_variable_shapes(phase, base_shape, latent_dim, kernel_spec, filter_spec)
+    for name, shp in shapes.items():           # create in the reference's order (weights N(0,1), biases 0)
+        store.get(name, shp, 'normal' if name.endswith('weight') else 'zeros')
+    freeze_names = None if freeze_vars is None else [_key(v) for v in freeze_vars]
+    cfg = dict(generator=generator, discriminator=discriminator, latent_dim=latent_dim, alpha=alpha, phase=phase,
+               base_shape=base_shape, kernel_spec=kernel_spec, filter_spec=filter_spec, activation=activation,
+               leakiness=leakiness, loss_fn=loss_fn, gp_weight=gp_weight, optim_strategy=optim_strategy,
+               noise_stddev=noise_stddev, freeze_names=freeze_names, placeholder=real_image_input)
+    graph = StepGraph(store, cfg)
+    gen_loss, disc_loss = Fetch(graph, 'gen_loss'), Fetch(graph, 'disc_loss')
+    gp_loss, gen_sample = Fetch(graph, 'gp_loss'), Fetch(graph, 'gen_sample')
+
+    gen_vars = [n for n in shapes if n.startswith('generator/')]
+    disc_vars = [n for n in shapes if n.startswith('discriminator/')]
+    train_gen, g_gradients, g_variables, max_g_norm = minimize_with_clipping(optimizer_gen, gen_loss, gen_vars, g_clipping)
+    train_gen_freeze = g_gradients_freeze = g_variables_freeze = max_g_norm_freeze = None
+    if freeze_names is not None:
+        gen_vars_limited = [n for n in gen_vars if n not in set(freeze_names)]
+        train_gen_freeze, g_gradients_freeze, g_variables_freeze, max_g_norm_freeze = minimize_with_clipping(
+            optimizer_gen, gen_loss, gen_vars_limited, g_clipping)
+    train_disc, d_gradients, d_variables, max_d_norm = minimize_with_clipping(optimizer_disc, disc_loss, disc_vars, d_clipping)
+    train_disc_freeze = d_gradients_freeze = d_variables_freeze = max_d_norm_freeze = None
+    if freeze_names is not None:
+        disc_vars_limited = [n for n in disc_vars if n not in set(freeze_names)]
+        train_disc_freeze, d_gradients_freeze, d_variables_freeze, max_d_norm_freeze = minimize_with_clipping(
+            optimizer_disc, disc_loss, disc_vars_limited, d_clipping)
+
+    return train_gen, train_disc, gen_loss, disc_loss, gp_loss, gen_sample, g_gradients, g_variables, \
+        d_gradients, d_variables, max_g_norm, max_d_norm, \
+        train_gen_freeze, g_gradients_freeze, g_variables_freeze, max_g_norm_freeze, \
+        train_disc_freeze, d_gradients_freeze, d_variables_freeze, max_d_norm_freeze
+
+
+def lr_update(lr, intra_phase_step, steps_per_phase, lr_max, lr_increase, lr_decrease, lr_rise_niter, lr_decay_niter):
+    """optimization.py:227-296: returns the op that assigns the scheduled value to `lr` (f32 arithmetic)."""
+    def val(v):
+        return v.eval() if isinstance(v, ScalarVariable) else v
+
+    def compute():
+        step = int(val(intra_phase_step))
+        total = int(val(steps_per_phase))
+        lmax = np.float32(val(lr_max))
+        new = lmax
+        if lr_increase or lr_decrease:
+            a = np.float32(lmax / np.float32(100))
+            if lr_increase == 'linear':
+                if step < lr_rise_niter:
+                    new = np.float32(step / lr_rise_niter) * lmax
+            elif lr_increase == 'exponential':
+                if step < lr_rise_niter:
+                    new = a * np.exp(np.float32(np.log(100) / lr_rise_niter) * np.float32(step), dtype=np.float32)
+            if lr_decrease:
+                step_decay_start = total - lr_decay_niter
+                remaining = total - step
+                if lr_decrease == 'linear':
+                    if step > step_decay_start:
+                        new = np.float32(remaining / lr_decay_niter) * lmax
+                elif lr_decrease == 'exponential':
+                    if step > step_decay_start:
+                        new = a * np.exp(np.float32(np.log(100) / lr_decay_niter) * np.float32(remaining),
+                                         dtype=np.float32)
+        return lr.assign(new)
+    return Op(compute, 'lr_update')
+
+
+class Session:
+    """Eager counterpart of tf.Session for this path: run(fetches, feed_dict) over Fetch handles and Ops."""
+
+    def __init__(self, device='cuda'):
+        self.device = torch.device(device)
+
+    def run(self, fetches, feed_dict=None):
+        single = not isinstance(fetches, (list, tuple))
+        fl = [fetches] if single else list(fetches)
+        results = [None] * len(fl)
+        graphs = {}
+        for i, f in enumerate(fl):
+            if isinstance(f, Op):
+                results[i] = f.run()
+            elif isinstance(f, Fetch):
+                graphs.setdefault(id(f.graph), (f.graph, []))[1].append(i)
+            elif f is None:
+                results[i] = None
+            else:
+                raise TypeError(f'cannot run {f!r}')
+        for graph, idxs in graphs.values():
+            ph = graph.cfg['placeholder']
+            if feed_dict is None or ph not in feed_dict:
+                raise ValueError('real_image_input must be fed')
+            batch = feed_dict[ph]
+            if not torch.is_tensor(batch):
+                batch = torch.from_numpy(np.ascontiguousarray(batch))
+            batch = batch.to(self.device, torch.float32, non_blocking=True)
+            vals = graph.run([fl[i] for i in idxs], batch)
+            for i, v in zip(idxs, vals):
+                results[i] = v
+        return results[0] if single else results

@@ -1,0 +1,129 @@
+"""GPU parity of the whole hot path (networks -> losses -> gradients -> TF-Adam -> EMA) against the fp64
+oracle fixtures tests/golden/oracle_step_*.npz, driven through the reference-shaped API
+(optimization.optimize_step + Session.run).  fp32 path tolerances follow SURVEY.md section 8c:
+rtol 1e-4 / atol 1e-5 on activations and losses, 1e-3 on gradients (they pass through the GP double backward)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.stepfix import BASE_SHAPE, FILTER_SPEC, KERNEL_SPEC, LATENT, load_step_fixture
+
+pytestmark = pytest.mark.gpu
+
+FIXTURES = ['oracle_step_p1_wgan_a000.npz', 'oracle_step_p2_wgan_a060.npz', 'oracle_step_p3_logistic_a025.npz',
+            'oracle_step_p3_wgan_a000.npz']
+
+
+def _build(fx, dtype):
+    import saragan_amd.optimization as opt
+    from saragan_amd.ExtendedEMA import ExtendedEMA
+    from saragan_amd.networks import loss as L
+    from saragan_amd.networks.ops import ScalarVariable
+    from saragan_amd.networks.pgan.discriminator import discriminator
+    from saragan_amd.networks.pgan.generator import generator
+    from saragan_amd.varstore import VariableStore, set_compute_dtype, use_store
+    set_compute_dtype(dtype)
+    store = VariableStore('cuda', seed=0)
+    L.set_random_source(L.InjectedRandom({k: v.float() for k, v in fx['rnd'].items()}))
+    alpha = ScalarVariable(fx['alpha'], 'alpha')
+    g_lr, d_lr = ScalarVariable(1e-3, 'g_lr'), ScalarVariable(1e-3, 'd_lr')
+    og, od = opt.AdamOptimizer(g_lr, 0.0, 0.9), opt.AdamOptimizer(d_lr, 0.0, 0.9)
+    ph = opt.Placeholder([4, 1, 1, 1, 1])
+    cfg = fx['cfg']
+    freeze = None if fx['freeze'] is None else list(fx['freeze'])
+    with use_store(store):
+        tup = opt.optimize_step(og, od, generator, discriminator, ph, LATENT, alpha, fx['phase'], BASE_SHAPE,
+                                KERNEL_SPEC, FILTER_SPEC, 'leaky_relu', 0.2, fx['loss_fn'], cfg['gp_weight'],
+                                'simultaneous', False, False, 0.01, freeze if freeze is not None else None)
+    store.load_state_dict({k: v for k, v in fx['p0'].items()}, strict=True)
+    graph = tup[0].graph
+    ema = ExtendedEMA(list(store.vars.keys()), 0.99, graph=graph)
+    return store, tup, ph, ema, opt.Session('cuda')
+
+
+@pytest.mark.parametrize('name', FIXTURES)
+def test_step_matches_oracle_fp32(golden_dir, name):
+    fx = load_step_fixture(os.path.join(golden_dir, name), torch.float64)
+    store, tup, ph, ema, sess = _build(fx, torch.float32)
+    (train_gen, train_disc, gen_loss, disc_loss, gp_loss, gen_sample, g_grad, g_vars, d_grad, d_vars, mg, md,
+     train_gen_fz, g_grad_fz, g_vars_fz, mg_fz, train_disc_fz, d_grad_fz, d_vars_fz, md_fz) = tup
+    mixing = fx['freeze'] is not None
+    tg, td = (train_gen_fz, train_disc_fz) if mixing else (train_gen, train_disc)
+    gg_h, gv, dg_h, dv = (g_grad_fz, g_vars_fz, d_grad_fz, d_vars_fz) if mixing else (g_grad, g_vars, d_grad, d_vars)
+    ema_op = ema.apply()
+    feed = {ph: fx['real'].float()}
+    _, _, gl, dl, gpl, gs, gg, dg, mgn, mdn = sess.run(
+        [tg, td, gen_loss, disc_loss, gp_loss, gen_sample, gg_h, dg_h, (mg_fz if mixing else mg),
+         (md_fz if mixing else md)], feed_dict=feed)
+    sess.run(ema_op)
+    np.testing.assert_allclose(float(gl), float(fx['gen_loss']), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(float(dl), float(fx['disc_loss']), rtol=1e-4, atol=1e-5)
+    ref = fx['gp_loss'].numpy()
+    np.testing.assert_allclose(gpl.double().cpu().numpy().reshape(ref.shape), ref, rtol=1e-3, atol=1e-5 * max(1.0, np.abs(ref).max()))
+    np.testing.assert_allclose(gs.double().cpu().numpy(), fx['gen_sample'].numpy(), rtol=1e-4, atol=1e-5)
+    for handle_vars, grads, refs in ((gv, gg, fx['gg']), (dv, dg, fx['dg'])):
+        assert [v.key for v in handle_vars] == list(refs.keys())
+        for v, g in zip(handle_vars, grads):
+            r = refs[v.key].numpy()
+            np.testing.assert_allclose(g.double().cpu().numpy(), r, rtol=1e-3, atol=1e-4 * np.abs(r).max() + 1e-9,
+                                       err_msg=v.key)
+    want_max = max(float(torch.linalg.vector_norm(v)) for v in fx['dg'].values())
+    np.testing.assert_allclose(float(mdn), want_max, rtol=1e-3)
+    # step 1 weights + EMA, then a second step
+    def check_params(tag_p, tag_e):
+        for k, p in store.vars.items():
+            r = fx[tag_p][k].numpy()
+            np.testing.assert_allclose(p.detach().double().cpu().numpy(), r, rtol=1e-4, atol=2e-5, err_msg=f'{tag_p}:{k}')
+            e = fx[tag_e][k].numpy()
+            np.testing.assert_allclose(ema.average(k).double().cpu().numpy(), e, rtol=1e-4, atol=2e-5, err_msg=f'{tag_e}:{k}')
+    check_params('p1', 'ema1')
+    sess.run([tg, td], feed_dict=feed)
+    sess.run(ema_op)
+    check_params('p2', 'ema2')
+    if mixing:   # quirk Q4: previous-phase variables are not updated while alpha > 0
+        for k in fx['freeze']:
+            if k in store.vars:
+                np.testing.assert_array_equal(store.vars[k].detach().cpu().numpy(), fx['p0'][k].float().numpy())
+
+
+@pytest.mark.parametrize('name', FIXTURES[1:3])
+def test_step_bf16_close_to_oracle(golden_dir, name):
+    """bf16 storage/MFMA path vs the fp64 oracle: rtol 2e-2 on losses and samples."""
+    fx = load_step_fixture(os.path.join(golden_dir, name), torch.float64)
+    store, tup, ph, ema, sess = _build(fx, torch.bfloat16)
+    mixing = fx['freeze'] is not None
+    tg, td = (tup[12], tup[16]) if mixing else (tup[0], tup[1])
+    _, _, gl, dl, gs = sess.run([tg, td, tup[2], tup[3], tup[5]], feed_dict={ph: fx['real'].float()})
+    np.testing.assert_allclose(float(gl), float(fx['gen_loss']), rtol=3e-2, atol=3e-2)
+    np.testing.assert_allclose(float(dl), float(fx['disc_loss']), rtol=3e-2, atol=3e-2)
+    ref = fx['gen_sample'].numpy()
+    np.testing.assert_allclose(gs.double().cpu().numpy(), ref, rtol=3e-2, atol=3e-2 * np.abs(ref).max())
+    from saragan_amd.varstore import set_compute_dtype
+    set_compute_dtype(torch.float32)
+
+
+def test_variable_names_created_by_networks_match_plan():
+    """Running generator()/discriminator() creates exactly the planned variables."""
+    from saragan_amd.networks.pgan.discriminator import discriminator
+    from saragan_amd.networks.pgan.generator import generator
+    from saragan_amd.networks.pgan.variables import pgan_variable_shapes
+    from saragan_amd.varstore import VariableStore, set_compute_dtype, use_store
+    set_compute_dtype(torch.float32)
+    store = VariableStore('cuda', seed=1)
+    with use_store(store), torch.no_grad():
+        z = torch.randn(2, LATENT, device='cuda')
+        img = generator(z, 0.5, 3, BASE_SHAPE, 'leaky_relu', KERNEL_SPEC, FILTER_SPEC, param=0.2)
+        assert tuple(img.shape) == (2, 1, 4, 16, 16)
+        out = discriminator(img, 0.5, 3, LATENT, 'leaky_relu', KERNEL_SPEC, FILTER_SPEC, param=0.2)
+        assert tuple(out.shape) == (2, 1)
+        with pytest.raises(NotImplementedError):
+            generator(z, 0.5, 3, BASE_SHAPE, 'leaky_relu', KERNEL_SPEC, FILTER_SPEC, param=0.2, conditioning=1)
+        with pytest.raises(ValueError):
+            generator(z, 0.5, 4, BASE_SHAPE, 'leaky_relu', KERNEL_SPEC, FILTER_SPEC, param=0.2)
+    plan = pgan_variable_shapes(3, BASE_SHAPE, LATENT, KERNEL_SPEC, FILTER_SPEC)
+    created = {k: tuple(v.shape) for k, v in store.vars.items()}
+    created.pop('generator/generator_block_4/conv_1/weight', None)   # partial creation by the failing call
+    assert {k: tuple(v) for k, v in plan.items()} == {k: v for k, v in created.items() if k in plan}
+    assert set(created) - set(plan) <= {'generator/to_rgb_3/weight', 'generator/to_rgb_3/bias'}

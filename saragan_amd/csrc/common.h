@@ -91,7 +91,7 @@ static inline int sg_pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return 
 
 // Picks the tile (powers of two clipped to the extent, TW <= 32, at most `bm` voxels) that stages the
 // fewest halo voxels over the whole tensor; small volumes fold batch samples into the tile (TN > 1).
-static inline sg_tile_geom sg_make_geom(const sg_conv_shape* s, int bm) {
+static inline sg_tile_geom sg_make_geom(const sg_conv_shape* s, int bm, bool prefer_w32 = false) {
   sg_tile_geom g;
   g.N = s->n; g.D = s->d; g.H = s->h; g.W = s->w;
   g.PD = s->kd / 2; g.PH = s->kh / 2; g.PW = s->kw / 2;
@@ -105,7 +105,9 @@ static inline sg_tile_geom sg_make_geom(const sg_conv_shape* s, int bm) {
         const double tiles = (double)sg_cdiv(s->w, cw) * sg_cdiv(s->h, chh) * sg_cdiv(s->d, cd);
         const double halo = (double)(cw + 2 * g.PW) * (chh + 2 * g.PH) * (cd + 2 * g.PD);
         // staged voxels + a per-tile cost that favours full tiles (fixed barrier/epilogue overhead)
-        const double score = tiles * (halo + 0.25 * bm) - 1e-3 * cw;
+        double score = tiles * (halo + 0.25 * bm) - 1e-3 * cw;
+        // v2 kernels read 32 consecutive halo rows per MFMA operand: only tiles spanning min(W,32) are conflict free
+        if (prefer_w32 && cw != (s->w < 32 ? s->w : 32)) score *= 4.0;
         if (score < best) { best = score; bd = cd; bh = chh; bw = cw; }
       }
   g.TW = bw; g.TH = bh; g.TD = bd;

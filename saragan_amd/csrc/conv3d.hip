@@ -13,6 +13,7 @@
 // so a wave fetches a fragment with one lane-linear 1-KiB access (LDS-DMA friendly, conflict-free ds_read_b128).
 #include "common.h"
 #include "prof.h"
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------------
 // weight packing
@@ -107,10 +108,70 @@ struct ConvFwdArgs {
   int rs;               // LDS row stride of the halo image (bytes)
   int xbytes;           // LDS bytes of the halo image
   sg_fastdiv fnp;       // fastdiv by pieces per halo row (G*2)
+  int sshift, rshift;   // v2: log2(slots per row), log2(rows per 256-byte bank row)
+  int wbytes, ntiles;   // v3r: resident weight image bytes, number of spatial tiles
+  unsigned long long* dbg;  // diagnostic time stamps (NULL in production)
   int vec_in, vec_out;
   int act, pixel_norm;
   float slope, eps;
 };
+
+// ---- epilogue shared by both forward kernels: lane owns voxel r of each M tile and output channels
+// (i&3) + 8*(i>>2) + 4*hh of each N tile: bias, LeakyReLU and pixel-norm are lane-local (+1 shuffle).
+template <typename T, int MTW, int NTB>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MTW][NTB], const int64_t (&ooff)[MTW],
+                                              const ConvFwdArgs& a, int nt0, int hh) {
+  T* y = reinterpret_cast<T*>(a.y);
+  const float inv_c = 1.f / (float)a.cout;
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) {
+    float ss = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NTB; ++nt) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = (nt0 + nt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        float v = acc[mt][nt][i];
+        if (a.bias != nullptr && co < a.cout) v += a.bias[co];
+        if (a.act) v = fmaxf(v, v * a.slope);
+        acc[mt][nt][i] = v;
+        ss += v * v;
+      }
+    }
+    if (a.pixel_norm) {
+      ss += __shfl_xor(ss, 32);
+      const float sc = rsqrtf(ss * inv_c + a.eps);
+#pragma unroll
+      for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][nt][i] *= sc;
+      if (a.pn_scale != nullptr && hh == 0 && ooff[mt] >= 0) a.pn_scale[ooff[mt]] = sc;
+    }
+    if (ooff[mt] >= 0) {
+      T* yrow = y + ooff[mt] * (int64_t)a.cout;
+#pragma unroll
+      for (int nt = 0; nt < NTB; ++nt) {
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          const int co = (nt0 + nt) * 32 + 8 * qd + 4 * hh;
+          if (a.vec_out && co + 4 <= a.cout) {
+            T tmp[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tmp[e] = sg_traits<T>::from_f(acc[mt][nt][qd * 4 + e]);
+            if (sizeof(T) == 2)
+              *reinterpret_cast<u32x2*>(yrow + co) = *reinterpret_cast<u32x2*>(tmp);
+            else
+              *reinterpret_cast<u32x4*>(yrow + co) = *reinterpret_cast<u32x4*>(tmp);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (co + e < a.cout) yrow[co + e] = sg_traits<T>::from_f(acc[mt][nt][qd * 4 + e]);
+          }
+        }
+      }
+    }
+  }
+}
 
 template <typename T, int MTW, int NTB>
 __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
@@ -204,57 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(ConvFwdArgs a) {
     }
   }
 
-  // ---- epilogue: lane owns voxel r of each M tile and couts (i&3) + 8*(i>>2) + 4*hh of each N tile ----
-  T* y = reinterpret_cast<T*>(a.y);
-  const float inv_c = 1.f / (float)a.cout;
-#pragma unroll
-  for (int mt = 0; mt < MTW; ++mt) {
-    float ss = 0.f;
-#pragma unroll
-    for (int nt = 0; nt < NTB; ++nt) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int co = (nt0 + nt) * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        float v = acc[mt][nt][i];
-        if (a.bias != nullptr && co < a.cout) v += a.bias[co];
-        if (a.act) v = fmaxf(v, v * a.slope);
-        acc[mt][nt][i] = v;
-        ss += v * v;
-      }
-    }
-    if (a.pixel_norm) {
-      ss += __shfl_xor(ss, 32);
-      const float sc = rsqrtf(ss * inv_c + a.eps);
-#pragma unroll
-      for (int nt = 0; nt < NTB; ++nt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[mt][nt][i] *= sc;
-      if (a.pn_scale != nullptr && hh == 0 && ooff[mt] >= 0) a.pn_scale[ooff[mt]] = sc;
-    }
-    if (ooff[mt] >= 0) {
-      T* yrow = y + ooff[mt] * (int64_t)a.cout;
-#pragma unroll
-      for (int nt = 0; nt < NTB; ++nt) {
-#pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-          const int co = (nt0 + nt) * 32 + 8 * qd + 4 * hh;
-          if (a.vec_out && co + 4 <= a.cout) {
-            T tmp[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) tmp[e] = sg_traits<T>::from_f(acc[mt][nt][qd * 4 + e]);
-            if (sizeof(T) == 2)
-              *reinterpret_cast<u32x2*>(yrow + co) = *reinterpret_cast<u32x2*>(tmp);
-            else
-              *reinterpret_cast<u32x4*>(yrow + co) = *reinterpret_cast<u32x4*>(tmp);
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (co + e < a.cout) yrow[co + e] = sg_traits<T>::from_f(acc[mt][nt][qd * 4 + e]);
-          }
-        }
-      }
-    }
-  }
+  conv_epilogue<T, MTW, NTB>(acc, ooff, a, nt0, hh);
 }
 
 template <typename T, int MTW, int NTB>
@@ -305,6 +316,524 @@ static int launch_fwd(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st) {
   return SG_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// forward, v2: the tuned path for 16-byte-aligned channel counts.
+//  * halo image rows are exactly G*32 bytes, no padding; 16-byte slot s of row r lives at slot s ^ f(r),
+//    f(r) = (r / R) % S with S = slots per row, R = 16 / S rows per 256-byte bank row: a wave's ds_read_b128
+//    of 32 consecutive rows is bank-conflict free for every tap shift (tiles are 32 voxels wide in W);
+//  * halo and weights are staged by LDS-DMA (global_load_lds, 16 B per lane, no VGPR round trip): the DMA
+//    writes LDS lane-linearly, so the swizzle is applied on the SOURCE address; voxels outside the volume
+//    read from a zero page;
+//  * weights are double buffered: the slab of phase p+1 is in flight while phase p runs on the MFMAs; one
+//    __syncthreads() per phase.
+// ------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(1024))) uint32_t sg_zero_page[256] = {0};   // 1 KiB of zeros
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__device__ __forceinline__ void sg_glds16(const void* g, char* lds_uniform_base) {
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)g, (lds_ptr_t)lds_uniform_base, 16, 0, 0);
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_halo_dma(char* xlds, const T* __restrict__ x, const sg_tile_geom& g,
+                                               const sg_tile_origin& o, int cin, int c0, int S, int sshift,
+                                               int rshift, int wave, int lane) {
+  constexpr int EPP = 16 / (int)sizeof(T);
+  const int hv = g.TN * g.HD * g.HH * g.HW;
+  const int items = hv * S;
+  const int Di = g.ups ? (g.D >> 1) : g.D, Hi = g.ups ? (g.H >> 1) : g.H, Wi = g.ups ? (g.W >> 1) : g.W;
+  for (int base = wave * 64; base < items; base += 256) {
+    const int it = base + lane;
+    const int row = it >> sshift;
+    const int p = it & (S - 1);
+    const int sl = p ^ ((row >> rshift) & (S - 1));  // logical slot stored at physical slot p
+    uint32_t v = (uint32_t)row;
+    uint32_t q = sg_div(v, g.fHW);
+    int hw = (int)(v - q * g.HW);
+    uint32_t q2 = sg_div(q, g.fHH);
+    int hh_ = (int)(q - q2 * g.HH);
+    uint32_t q3 = sg_div(q2, g.fHD);
+    int hd = (int)(q2 - q3 * g.HD);
+    int n = o.n0 + (int)q3;
+    int d = o.d0 + hd - g.PD, h = o.h0 + hh_ - g.PH, w = o.w0 + hw - g.PW;
+    const int c = c0 + sl * EPP;
+    const void* src = sg_zero_page;
+    if (row < hv && n < g.N && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H &&
+        (unsigned)w < (unsigned)g.W && c < cin) {
+      if (g.ups) { d >>= 1; h >>= 1; w >>= 1; }
+      src = x + ((((int64_t)n * Di + d) * Hi + h) * Wi + w) * (int64_t)cin + c;
+    }
+    sg_glds16(src, xlds + (size_t)base * 16);
+  }
+}
+
+template <typename T, int MTW, int NTB, int GC>
+__global__ __launch_bounds__(256, 2) void conv_fwd2_kernel(ConvFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int CH = sg_traits<T>::CH;
+  const sg_tile_geom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  char* xlds = smem;
+  char* wlds = smem + a.xbytes;
+  const int wbuf_bytes = a.TG * a.G * NTB * 1024;
+  const T* x = reinterpret_cast<const T*>(a.x);
+  const char* wp = reinterpret_cast<const char*>(a.wp);
+  const int S = a.G * 2;                      // 16-byte slots per halo row (power of two)
+  const int sshift = a.sshift, rshift = a.rshift;
+  const int rb = a.G * 32;
+
+  const sg_tile_origin o = sg_tile_of(g, blockIdx.x);
+  const int nt0 = blockIdx.y * NTB;
+  const int tvox = g.TN * g.TD * g.TH * g.TW;
+
+  int lrow[MTW];
+  int64_t ooff[MTW];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) {
+    const int m = (wave * MTW + mt) * 32 + r;
+    uint32_t q = sg_div((uint32_t)m, g.fTW);
+    int tw = m - (int)q * g.TW;
+    uint32_t q2 = sg_div(q, g.fTH);
+    int th = (int)(q - q2 * g.TH);
+    uint32_t q3 = sg_div(q2, g.fTD);
+    int td = (int)(q2 - q3 * g.TD);
+    int tn = (int)q3;
+    const int n = o.n0 + tn, d = o.d0 + td, h = o.h0 + th, w = o.w0 + tw;
+    const bool ok = (m < tvox) && n < g.N && d < g.D && h < g.H && w < g.W;
+    lrow[mt] = ok ? (((tn * g.HD + td) * g.HH + th) * g.HW + tw) : 0;
+    ooff[mt] = ok ? ((((int64_t)n * g.D + d) * g.H + h) * g.W + w) : -1;
+  }
+
+  f32x16 acc[MTW][NTB];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+
+  const int ntb = min(NTB, a.ntile - nt0);
+  const int nphase_t = (a.taps + a.TG - 1) / a.TG;          // tap phases per channel group
+  const int ngroup = (a.nchunk + a.G - 1) / a.G;
+  const int nphase = nphase_t * ngroup;
+
+  auto stage_w = [&](int p, char* dst) {
+    const int grp = p / nphase_t, tp = p - grp * nphase_t;
+    const int c0 = grp * a.G, t0 = tp * a.TG;
+    const int gcur = min(a.G, a.nchunk - c0), tcur = min(a.TG, a.taps - t0);
+    const int nfrag = gcur * tcur * NTB;
+    for (int f = wave; f < nfrag; f += 4) {
+      const int nt = f % NTB;
+      const int q = f / NTB;
+      const int t = q % tcur;
+      const int gi = q / tcur;
+      const char* src = nt < ntb ? wp + ((((int64_t)(c0 + gi) * a.taps + (t0 + t)) * a.ntile + (nt0 + nt)) << 10)
+                                 : reinterpret_cast<const char*>(sg_zero_page);   // dead N tile: zero weights
+      sg_glds16(src + lane * 16, dst + ((size_t)f << 10));
+    }
+  };
+
+  stage_halo_dma<T>(xlds, x, g, o, a.cin, 0, S, sshift, rshift, wave, lane);
+  stage_w(0, wlds);
+  __syncthreads();
+
+  for (int p = 0; p < nphase; ++p) {
+    const int grp = p / nphase_t, tp = p - grp * nphase_t;
+    const int c0 = grp * a.G, t0 = tp * a.TG;
+    const int gcur = min(a.G, a.nchunk - c0), tcur = min(a.TG, a.taps - t0);
+    const char* wcur = wlds + (p & 1) * wbuf_bytes;
+    const bool group_ends = (tp == nphase_t - 1);
+    if (p + 1 < nphase && !group_ends) stage_w(p + 1, wlds + ((p + 1) & 1) * wbuf_bytes);
+
+    // one step = one tap (all chunks of the group); fragments of step t+1 are fetched before the MFMAs of step t
+    int kw_i = t0 % a.kw, kh_i = (t0 / a.kw) % a.kh, kd_i = t0 / (a.kw * a.kh);
+    auto load_step = [&](int t, u32x4 (&wf)[GC][NTB], u32x4 (&xf)[GC][MTW]) {
+      const int taprow = (kd_i * g.HH + kh_i) * g.HW + kw_i;
+      if (++kw_i == a.kw) { kw_i = 0; if (++kh_i == a.kh) { kh_i = 0; ++kd_i; } }
+#pragma unroll
+      for (int gi = 0; gi < GC; ++gi) {
+#pragma unroll
+        for (int nt = 0; nt < NTB; ++nt)
+          wf[gi][nt] = *reinterpret_cast<const u32x4*>(wcur + ((size_t)((gi * tcur + t) * NTB + nt) << 10) + lane * 16);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          const int row = lrow[mt] + taprow;
+          const int sl = (gi * 2 + hh) ^ ((row >> rshift) & (S - 1));
+          xf[gi][mt] = *reinterpret_cast<const u32x4*>(xlds + row * rb + (sl << 4));
+        }
+      }
+    };
+    auto mma_step = [&](const u32x4 (&wf)[GC][NTB], const u32x4 (&xf)[GC][MTW]) {
+#pragma unroll
+      for (int gi = 0; gi < GC; ++gi) {
+        if (gi < gcur) {
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTB; ++nt) acc[mt][nt] = sg_mfma_chunk<T>(wf[gi][nt], xf[gi][mt], acc[mt][nt]);
+        }
+      }
+    };
+    {
+      u32x4 wA[GC][NTB], xA[GC][MTW], wB[GC][NTB], xB[GC][MTW];
+      load_step(0, wA, xA);
+      int t = 0;
+      for (; t + 2 <= tcur; t += 2) {
+        load_step(t + 1, wB, xB);
+        mma_step(wA, xA);
+        if (t + 2 < tcur) load_step(t + 2, wA, xA);
+        mma_step(wB, xB);
+      }
+      if (t < tcur) mma_step(wA, xA);
+    }
+    __syncthreads();
+    if (group_ends && p + 1 < nphase) {   // next channel group: restage the halo (single buffer) + its first slab
+      stage_halo_dma<T>(xlds, x, g, o, a.cin, (grp + 1) * a.G * CH, S, sshift, rshift, wave, lane);
+      stage_w(p + 1, wlds + ((p + 1) & 1) * wbuf_bytes);
+      __syncthreads();
+    }
+  }
+  conv_epilogue<T, MTW, NTB>(acc, ooff, a, nt0, hh);
+}
+
+static int sg_env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+
+template <typename T, int MTW, int NTB, int GC>
+static int launch_fwd2(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st) {
+  constexpr int BM = MTW * 128;
+  a.g = sg_make_geom(s, BM, /*prefer_w32=*/true);
+  const sg_tile_geom& g = a.g;
+  const int64_t ntiles = (int64_t)g.nTn * g.nTd * g.nTh * g.nTw;
+  if (ntiles >= (1 << 24)) return SG_EINVAL;
+  const int hv = g.TN * g.HD * g.HH * g.HW;
+  const int lds_cap = sg_env_int("SG_FWD_LDS", 80 * 1024);   // per block; 80 KiB = two blocks per CU
+  const int G = GC;
+  a.G = G;
+  a.rs = G * 32;
+  a.sshift = G == 1 ? 1 : (G == 2 ? 2 : 3);
+  a.rshift = G == 1 ? 3 : (G == 2 ? 2 : 1);
+  a.xbytes = ((hv * a.rs) + 1023) & ~1023;
+  int cap = lds_cap;
+  if (a.xbytes + 2 * G * NTB * 1024 > cap) cap = 160 * 1024;
+  int TG = (cap - a.xbytes) / (2 * G * NTB * 1024);
+  if (TG < 1) return SG_EINVAL;
+  if (TG > a.taps) TG = a.taps;
+  // even out the phases (e.g. 27 taps with room for 10 -> 3 phases of 9)
+  const int nph = sg_cdiv(a.taps, TG);
+  TG = sg_cdiv(a.taps, nph);
+  TG = sg_env_int("SG_FWD_TG", TG);
+  a.TG = TG;
+  a.vec_in = 1;
+  a.vec_out = (s->cout % 4 == 0) ? 1 : 0;
+  const size_t lds = (size_t)a.xbytes + 2ull * TG * G * NTB * 1024;
+  if (lds > 160 * 1024) return SG_EINVAL;
+  auto kern = conv_fwd2_kernel<T, MTW, NTB, GC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid((unsigned)ntiles, (unsigned)sg_cdiv(a.ntile, NTB));
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------
+// forward, v3r: persistent, weight-stationary variant for Cin <= one channel group (32 bf16 / 16 f32 channels).
+// One block per CU owns a 32-wide slice of output channels (blockIdx.y) and walks spatial tiles.  ALL weights of
+// the slice stay resident in LDS (27 taps x GC KiB); the halo image is double buffered and the next tile's halo
+// is fetched by LDS-DMA while the MFMAs run on the current one, so the only per-tile synchronisation is one
+// barrier and HBM/L2 traffic per tile is the halo alone.  Tiles are dealt so that the blocks of one XCD
+// (blockIdx.x % 8, the round-robin dispatch group) work on spatially adjacent tiles: halo overlap hits that
+// XCD's L2 (placement affects speed only).
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int MTW, int GC, int KD, int KH, int KW>
+__global__ __launch_bounds__(512) void conv_fwd3r_kernel(ConvFwdArgs a) {
+  // 8 waves = two groups of 4 (one wave of each group per SIMD).  Phase p: group (p & 1) runs the MFMA loop of
+  // tile p out of ITS halo buffer; the other group stores tile p-1 (accumulators stay in registers across the
+  // barrier) and fetches tile p+1 into its own buffer.  One workgroup barrier per phase.
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NTB = 1;
+  constexpr int TAPS = KD * KH * KW;
+  constexpr int EPP = 16 / (int)sizeof(T);
+  const sg_tile_geom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave8 >> 2, wave = wave8 & 3;
+  const int r = lane & 31, hh = lane >> 5;
+  // LDS map: [halo buffer of group 0][halo buffer of group 1][resident weights: [tap][gi] fragments of 1 KiB]
+  char* xmine = smem + grp * a.xbytes;
+  char* wlds = smem + 2 * a.xbytes;
+  const T* x = reinterpret_cast<const T*>(a.x);
+  const char* wp = reinterpret_cast<const char*>(a.wp);
+  constexpr int S = GC * 2;
+  constexpr int sshift = GC == 1 ? 1 : (GC == 2 ? 2 : 3);
+  constexpr int rshift = GC == 1 ? 3 : (GC == 2 ? 2 : 1);
+  constexpr int rb = GC * 32;
+  const int nt0 = blockIdx.y;
+  const int tvox = g.TN * g.TD * g.TH * g.TW;
+
+  // tile schedule: XCD group xg = blockIdx.x % 8 owns a contiguous chunk of the tile list
+  const int xg = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int per_x = gridDim.x >> 3;
+  const int cpx = (a.ntiles + 7) >> 3;
+  const int t_begin = xg * cpx;
+  const int t_end = min(a.ntiles, t_begin + cpx);
+  const int first = t_begin + slot;
+  const int K = first < t_end ? (t_end - first + per_x - 1) / per_x : 0;   // tiles of this block
+
+  // ---- tile-invariant per-lane state ----------------------------------------------------------------
+  int xaddr[TAPS][MTW];   // LDS byte address of every (tap, M tile) operand fragment, chunk 0, own buffer
+  int tcoord[MTW];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) {
+    const int m = (wave * MTW + mt) * 32 + r;
+    uint32_t q = sg_div((uint32_t)m, g.fTW);
+    int tw = m - (int)q * g.TW;
+    uint32_t q2 = sg_div(q, g.fTH);
+    int th = (int)(q - q2 * g.TH);
+    uint32_t q3 = sg_div(q2, g.fTD);
+    int td = (int)(q2 - q3 * g.TD);
+    int tn = (int)q3;
+    const int lrow = (m < tvox) ? (((tn * g.HD + td) * g.HH + th) * g.HW + tw) : 0;
+    tcoord[mt] = (m < tvox) ? (tw | (th << 8) | (td << 16) | (tn << 24)) : -1;
+#pragma unroll
+    for (int kd = 0; kd < KD; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+          const int row = lrow + (kd * g.HH + kh) * g.HW + kw;
+          xaddr[(kd * KH + kh) * KW + kw][mt] =
+              grp * a.xbytes + row * rb + (((hh) ^ ((row >> rshift) & (S - 1))) << 4);
+        }
+  }
+  // halo staging items of this lane: element offset relative to the tile's first halo voxel + packed coords
+  const int hv = g.TN * g.HD * g.HH * g.HW;
+  const int items = hv * S;
+  constexpr int MAXIT = 14;   // LDS-DMA pieces per wave per tile (host checks)
+  int it_rel[MAXIT], it_crd[MAXIT];
+  const int Di = g.ups ? (g.D >> 1) : g.D, Hi = g.ups ? (g.H >> 1) : g.H, Wi = g.ups ? (g.W >> 1) : g.W;
+#pragma unroll
+  for (int k = 0; k < MAXIT; ++k) {
+    const int it = (wave + 4 * k) * 64 + lane;
+    const int row = it >> sshift;
+    const int p = it & (S - 1);
+    const int sl = p ^ ((row >> rshift) & (S - 1));
+    uint32_t v = (uint32_t)row;
+    uint32_t q = sg_div(v, g.fHW);
+    int hw = (int)(v - q * g.HW);
+    uint32_t q2 = sg_div(q, g.fHH);
+    int hh_ = (int)(q - q2 * g.HH);
+    uint32_t q3 = sg_div(q2, g.fHD);
+    int hd = (int)(q2 - q3 * g.HD);
+    const int c = sl * EPP;
+    const bool live = row < hv && c < a.cin;
+    it_crd[k] = live ? (hw | (hh_ << 8) | (hd << 16) | ((int)q3 << 24)) : -1;
+    it_rel[k] = live ? ((((int)q3 * g.D + hd) * g.H + hh_) * g.W + hw) * a.cin + c : 0;
+  }
+
+  // Halo staging by LDS-DMA: asynchronous (lands while this group runs its epilogue), no VGPRs held.  A piece
+  // costs 100-200 issue cycles on THIS wave only; the MFMA group on the same SIMDs keeps running.
+  auto stage_tile = [&](const sg_tile_origin& o) {
+    const bool interior = !g.ups && o.d0 >= g.PD && o.h0 >= g.PH && o.w0 >= g.PW && o.d0 + g.TD + g.PD <= g.D &&
+                          o.h0 + g.TH + g.PH <= g.H && o.w0 + g.TW + g.PW <= g.W && o.n0 + g.TN <= g.N;
+    if (interior) {   // every halo voxel is inside the volume: one 64-bit add per piece
+      const T* base = x + ((((int64_t)o.n0 * g.D + (o.d0 - g.PD)) * g.H + (o.h0 - g.PH)) * g.W + (o.w0 - g.PW)) *
+                              (int64_t)a.cin;
+#pragma unroll
+      for (int k = 0; k < MAXIT; ++k) {
+        if ((wave + 4 * k) * 64 < items) {
+          const void* src = it_crd[k] >= 0 ? (const void*)(base + it_rel[k]) : (const void*)sg_zero_page;
+          sg_glds16(src, xmine + (size_t)(wave + 4 * k) * 1024);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < MAXIT; ++k) {
+        if ((wave + 4 * k) * 64 < items) {
+          const int crd = it_crd[k];
+          int n = o.n0 + (crd >> 24);
+          int d = o.d0 + ((crd >> 16) & 255) - g.PD, h = o.h0 + ((crd >> 8) & 255) - g.PH,
+              w = o.w0 + (crd & 255) - g.PW;
+          const void* src = sg_zero_page;
+          if (crd >= 0 && n < g.N && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H &&
+              (unsigned)w < (unsigned)g.W) {
+            if (g.ups) { d >>= 1; h >>= 1; w >>= 1; }
+            const int row = ((wave + 4 * k) * 64 + lane) >> sshift;
+            const int sl_c = ((lane & (S - 1)) ^ ((row >> rshift) & (S - 1))) * EPP;
+            src = x + ((((int64_t)n * Di + d) * Hi + h) * Wi + w) * (int64_t)a.cin + sl_c;
+          }
+          sg_glds16(src, xmine + (size_t)(wave + 4 * k) * 1024);
+        }
+      }
+    }
+  };
+
+  // resident weights (all 8 waves)
+  {
+    constexpr int nfrag = TAPS * GC;
+    for (int f = wave8; f < nfrag; f += 8) {
+      const int tap = f / GC, gi = f - tap * GC;
+      const char* src = gi < a.nchunk ? wp + ((((int64_t)gi * TAPS + tap) * a.ntile + nt0) << 10)
+                                      : reinterpret_cast<const char*>(sg_zero_page);
+      sg_glds16(src + lane * 16, wlds + ((size_t)f << 10));
+    }
+  }
+  float* bias_lds = reinterpret_cast<float*>(wlds + a.wbytes);   // 32 floats: bias of this block's channel slice
+  if (tid < 32) {
+    const int co = nt0 * 32 + tid;
+    bias_lds[tid] = (a.bias != nullptr && co < a.cout) ? a.bias[co] : 0.f;
+  }
+  if (grp == 0 && K > 0) stage_tile(sg_tile_of(g, (uint32_t)first));
+  __syncthreads();
+
+  const char* wl = wlds + lane * 16;
+  T* y = reinterpret_cast<T*>(a.y);
+  const float inv_c = 1.f / (float)a.cout;
+  f32x16 acc[MTW];
+
+  int dbgi = 0;
+  auto stamp = [&]() {
+    if (a.dbg != nullptr && blockIdx.x == 8 && blockIdx.y == 0 && lane == 0 && wave == 0 && dbgi < 120)
+      a.dbg[grp * 128 + dbgi] = __builtin_amdgcn_s_memtime();
+    ++dbgi;
+  };
+  for (int p = 0; p <= K; ++p) {
+    stamp();
+    if ((p & 1) == grp) {
+      if (p < K) {
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+        constexpr int NS = TAPS * GC;
+        constexpr int RING = 3, PF = RING - 1;
+        u32x4 wfr[RING], xfr[RING][MTW];
+        auto ld = [&](int st, int sl_) {
+          const int tap = st / GC, gi = st % GC;
+          wfr[sl_] = *reinterpret_cast<const u32x4*>(wl + (st << 10));
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt)
+            xfr[sl_][mt] = *reinterpret_cast<const u32x4*>(smem + (xaddr[tap][mt] ^ (gi << 5)));
+        };
+#pragma unroll
+        for (int st = 0; st < PF && st < NS; ++st) ld(st, st % RING);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+          if (st + PF < NS) ld(st + PF, (st + PF) % RING);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) acc[mt] = sg_mfma_chunk<T>(wfr[st % RING], xfr[st % RING][mt], acc[mt]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+      if (p + 1 < K) stage_tile(sg_tile_of(g, (uint32_t)(first + (p + 1) * per_x)));   // into my (now idle) buffer
+      stamp();
+      if (p >= 1) {
+        const sg_tile_origin o = sg_tile_of(g, (uint32_t)(first + (p - 1) * per_x));
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          const int tc = tcoord[mt];
+          const int n = o.n0 + (tc >> 24), d = o.d0 + ((tc >> 16) & 255), h = o.h0 + ((tc >> 8) & 255),
+                    w = o.w0 + (tc & 255);
+          const bool ok = tc >= 0 && n < g.N && d < g.D && h < g.H && w < g.W;
+          float ss = 0.f;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            float v = acc[mt][i] + bias_lds[(i & 3) + 8 * (i >> 2) + 4 * hh];
+            if (a.act) v = fmaxf(v, v * a.slope);
+            acc[mt][i] = v;
+            ss += v * v;
+          }
+          if (a.pixel_norm) {
+            ss += __shfl_xor(ss, 32);
+            const float sc = rsqrtf(ss * inv_c + a.eps);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][i] *= sc;
+            if (a.pn_scale != nullptr && hh == 0 && ok)
+              a.pn_scale[(((int64_t)n * g.D + d) * g.H + h) * g.W + w] = sc;
+          }
+          if (ok) {
+            T* yrow = y + ((((int64_t)n * g.D + d) * g.H + h) * g.W + w) * (int64_t)a.cout;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+              const int co = nt0 * 32 + 8 * qd + 4 * hh;
+              if (a.vec_out && co + 4 <= a.cout) {
+                T tmp[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tmp[e] = sg_traits<T>::from_f(acc[mt][qd * 4 + e]);
+                if (sizeof(T) == 2) *reinterpret_cast<u32x2*>(yrow + co) = *reinterpret_cast<u32x2*>(tmp);
+                else *reinterpret_cast<u32x4*>(yrow + co) = *reinterpret_cast<u32x4*>(tmp);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (co + e < a.cout) yrow[co + e] = sg_traits<T>::from_f(acc[mt][qd * 4 + e]);
+              }
+            }
+          }
+        }
+      }
+    }
+    stamp();
+    __syncthreads();
+  }
+  // the group that computed the last tile (K-1) still holds it: phase K stored it iff ((K & 1) != grp), i.e. the
+  // group (K-1)&1 ran the else-branch in phase K.  Nothing is left over.
+}
+
+template <typename T, int MTW, int GC, int KD, int KH, int KW>
+static int launch_fwd3r(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used) {
+  *used = false;
+  constexpr int BM = MTW * 128;
+  a.g = sg_make_geom(s, BM, /*prefer_w32=*/true);
+  const sg_tile_geom& g = a.g;
+  if (g.TW > 255 || g.TH > 255 || g.TD > 255 || g.TN > 127) return SG_OK;
+  const int64_t ntiles = (int64_t)g.nTn * g.nTd * g.nTh * g.nTw;
+  if (ntiles >= (1 << 24) || ntiles < 512) return SG_OK;   // persistence only pays with many tiles per CU
+  const int hv = g.TN * g.HD * g.HH * g.HW;
+  a.G = GC;
+  a.rs = GC * 32;
+  a.xbytes = ((hv * a.rs) + 1023) & ~1023;
+  a.wbytes = a.taps * GC * 1024;
+  const size_t lds = (size_t)a.wbytes + 2ull * a.xbytes + 128;
+  if (lds > 160 * 1024) return SG_OK;
+  a.ntiles = (int)ntiles;
+  a.vec_in = 1;
+  a.vec_out = (s->cout % 4 == 0) ? 1 : 0;
+  if (sg_cdiv(hv * GC * 2, 64) > 56) return SG_OK;   // more halo DMA pieces than the kernel's per-lane table holds
+  auto kern = conv_fwd3r_kernel<T, MTW, GC, KD, KH, KW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  int gx = 256 / a.ntile;            // one block per CU in total
+  gx = (gx / 8) * 8;
+  if (gx < 8) gx = 8;
+  gx = sg_env_int("SG_FWD3_GX", gx);
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.ntile), dim3(512), lds, st, a);
+  SG_LAUNCH_CHECK();
+  *used = true;
+  return SG_OK;
+}
+
+static unsigned long long* g_dbg_ts = nullptr;
+extern "C" __attribute__((visibility("default"))) void sg_debug_set_ts_buffer(void* p) { g_dbg_ts = (unsigned long long*)p; }
+
 extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_conv_shape* s,
                              const sg_conv_epilogue* ep, sg_dtype dt, sg_stream_t st) {
   if (!conv_shape_ok(s) || !x || !wp || !y) return SG_EINVAL;
@@ -317,6 +846,7 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
   a.slope = ep ? ep->slope : 0.f;
   a.pixel_norm = ep ? ep->pixel_norm : 0;
   a.eps = ep ? ep->eps : 0.f;
+  a.dbg = g_dbg_ts;
   a.cin = s->cin; a.cout = s->cout;
   a.taps = s->kd * s->kh * s->kw; a.kh = s->kh; a.kw = s->kw;
   a.nchunk = conv_nchunk(s, dt);
@@ -325,14 +855,47 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
   sg_prof_scope prof(0, s, dt, sg_st(st));
   int rc;
   hipStream_t hs = sg_st(st);
+  const int es = dt == SG_BF16 ? 2 : 4;
+  const bool v2 = ((s->cin * es) % 16 == 0) && !sg_env_int("SG_FWD_V1", 0);
+  if (v2 && !sg_env_int("SG_FWD_NO_V3", 0) && (!a.pixel_norm || a.ntile == 1)) {
+    bool used = false;
+    rc = SG_OK;
+    const bool k333 = s->kd == 3 && s->kh == 3 && s->kw == 3, k133 = s->kd == 1 && s->kh == 3 && s->kw == 3;
+    if (dt == SG_BF16) {
+      if (k333 && a.nchunk == 2) rc = launch_fwd3r<bf16_t, 2, 2, 3, 3, 3>(a, s, hs, &used);
+      else if (k333 && a.nchunk == 1) rc = launch_fwd3r<bf16_t, 2, 1, 3, 3, 3>(a, s, hs, &used);
+      else if (k133 && a.nchunk == 2) rc = launch_fwd3r<bf16_t, 2, 2, 1, 3, 3>(a, s, hs, &used);
+      else if (k133 && a.nchunk == 1) rc = launch_fwd3r<bf16_t, 2, 1, 1, 3, 3>(a, s, hs, &used);
+    } else {
+      if (k333 && a.nchunk == 2) rc = launch_fwd3r<float, 2, 2, 3, 3, 3>(a, s, hs, &used);
+      else if (k333 && a.nchunk == 1) rc = launch_fwd3r<float, 2, 1, 3, 3, 3>(a, s, hs, &used);
+      else if (k133 && a.nchunk == 2) rc = launch_fwd3r<float, 2, 2, 1, 3, 3>(a, s, hs, &used);
+      else if (k133 && a.nchunk == 1) rc = launch_fwd3r<float, 2, 1, 1, 3, 3>(a, s, hs, &used);
+    }
+    if (rc != SG_OK || used) { prof.done(rc); return rc; }
+  }
   if (dt == SG_BF16) {
-    if (a.ntile == 1) rc = launch_fwd<bf16_t, 2, 1>(a, s, hs);
-    else if (a.ntile == 2) rc = launch_fwd<bf16_t, 2, 2>(a, s, hs);
-    else rc = launch_fwd<bf16_t, 2, 4>(a, s, hs);
+    if (v2) {
+      const bool g2 = a.nchunk >= 2;
+      if (a.ntile == 1) rc = g2 ? launch_fwd2<bf16_t, 2, 1, 2>(a, s, hs) : launch_fwd2<bf16_t, 2, 1, 1>(a, s, hs);
+      else if (a.ntile == 2) rc = g2 ? launch_fwd2<bf16_t, 2, 2, 2>(a, s, hs) : launch_fwd2<bf16_t, 2, 2, 1>(a, s, hs);
+      else rc = g2 ? launch_fwd2<bf16_t, 2, 4, 2>(a, s, hs) : launch_fwd2<bf16_t, 2, 4, 1>(a, s, hs);
+    } else {
+      if (a.ntile == 1) rc = launch_fwd<bf16_t, 2, 1>(a, s, hs);
+      else if (a.ntile == 2) rc = launch_fwd<bf16_t, 2, 2>(a, s, hs);
+      else rc = launch_fwd<bf16_t, 2, 4>(a, s, hs);
+    }
   } else if (dt == SG_F32) {
-    if (a.ntile == 1) rc = launch_fwd<float, 2, 1>(a, s, hs);
-    else if (a.ntile == 2) rc = launch_fwd<float, 2, 2>(a, s, hs);
-    else rc = launch_fwd<float, 2, 4>(a, s, hs);
+    if (v2) {
+      const bool g2 = a.nchunk >= 2;
+      if (a.ntile == 1) rc = g2 ? launch_fwd2<float, 2, 1, 2>(a, s, hs) : launch_fwd2<float, 2, 1, 1>(a, s, hs);
+      else if (a.ntile == 2) rc = g2 ? launch_fwd2<float, 2, 2, 2>(a, s, hs) : launch_fwd2<float, 2, 2, 1>(a, s, hs);
+      else rc = g2 ? launch_fwd2<float, 2, 4, 2>(a, s, hs) : launch_fwd2<float, 2, 4, 1>(a, s, hs);
+    } else {
+      if (a.ntile == 1) rc = launch_fwd<float, 2, 1>(a, s, hs);
+      else if (a.ntile == 2) rc = launch_fwd<float, 2, 2>(a, s, hs);
+      else rc = launch_fwd<float, 2, 4>(a, s, hs);
+    }
   } else {
     rc = SG_EINVAL;
   }

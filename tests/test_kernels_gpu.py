@@ -54,6 +54,8 @@ CONV_CASES = [
     (2, 16, 1, (4, 8, 8), (1, 1, 1)),        # to_rgb shape
     (2, 6, 10, (3, 5, 4), (3, 3, 3)),        # scalar load/store paths
     (1, 16, 16, (5, 20, 40), (3, 3, 3)),     # non power-of-two extents (start shape (1,5,16,16) family)
+    (2, 32, 64, (16, 64, 64), (3, 3, 3)),    # >= 512 tiles: persistent weight-stationary kernel, 2 cout slices
+    (2, 16, 32, (17, 66, 70), (3, 3, 3)),    # same kernel, ragged extents, single K chunk
 ]
 
 

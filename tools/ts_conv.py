@@ -1,0 +1,31 @@
+import ctypes as C, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from saragan_amd import _lib
+from saragan_amd._lib import ConvEpilogue, ConvShape
+lib = _lib.load()
+lib.sg_debug_set_ts_buffer.argtypes = [C.c_void_p]
+dev = torch.device('cuda:0')
+n, d, h, w, cin, cout = 8, 32, 128, 128, 32, 32
+shp = ConvShape(n, d, h, w, cin, cout, 3, 3, 3, 0)
+dt = _lib.SG_BF16
+st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+x = torch.randn(n, d, h, w, cin, device=dev).bfloat16()
+wt = torch.randn(3, 3, 3, cin, cout, device=dev)
+wp = torch.empty(lib.sg_conv3d_packed_bytes(C.byref(shp), dt), device=dev, dtype=torch.uint8)
+_lib.check(lib.sg_conv3d_pack_weights(wt.data_ptr(), 0.05, 0, wp.data_ptr(), C.byref(shp), dt, st))
+y = torch.empty(n, d, h, w, cout, device=dev, dtype=torch.bfloat16)
+bias = torch.zeros(cout, device=dev)
+ep = ConvEpilogue(bias.data_ptr(), 1, 0.2, 0, 1e-8, None)
+for _ in range(3):
+    _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep), dt, st))
+ts = torch.zeros(256, dtype=torch.int64, device=dev)
+lib.sg_debug_set_ts_buffer(ts.data_ptr())
+_lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep), dt, st))
+torch.cuda.synchronize()
+lib.sg_debug_set_ts_buffer(None)
+t = ts.cpu().numpy()
+for g in range(2):
+    v = t[g * 128:(g + 1) * 128]
+    v = v[v > 0]
+    print('group', g, 'n', len(v))
+    print(' deltas:', [int(b - a) for a, b in zip(v[:40], v[1:41])])

@@ -36,6 +36,7 @@ def parse():
     ap.add_argument('--loss', default='wgan', choices=['wgan', 'logistic'])
     ap.add_argument('--alpha', type=float, default=0.0, help='0: stabilising phase; >0: mixing (freeze ops)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dump-prof', action='store_true', help='per-shape conv kernel table on stderr')
     ap.add_argument('--cpu-budget-s', type=float, default=30.0)
     return ap.parse_args()
 
@@ -193,6 +194,14 @@ def main():
         dt = float(t.item())
     if rank != 0:
         return
+    if args.dump_prof:
+        rows = sorted((ents[i] for i in range(n_ent.value)), key=lambda e: -e.total_ms)
+        for e in rows:
+            s_ = e.shape
+            print(f"{'fwd ' if e.kind == 0 else 'wgrd'} n{s_.n} {s_.d}x{s_.h}x{s_.w} {s_.cin:4d}->{s_.cout:4d} k{s_.kd}{s_.kh}{s_.kw} "
+                  f"ups{s_.upsample_in} calls/step {e.launches / args.steps:5.1f} avg {e.total_ms / e.launches * 1e3:8.1f} us "
+                  f"ms/step {e.total_ms / args.steps:7.3f} TF/s {e.flops_per_launch / (e.total_ms / e.launches) / 1e9:7.1f}",
+                  file=sys.stderr)
     vols = args.batch * world * args.steps
     value = vols / dt
     # dominant kernel = the (kind, shape) with the largest total time

@@ -831,6 +831,289 @@ static int launch_fwd3r(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
   return SG_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// forward, v4: persistent 8-wave ping-pong for ANY channel count (multiples of the 16-byte piece): the K loop
+// runs in 32-byte channel chunks (16 bf16 / 8 f32 channels).  A work item is (tile, chunk); group g = item
+// parity owns halo buffer g and weight buffer g.  While group g runs the 27 x MTW x NTB MFMAs of its item, the
+// other group fetches ITS next halo chunk and weight slab (all taps of that chunk, NTB output tiles) by
+// LDS-DMA and, when its previous item closed a tile, runs that tile's epilogue.  One barrier per item.
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int MTW, int NTB, int KD, int KH, int KW>
+__global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TAPS = KD * KH * KW;
+  constexpr int EPP = 16 / (int)sizeof(T);
+  constexpr int CH = sg_traits<T>::CH;
+  const sg_tile_geom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave8 >> 2, wave = wave8 & 3;
+  const int r = lane & 31, hh = lane >> 5;
+  // LDS map: [halo 0][halo 1][weights 0][weights 1][bias: NTB*32 floats]
+  char* xmine = smem + grp * a.xbytes;
+  char* wmine = smem + 2 * a.xbytes + grp * a.wbytes;
+  float* bias_lds = reinterpret_cast<float*>(smem + 2 * a.xbytes + 2 * a.wbytes);
+  const T* x = reinterpret_cast<const T*>(a.x);
+  const char* wp = reinterpret_cast<const char*>(a.wp);
+  constexpr int rb = 32;                      // halo row bytes: one 32-byte chunk, 2 slots, f(row) = (row>>3)&1
+  const int nt0 = blockIdx.y * NTB;
+  const int ntb = min(NTB, a.ntile - nt0);
+  const int tvox = g.TN * g.TD * g.TH * g.TW;
+  const int ncg = a.nchunk;                   // chunks per tile
+
+  const int xg = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int per_x = gridDim.x >> 3;
+  const int cpx = (a.ntiles + 7) >> 3;
+  const int t_begin = xg * cpx;
+  const int t_end = min(a.ntiles, t_begin + cpx);
+  const int first = t_begin + slot;
+  const int K = first < t_end ? (t_end - first + per_x - 1) / per_x : 0;   // tiles of this block
+  const int kmine = (K + 1 - grp) >> 1;                                     // tiles of my group
+  const int items_mine = kmine * ncg;
+  const int items_max = ((K + 1) >> 1) * ncg;                               // group 0 has the most
+
+  int xaddr[TAPS][MTW];
+  int tcoord[MTW];
+#pragma unroll
+  for (int mt = 0; mt < MTW; ++mt) {
+    const int m = (wave * MTW + mt) * 32 + r;
+    uint32_t q = sg_div((uint32_t)m, g.fTW);
+    int tw = m - (int)q * g.TW;
+    uint32_t q2 = sg_div(q, g.fTH);
+    int th = (int)(q - q2 * g.TH);
+    uint32_t q3 = sg_div(q2, g.fTD);
+    int td = (int)(q2 - q3 * g.TD);
+    int tn = (int)q3;
+    const int lrow = (m < tvox) ? (((tn * g.HD + td) * g.HH + th) * g.HW + tw) : 0;
+    tcoord[mt] = (m < tvox) ? (tw | (th << 8) | (td << 16) | (tn << 24)) : -1;
+#pragma unroll
+    for (int kd = 0; kd < KD; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < KW; ++kw) {
+          const int row = lrow + (kd * g.HH + kh) * g.HW + kw;
+          xaddr[(kd * KH + kh) * KW + kw][mt] = grp * a.xbytes + row * rb + ((hh ^ ((row >> 3) & 1)) << 4);
+        }
+  }
+  const int hv = g.TN * g.HD * g.HH * g.HW;
+  const int items = hv * 2;
+  constexpr int MAXIT = 8;
+  int it_rel[MAXIT];   // element offset (chunk 0) relative to the tile's first halo voxel, -1 dead
+  const int Di = g.ups ? (g.D >> 1) : g.D, Hi = g.ups ? (g.H >> 1) : g.H, Wi = g.ups ? (g.W >> 1) : g.W;
+#pragma unroll
+  for (int k = 0; k < MAXIT; ++k) {
+    const int it = (wave + 4 * k) * 64 + lane;
+    const int row = it >> 1;
+    const int sl = (it & 1) ^ ((row >> 3) & 1);
+    uint32_t q = sg_div((uint32_t)row, g.fHW);
+    int hw = (int)(row - q * g.HW);
+    uint32_t q2 = sg_div(q, g.fHH);
+    int hh_ = (int)(q - q2 * g.HH);
+    uint32_t q3 = sg_div(q2, g.fHD);
+    int hd = (int)(q2 - q3 * g.HD);
+    it_rel[k] = row < hv ? ((((int)q3 * g.D + hd) * g.H + hh_) * g.W + hw) * a.cin + sl * EPP : -1;
+  }
+
+  auto tile_of_item = [&](int q) { return first + (2 * (q / ncg) + grp) * per_x; };
+
+  auto stage_item = [&](int q) {
+    const int t = tile_of_item(q);
+    const int cg = q % ncg;
+    const sg_tile_origin o = sg_tile_of(g, (uint32_t)t);
+    const int c0 = cg * CH;
+    const bool interior = !g.ups && o.d0 >= g.PD && o.h0 >= g.PH && o.w0 >= g.PW && o.d0 + g.TD + g.PD <= g.D &&
+                          o.h0 + g.TH + g.PH <= g.H && o.w0 + g.TW + g.PW <= g.W && o.n0 + g.TN <= g.N &&
+                          c0 + CH <= a.cin;
+    if (interior) {
+      const T* base = x + ((((int64_t)o.n0 * g.D + (o.d0 - g.PD)) * g.H + (o.h0 - g.PH)) * g.W + (o.w0 - g.PW)) *
+                              (int64_t)a.cin + c0;
+#pragma unroll
+      for (int k = 0; k < MAXIT; ++k)
+        if ((wave + 4 * k) * 64 < items)
+          sg_glds16(it_rel[k] >= 0 ? (const void*)(base + it_rel[k]) : (const void*)sg_zero_page,
+                    xmine + (size_t)(wave + 4 * k) * 1024);
+    } else {
+#pragma unroll 1
+      for (int k = 0; k < MAXIT; ++k) {
+        if ((wave + 4 * k) * 64 < items) {
+          const int it = (wave + 4 * k) * 64 + lane;
+          const int row = it >> 1;
+          const int sl = (it & 1) ^ ((row >> 3) & 1);
+          uint32_t q_ = sg_div((uint32_t)row, g.fHW);
+          int hw = (int)(row - q_ * g.HW);
+          uint32_t q2 = sg_div(q_, g.fHH);
+          int hh_ = (int)(q_ - q2 * g.HH);
+          uint32_t q3 = sg_div(q2, g.fHD);
+          int hd = (int)(q2 - q3 * g.HD);
+          int n = o.n0 + (int)q3, d = o.d0 + hd - g.PD, h = o.h0 + hh_ - g.PH, w = o.w0 + hw - g.PW;
+          const int c = c0 + sl * EPP;
+          const void* src = sg_zero_page;
+          if (row < hv && c < a.cin && n < g.N && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H &&
+              (unsigned)w < (unsigned)g.W) {
+            if (g.ups) { d >>= 1; h >>= 1; w >>= 1; }
+            src = x + ((((int64_t)n * Di + d) * Hi + h) * Wi + w) * (int64_t)a.cin + c;
+          }
+          sg_glds16(src, xmine + (size_t)(wave + 4 * k) * 1024);
+        }
+      }
+    }
+    // weight slab of this chunk: [tap][nt] fragments
+    constexpr int nfrag = TAPS * NTB;
+    for (int f = wave; f < nfrag; f += 4) {
+      const int tap = f / NTB, nt = f - tap * NTB;
+      const char* src = nt < ntb ? wp + ((((int64_t)cg * TAPS + tap) * a.ntile + (nt0 + nt)) << 10)
+                                 : reinterpret_cast<const char*>(sg_zero_page);
+      sg_glds16(src + lane * 16, wmine + ((size_t)f << 10));
+    }
+  };
+
+  if (tid < NTB * 32) {
+    const int co = nt0 * 32 + tid;
+    bias_lds[tid] = (a.bias != nullptr && co < a.cout) ? a.bias[co] : 0.f;
+  }
+  if (grp == 0 && items_mine > 0) stage_item(0);
+  __syncthreads();
+
+  const char* wl = wmine + lane * 16;
+  T* y = reinterpret_cast<T*>(a.y);
+  const float inv_c = 1.f / (float)a.cout;
+  f32x16 acc[MTW][NTB];
+
+  const int nphase = 2 * items_max + 1;
+  for (int p = 0; p < nphase; ++p) {
+    const int q = p >> 1;                      // item index within the running group
+    if ((p & 1) == grp) {
+      if (q < items_mine) {
+        if (q % ncg == 0) {
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+              for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+        }
+        constexpr int RING = 3, PF = RING - 1;
+        u32x4 wfr[RING][NTB], xfr[RING][MTW];
+        auto ld = [&](int tap, int sl_) {
+#pragma unroll
+          for (int nt = 0; nt < NTB; ++nt)
+            wfr[sl_][nt] = *reinterpret_cast<const u32x4*>(wl + ((tap * NTB + nt) << 10));
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt) xfr[sl_][mt] = *reinterpret_cast<const u32x4*>(smem + xaddr[tap][mt]);
+        };
+#pragma unroll
+        for (int st = 0; st < PF && st < TAPS; ++st) ld(st, st % RING);
+#pragma unroll
+        for (int st = 0; st < TAPS; ++st) {
+          if (st + PF < TAPS) ld(st + PF, (st + PF) % RING);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTB; ++nt)
+              acc[mt][nt] = sg_mfma_chunk<T>(wfr[st % RING][nt], xfr[st % RING][mt], acc[mt][nt]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
+      // my next item is q' = (p + 1) >> 1; my previous one q' - 1 (ran in phase p - 1)
+      const int qn = (p + 1) >> 1;
+      if (qn < items_mine) stage_item(qn);
+      const int qp = qn - 1;
+      if (qp >= 0 && qp < items_mine && (qp % ncg) == ncg - 1) {
+        const sg_tile_origin o = sg_tile_of(g, (uint32_t)tile_of_item(qp));
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          const int tc = tcoord[mt];
+          const int n = o.n0 + (tc >> 24), d = o.d0 + ((tc >> 16) & 255), h = o.h0 + ((tc >> 8) & 255),
+                    w = o.w0 + (tc & 255);
+          const bool ok = tc >= 0 && n < g.N && d < g.D && h < g.H && w < g.W;
+          float ss = 0.f;
+#pragma unroll
+          for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              float v = acc[mt][nt][i] + bias_lds[nt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];
+              if (a.act) v = fmaxf(v, v * a.slope);
+              acc[mt][nt][i] = v;
+              ss += v * v;
+            }
+          if (a.pixel_norm) {
+            ss += __shfl_xor(ss, 32);
+            const float sc = rsqrtf(ss * inv_c + a.eps);
+#pragma unroll
+            for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+              for (int i = 0; i < 16; ++i) acc[mt][nt][i] *= sc;
+            if (a.pn_scale != nullptr && hh == 0 && ok)
+              a.pn_scale[(((int64_t)n * g.D + d) * g.H + h) * g.W + w] = sc;
+          }
+          if (ok) {
+            T* yrow = y + ((((int64_t)n * g.D + d) * g.H + h) * g.W + w) * (int64_t)a.cout;
+#pragma unroll
+            for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+              for (int qd = 0; qd < 4; ++qd) {
+                const int co = (nt0 + nt) * 32 + 8 * qd + 4 * hh;
+                if (a.vec_out && co + 4 <= a.cout) {
+                  T tmp[4];
+#pragma unroll
+                  for (int e = 0; e < 4; ++e) tmp[e] = sg_traits<T>::from_f(acc[mt][nt][qd * 4 + e]);
+                  if (sizeof(T) == 2) *reinterpret_cast<u32x2*>(yrow + co) = *reinterpret_cast<u32x2*>(tmp);
+                  else *reinterpret_cast<u32x4*>(yrow + co) = *reinterpret_cast<u32x4*>(tmp);
+                } else {
+#pragma unroll
+                  for (int e = 0; e < 4; ++e)
+                    if (co + e < a.cout) yrow[co + e] = sg_traits<T>::from_f(acc[mt][nt][qd * 4 + e]);
+                }
+              }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T, int MTW, int NTB, int KD, int KH, int KW>
+static int launch_fwd4(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used) {
+  *used = false;
+  constexpr int BM = MTW * 128;
+  a.g = sg_make_geom(s, BM, /*prefer_w32=*/true);
+  const sg_tile_geom& g = a.g;
+  if (g.TW > 255 || g.TH > 255 || g.TD > 255 || g.TN > 127) return SG_OK;
+  const int64_t ntiles = (int64_t)g.nTn * g.nTd * g.nTh * g.nTw;
+  const int ny = sg_cdiv(a.ntile, NTB);
+  int gx = (256 / ny) / 8 * 8;
+  if (gx < 8) gx = 8;
+  if (ntiles >= (1 << 24) || ntiles < 2 * gx) return SG_OK;
+  if ((int64_t)s->n * s->d * s->h * s->w * (int64_t)s->cin >= (1ll << 31)) return SG_OK;
+  const int hv = g.TN * g.HD * g.HH * g.HW;
+  a.G = 1;
+  a.rs = 32;
+  a.xbytes = ((hv * 32) + 1023) & ~1023;
+  a.wbytes = a.taps * NTB * 1024;
+  if (sg_cdiv(hv * 2, 64) > 32) return SG_OK;
+  const size_t lds = 2ull * a.xbytes + 2ull * a.wbytes + NTB * 128;
+  if (lds > 160 * 1024) return SG_OK;
+  a.ntiles = (int)ntiles;
+  a.vec_in = 1;
+  a.vec_out = (s->cout % 4 == 0) ? 1 : 0;
+  auto kern = conv_fwd4_kernel<T, MTW, NTB, KD, KH, KW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ny), dim3(512), lds, st, a);
+  SG_LAUNCH_CHECK();
+  *used = true;
+  return SG_OK;
+}
+
 static unsigned long long* g_dbg_ts = nullptr;
 extern "C" __attribute__((visibility("default"))) void sg_debug_set_ts_buffer(void* p) { g_dbg_ts = (unsigned long long*)p; }
 
@@ -874,30 +1157,58 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     }
     if (rc != SG_OK || used) { prof.done(rc); return rc; }
   }
-  if (dt == SG_BF16) {
-    if (v2) {
-      const bool g2 = a.nchunk >= 2;
-      if (a.ntile == 1) rc = g2 ? launch_fwd2<bf16_t, 2, 1, 2>(a, s, hs) : launch_fwd2<bf16_t, 2, 1, 1>(a, s, hs);
-      else if (a.ntile == 2) rc = g2 ? launch_fwd2<bf16_t, 2, 2, 2>(a, s, hs) : launch_fwd2<bf16_t, 2, 2, 1>(a, s, hs);
-      else rc = g2 ? launch_fwd2<bf16_t, 2, 4, 2>(a, s, hs) : launch_fwd2<bf16_t, 2, 4, 1>(a, s, hs);
+  if (v2 && !sg_env_int("SG_FWD_NO_V4", 0) && (!a.pixel_norm || a.ntile <= 2)) {
+    bool used = false;
+    rc = SG_OK;
+    const bool k333 = s->kd == 3 && s->kh == 3 && s->kw == 3, k133 = s->kd == 1 && s->kh == 3 && s->kw == 3;
+    const bool n1 = a.ntile == 1;
+    if (dt == SG_BF16) {
+      if (k333) rc = n1 ? launch_fwd4<bf16_t, 2, 1, 3, 3, 3>(a, s, hs, &used) : launch_fwd4<bf16_t, 2, 2, 3, 3, 3>(a, s, hs, &used);
+      else if (k133) rc = n1 ? launch_fwd4<bf16_t, 2, 1, 1, 3, 3>(a, s, hs, &used) : launch_fwd4<bf16_t, 2, 2, 1, 3, 3>(a, s, hs, &used);
     } else {
-      if (a.ntile == 1) rc = launch_fwd<bf16_t, 2, 1>(a, s, hs);
-      else if (a.ntile == 2) rc = launch_fwd<bf16_t, 2, 2>(a, s, hs);
-      else rc = launch_fwd<bf16_t, 2, 4>(a, s, hs);
+      if (k333) rc = n1 ? launch_fwd4<float, 2, 1, 3, 3, 3>(a, s, hs, &used) : launch_fwd4<float, 2, 2, 3, 3, 3>(a, s, hs, &used);
+      else if (k133) rc = n1 ? launch_fwd4<float, 2, 1, 1, 3, 3>(a, s, hs, &used) : launch_fwd4<float, 2, 2, 1, 3, 3>(a, s, hs, &used);
     }
-  } else if (dt == SG_F32) {
-    if (v2) {
-      const bool g2 = a.nchunk >= 2;
-      if (a.ntile == 1) rc = g2 ? launch_fwd2<float, 2, 1, 2>(a, s, hs) : launch_fwd2<float, 2, 1, 1>(a, s, hs);
-      else if (a.ntile == 2) rc = g2 ? launch_fwd2<float, 2, 2, 2>(a, s, hs) : launch_fwd2<float, 2, 2, 1>(a, s, hs);
-      else rc = g2 ? launch_fwd2<float, 2, 4, 2>(a, s, hs) : launch_fwd2<float, 2, 4, 1>(a, s, hs);
-    } else {
-      if (a.ntile == 1) rc = launch_fwd<float, 2, 1>(a, s, hs);
-      else if (a.ntile == 2) rc = launch_fwd<float, 2, 2>(a, s, hs);
-      else rc = launch_fwd<float, 2, 4>(a, s, hs);
+    if (rc != SG_OK || used) { prof.done(rc); return rc; }
+  }
+  // v2 / v1: pick the largest register tile (MTW x NTB) that still fills the chip; low-resolution layers with few
+  // voxels get 128-voxel tiles and single 32-channel output slices so that the grid has enough blocks.
+  {
+    const int cand[5][2] = {{2, 4}, {2, 2}, {2, 1}, {1, 2}, {1, 1}};
+    int best = -1;
+    int64_t best_blocks = -1;
+    for (int i = 0; i < 5; ++i) {
+      const int mtw = cand[i][0], ntb = cand[i][1];
+      if (ntb > 1 && ntb / 2 >= a.ntile) continue;               // wider than the layer
+      if (a.pixel_norm && ntb < a.ntile) continue;                // pixel-norm needs every channel in the block
+      if (!v2 && mtw == 1) continue;
+      sg_tile_geom gg = sg_make_geom(s, mtw * 128, v2);
+      const int64_t blocks = (int64_t)gg.nTn * gg.nTd * gg.nTh * gg.nTw * sg_cdiv(a.ntile, ntb);
+      if (blocks >= 384) { best = i; break; }
+      if (blocks > best_blocks) { best_blocks = blocks; best = i; }
     }
-  } else {
-    rc = SG_EINVAL;
+    if (best < 0) best = 0;
+    const int mtw = cand[best][0], ntb = cand[best][1];
+    const int gc = !v2 ? 0 : (a.nchunk >= 4 && a.taps <= 9 ? 4 : (a.nchunk >= 2 ? 2 : 1));
+#define SG_FWD2(T, M, N)                                                                                   \
+  (gc == 4 ? launch_fwd2<T, M, N, 4>(a, s, hs) : gc == 2 ? launch_fwd2<T, M, N, 2>(a, s, hs)                \
+                                                       : launch_fwd2<T, M, N, 1>(a, s, hs))
+#define SG_FWD_PICK(T)                                                                                     \
+  do {                                                                                                     \
+    if (!v2) {                                                                                             \
+      rc = ntb == 4 ? launch_fwd<T, 2, 4>(a, s, hs) : ntb == 2 ? launch_fwd<T, 2, 2>(a, s, hs)              \
+                                                              : launch_fwd<T, 2, 1>(a, s, hs);              \
+    } else if (mtw == 2) {                                                                                 \
+      rc = ntb == 4 ? SG_FWD2(T, 2, 4) : ntb == 2 ? SG_FWD2(T, 2, 2) : SG_FWD2(T, 2, 1);                    \
+    } else {                                                                                               \
+      rc = ntb == 2 ? SG_FWD2(T, 1, 2) : SG_FWD2(T, 1, 1);                                                  \
+    }                                                                                                      \
+  } while (0)
+    if (dt == SG_BF16) SG_FWD_PICK(bf16_t);
+    else if (dt == SG_F32) SG_FWD_PICK(float);
+    else rc = SG_EINVAL;
+#undef SG_FWD_PICK
+#undef SG_FWD2
   }
   prof.done(rc);
   return rc;

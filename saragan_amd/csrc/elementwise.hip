@@ -124,12 +124,22 @@ __global__ void bias_act_bwd_scalar_kernel(const T* __restrict__ dy, const T* __
   }
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ part, float* __restrict__ out, int nb, int c) {
-  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ch >= c) return;
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                              int nb, int c) {
+  // one block per 32 channels: 8 row-groups x 32 channels, coalesced 128-byte rows, LDS tree at the end
+  __shared__ float red[8][32];
+  const int ch = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
   float s = 0.f;
-  for (int b = 0; b < nb; ++b) s += part[(int64_t)b * c + ch];
-  out[ch] = s;
+  if (ch < c)
+    for (int b = rg; b < nb; b += 8) s += part[(int64_t)b * c + ch];
+  red[rg][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (rg == 0 && ch < c) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+    out[ch] = t;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -447,7 +457,7 @@ extern "C" int sg_bias_act_fwd(const void* x, const float* bias, void* y, int64_
   return SG_OK;
 }
 
-static const int kBwdBlocks = 512;
+static const int kBwdBlocks = 1024;
 extern "C" size_t sg_bias_act_bwd_workspace(int32_t c) { return (size_t)kBwdBlocks * (size_t)(c > 0 ? c : 0) * sizeof(float); }
 
 extern "C" int sg_bias_act_bwd(const void* dy, const void* y, void* dx, float* dbias, void* workspace, int64_t nvox,
@@ -475,7 +485,7 @@ extern "C" int sg_bias_act_bwd(const void* dy, const void* y, void* dx, float* d
   }
   SG_LAUNCH_CHECK();
   if (dbias) {
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, hs, part, dbias, blocks, c);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 31) / 32), dim3(256), 0, hs, part, dbias, blocks, c);
     SG_LAUNCH_CHECK();
   }
   return SG_OK;

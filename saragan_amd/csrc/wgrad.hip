@@ -10,6 +10,7 @@
 // tile-ordered workspace, then scaled and re-laid out to DHWIO by a finalize kernel.
 #include "common.h"
 #include "prof.h"
+#include <stdlib.h>
 
 struct WgradArgs {
   const void* x;
@@ -165,10 +166,81 @@ static int conv_shape_ok_w(const sg_conv_shape* s) {
   return 1;
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// 1x1x1 weight gradient with a tiny channel count on one side (from_rgb: cin = image channels, to_rgb: cout =
+// image channels; networks/ops.py:239-247): dw[ci][co] = sum_v x[v][ci] * dy[v][co] is a column reduction,
+// HBM-bound.  "small" has cs <= 4 channels, "big" has cb channels (16-byte pieces, pieces | 256).
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pw_wgrad_partial_kernel(const T* __restrict__ small, const T* __restrict__ big,
+                                                               float* __restrict__ part, int64_t nvox, int cs, int cb) {
+  constexpr int E = 16 / (int)sizeof(T);
+  __shared__ float red[256 * E];
+  const int P = cb / E, rows = 256 / P;
+  const int p = threadIdx.x % P, rr = threadIdx.x / P;
+  float s[4][E];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < E; ++e) s[j][e] = 0.f;
+  for (int64_t v = (int64_t)blockIdx.x * rows + rr; v < nvox; v += (int64_t)gridDim.x * rows) {
+    u32x4 raw = *reinterpret_cast<const u32x4*>(big + v * cb + (int64_t)p * E);
+    const T* bt = reinterpret_cast<const T*>(&raw);
+    float bv[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) bv[e] = sg_traits<T>::to_f(bt[e]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < cs) {
+        const float sv = sg_traits<T>::to_f(small[v * cs + j]);
+#pragma unroll
+        for (int e = 0; e < E; ++e) s[j][e] += sv * bv[e];
+      }
+    }
+  }
+  for (int j = 0; j < cs; ++j) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < E; ++e) red[threadIdx.x * E + e] = s[j][e];
+    __syncthreads();
+    if (threadIdx.x < P) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        float t = 0.f;
+        for (int k = 0; k < rows; ++k) t += red[(k * P + threadIdx.x) * E + e];
+        part[((int64_t)blockIdx.x * cs + j) * cb + threadIdx.x * E + e] = t;
+      }
+    }
+  }
+}
+
+// dw[ci][co] = coef * sum_b part[b][j][i]; small_is_cin: (j, i) = (ci, co) else (j, i) = (co, ci)
+__global__ __launch_bounds__(256) void pw_wgrad_final_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                             float coef, int nb, int cs, int cb, int small_is_cin) {
+  __shared__ float red[8][32];
+  const int col = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+  const int c = cs * cb;
+  float sum = 0.f;
+  if (col < c)
+    for (int b = rg; b < nb; b += 8) sum += part[(int64_t)b * c + col];
+  red[rg][threadIdx.x & 31] = sum;
+  __syncthreads();
+  if (rg == 0 && col < c) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
+    const int j = col / cb, i = col - j * cb;
+    dw[small_is_cin ? (j * cb + i) : (i * cs + j)] = coef * t;
+  }
+}
+
 extern "C" size_t sg_conv3d_wgrad_workspace(const sg_conv_shape* s, sg_dtype dt) {
   (void)dt;
   if (!conv_shape_ok_w(s)) return 0;
-  return (size_t)(s->kd * s->kh * s->kw) * sg_cdiv(s->cin, 32) * sg_cdiv(s->cout, 32) * 4096;
+  size_t need = (size_t)(s->kd * s->kh * s->kw) * sg_cdiv(s->cin, 32) * sg_cdiv(s->cout, 32) * 4096;
+  const size_t pw = (size_t)1024 * 4 * (size_t)(s->cin > s->cout ? s->cin : s->cout) * sizeof(float);
+  return need > pw ? need : pw;
 }
 
 template <typename T, int BM>
@@ -215,6 +287,252 @@ static int launch_wgrad(WgradArgs& a, const sg_conv_shape* s, hipStream_t st) {
   return SG_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// wgrad v2 (bf16, tiles 32 voxels wide): persistent 8-wave ping-pong.  Two groups of 4 waves alternate: while
+// group g runs the MFMAs of its tile out of its own LDS images (x halo + dy tile, plain 64-byte rows: the
+// transposing reads of 4 consecutive rows are bank-conflict free), the other group fetches its next tile by
+// LDS-DMA.  Accumulators persist over all tiles of the block; one f32 atomic pass at the end.
+// ------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(1024))) uint32_t sg_zero_page_w[256] = {0};
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+__device__ __forceinline__ void sg_glds16w(const void* gp, char* lds_uniform_base) {
+  __builtin_amdgcn_global_load_lds((gbl_ptr_t)gp, (lds_ptr_t)lds_uniform_base, 16, 0, 0);
+}
+
+template <int KD, int KH, int KW>
+__global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16_t T;
+  constexpr int TAPS = KD * KH * KW;
+  constexpr int MAXT = (TAPS + 3) / 4;            // taps per wave
+  constexpr int BM = 256, KSTEPS = BM / 16;
+  const sg_tile_geom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave8 >> 2, wave = wave8 & 3;
+  const int bufbytes = a.xbytes + a.ybytes;
+  char* xmine = smem + grp * bufbytes;
+  char* ymine = xmine + a.xbytes;
+  const T* x = reinterpret_cast<const T*>(a.x);
+  const T* dy = reinterpret_cast<const T*>(a.dy);
+  const int ci_t = blockIdx.y / a.coT, co_t = blockIdx.y % a.coT;
+
+  // tile schedule (same XCD-chunked dealing as the forward kernel)
+  const int xg = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int per_x = gridDim.x >> 3;
+  const int cpx = (a.ntiles + 7) >> 3;
+  const int t_begin = xg * cpx;
+  const int t_end = min(a.ntiles, t_begin + cpx);
+  const int first = t_begin + slot;
+  const int K = first < t_end ? (t_end - first + per_x - 1) / per_x : 0;
+
+  // transposing-read lane geometry: 16-lane group q16, lane (qd, pp) supplies row qd, columns 4pp..4pp+3
+  const int i16 = lane & 15, q16 = lane >> 4;
+  const int qd = i16 >> 2, pp = i16 & 3;
+  const int colb = (16 * (q16 & 1) + 4 * pp) * 2;
+  const int kb = 8 * (q16 >> 1) + qd;
+  // lane-constant byte offsets of the two reads of a K step (rows kb, kb+4 of the 16-voxel run)
+  const int xl0 = (int)(xmine - smem) + kb * 64 + colb, xl1 = xl0 + 4 * 64;
+  const int yl0 = (int)(ymine - smem) + kb * 64 + colb, yl1 = yl0 + 4 * 64;
+
+  // halo staging tables: element offset relative to the tile's first halo voxel (-1: dead piece)
+  const int hvx = g.TN * g.HD * g.HH * g.HW, itx = hvx * 4;
+  const int hvy = g.TN * g.TD * g.TH * g.TW, ity = hvy * 4;
+  constexpr int MAXX = 14, MAXY = 4;
+  int relx[MAXX], rely[MAXY];
+#pragma unroll
+  for (int k = 0; k < MAXX; ++k) {
+    const int it = (wave + 4 * k) * 64 + lane;
+    const int row = it >> 2, c = ci_t * 32 + (it & 3) * 8;
+    uint32_t q = sg_div((uint32_t)row, g.fHW);
+    int hw = (int)(row - q * g.HW);
+    uint32_t q2 = sg_div(q, g.fHH);
+    int hh_ = (int)(q - q2 * g.HH);
+    uint32_t q3 = sg_div(q2, g.fHD);
+    int hd = (int)(q2 - q3 * g.HD);
+    relx[k] = (row < hvx && c < a.cin) ? ((((int)q3 * g.D + hd) * g.H + hh_) * g.W + hw) * a.cin + c : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < MAXY; ++k) {
+    const int it = (wave + 4 * k) * 64 + lane;
+    const int row = it >> 2, c = co_t * 32 + (it & 3) * 8;
+    uint32_t q = sg_div((uint32_t)row, g.fTW);
+    int tw = (int)(row - q * g.TW);
+    uint32_t q2 = sg_div(q, g.fTH);
+    int th = (int)(q - q2 * g.TH);
+    uint32_t q3 = sg_div(q2, g.fTD);
+    int td = (int)(q2 - q3 * g.TD);
+    rely[k] = (row < hvy && c < a.cout) ? ((((int)q3 * g.D + td) * g.H + th) * g.W + tw) * a.cout + c : -1;
+  }
+
+  auto stage_tile = [&](const sg_tile_origin& o) {
+    const bool interior = o.d0 >= g.PD && o.h0 >= g.PH && o.w0 >= g.PW && o.d0 + g.TD + g.PD <= g.D &&
+                          o.h0 + g.TH + g.PH <= g.H && o.w0 + g.TW + g.PW <= g.W && o.n0 + g.TN <= g.N;
+    const int64_t v0 = (((int64_t)o.n0 * g.D + o.d0) * g.H + o.h0) * g.W + o.w0;   // first tile voxel
+    const T* ybase = dy + v0 * a.cout;
+    const T* xbase = x + (v0 - ((int64_t)g.PD * g.H + g.PH) * g.W - g.PW) * a.cin;
+    if (interior) {
+#pragma unroll
+      for (int k = 0; k < MAXX; ++k)
+        if ((wave + 4 * k) * 64 < itx)
+          sg_glds16w(relx[k] >= 0 ? (const void*)(xbase + relx[k]) : (const void*)sg_zero_page_w,
+                     xmine + (size_t)(wave + 4 * k) * 1024);
+#pragma unroll
+      for (int k = 0; k < MAXY; ++k)
+        if ((wave + 4 * k) * 64 < ity)
+          sg_glds16w(rely[k] >= 0 ? (const void*)(ybase + rely[k]) : (const void*)sg_zero_page_w,
+                     ymine + (size_t)(wave + 4 * k) * 1024);
+    } else {   // boundary tile: recompute coordinates per piece (kept rolled: it must not cost registers)
+#pragma unroll 1
+      for (int k = 0; k < MAXX; ++k) {
+        if ((wave + 4 * k) * 64 < itx) {
+          const int it = (wave + 4 * k) * 64 + lane;
+          const int row = it >> 2, c = ci_t * 32 + (it & 3) * 8;
+          uint32_t q = sg_div((uint32_t)row, g.fHW);
+          int hw = (int)(row - q * g.HW);
+          uint32_t q2 = sg_div(q, g.fHH);
+          int hh_ = (int)(q - q2 * g.HH);
+          uint32_t q3 = sg_div(q2, g.fHD);
+          int hd = (int)(q2 - q3 * g.HD);
+          const int n = o.n0 + (int)q3, d = o.d0 + hd - g.PD, h = o.h0 + hh_ - g.PH, w = o.w0 + hw - g.PW;
+          const bool ok = row < hvx && c < a.cin && n < g.N && (unsigned)d < (unsigned)g.D &&
+                          (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
+          const int rel = ((((int)q3 * g.D + hd) * g.H + hh_) * g.W + hw) * a.cin + c;
+          sg_glds16w(ok ? (const void*)(xbase + rel) : (const void*)sg_zero_page_w,
+                     xmine + (size_t)(wave + 4 * k) * 1024);
+        }
+      }
+#pragma unroll 1
+      for (int k = 0; k < MAXY; ++k) {
+        if ((wave + 4 * k) * 64 < ity) {
+          const int it = (wave + 4 * k) * 64 + lane;
+          const int row = it >> 2, c = co_t * 32 + (it & 3) * 8;
+          uint32_t q = sg_div((uint32_t)row, g.fTW);
+          int tw = (int)(row - q * g.TW);
+          uint32_t q2 = sg_div(q, g.fTH);
+          int th = (int)(q - q2 * g.TH);
+          uint32_t q3 = sg_div(q2, g.fTD);
+          int td = (int)(q2 - q3 * g.TD);
+          const int n = o.n0 + (int)q3, d = o.d0 + td, h = o.h0 + th, w = o.w0 + tw;
+          const bool ok = row < hvy && c < a.cout && n < g.N && d < g.D && h < g.H && w < g.W;
+          const int rel = ((((int)q3 * g.D + td) * g.H + th) * g.W + tw) * a.cout + c;
+          sg_glds16w(ok ? (const void*)(ybase + rel) : (const void*)sg_zero_page_w,
+                     ymine + (size_t)(wave + 4 * k) * 1024);
+        }
+      }
+    }
+  };
+
+  // per-wave taps: tap = wave + 4*j; byte offset of the tap's row shift in the halo image
+  int tapoff[MAXT];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    const int tap = wave + 4 * j;
+    const int kw_i = tap % KW, kh_i = (tap / KW) % KH, kd_i = tap / (KW * KH);
+    tapoff[j] = tap < TAPS ? ((kd_i * g.HH + kh_i) * g.HW + kw_i) * 64 : 0;
+  }
+  // byte offset of the (td, th) line of K step pair j in the halo image / dy image
+  // (tile is TD x TH x 32: K steps 2j, 2j+1 cover line j)
+  f32x16 acc[MAXT];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  if (grp == 0 && K > 0) stage_tile(sg_tile_of(g, (uint32_t)first));
+  __syncthreads();
+
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
+  for (int p = 0; p <= K; ++p) {
+    if ((p & 1) == grp) {
+      if (p < K) {
+        int td = 0, th = 0;
+        for (int line = 0; line < KSTEPS / 2; ++line) {      // one (td, th) line of 32 voxels = 2 K steps
+          const int xl = ((td * g.HH + th) * g.HW) * 64;
+          if (++th == g.TH) { th = 0; ++td; }
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int xline = xl + half * 16 * 64;
+            const int yline = (line * 2 + half) * 16 * 64;
+            s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(smem + yl0 + yline));
+            s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(smem + yl1 + yline));
+            u32x4 bf;
+            bf[0] = __builtin_bit_cast(u32x2, b0)[0]; bf[1] = __builtin_bit_cast(u32x2, b0)[1];
+            bf[2] = __builtin_bit_cast(u32x2, b1)[0]; bf[3] = __builtin_bit_cast(u32x2, b1)[1];
+#pragma unroll
+            for (int j = 0; j < MAXT; ++j) {
+              if (wave + 4 * j < TAPS) {
+                s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(smem + xl0 + xline + tapoff[j]));
+                s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(smem + xl1 + xline + tapoff[j]));
+                u32x4 af;
+                af[0] = __builtin_bit_cast(u32x2, a0)[0]; af[1] = __builtin_bit_cast(u32x2, a0)[1];
+                af[2] = __builtin_bit_cast(u32x2, a1)[0]; af[3] = __builtin_bit_cast(u32x2, a1)[1];
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af),
+                                                                __builtin_bit_cast(bf16x8, bf), acc[j], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+    } else {
+      if (p + 1 < K) stage_tile(sg_tile_of(g, (uint32_t)(first + (p + 1) * per_x)));
+    }
+    __syncthreads();
+  }
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    const int tap = wave + 4 * j;
+    if (tap < TAPS && K > 0) {
+      float* dst = a.dwt + ((((int64_t)tap * a.ciT + ci_t) * a.coT + co_t) << 10);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+        unsafeAtomicAdd(dst + row * 32 + r, acc[j][i]);
+      }
+    }
+  }
+}
+
+template <int KD, int KH, int KW>
+static int launch_wgrad2(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used) {
+  *used = false;
+  a.g = sg_make_geom(s, 256, /*prefer_w32=*/true);
+  const sg_tile_geom& g = a.g;
+  if (g.TW != 32 || g.TN != 1 || g.TD * g.TH * g.TW != 256 || s->upsample_in) return SG_OK;
+  if ((s->cin % 8) || (s->cout % 8)) return SG_OK;
+  if ((int64_t)s->n * s->d * s->h * s->w * (int64_t)(s->cin > s->cout ? s->cin : s->cout) >= (1ll << 31)) return SG_OK;
+  const int64_t ntiles = (int64_t)g.nTn * g.nTd * g.nTh * g.nTw;
+  const int pairs = a.ciT * a.coT;
+  int gx = (256 / pairs) / 8 * 8;
+  if (gx < 8) gx = 8;
+  if (ntiles >= (1 << 24) || ntiles < 2 * gx) return SG_OK;
+  a.gy = a.g;
+  a.ntiles = (int)ntiles;
+  a.rs = 64;
+  const int hv = g.TN * g.HD * g.HH * g.HW;
+  a.xbytes = (hv * 64 + 1023) & ~1023;
+  a.ybytes = 256 * 64;
+  if (sg_cdiv(hv * 4, 64) > 56) return SG_OK;
+  const size_t lds = 2ull * (a.xbytes + a.ybytes);
+  if (lds > 160 * 1024) return SG_OK;
+  auto kern = conv_wgrad2_kernel<KD, KH, KW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  a.tap0 = 0; a.taps_blk = a.taps;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);
+  SG_LAUNCH_CHECK();
+  *used = true;
+  return SG_OK;
+}
+
 extern "C" int sg_conv3d_wgrad(const void* x, const void* dy, float* dw, float coef, void* workspace,
                                size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st) {
   if (!conv_shape_ok_w(s) || !x || !dy || !dw || !workspace) return SG_EINVAL;
@@ -223,15 +541,49 @@ extern "C" int sg_conv3d_wgrad(const void* x, const void* dy, float* dw, float c
   if (workspace_bytes < need) return SG_EWORKSPACE;
   hipStream_t hs = sg_st(st);
   sg_prof_scope prof(1, s, dt, hs);
-  hipError_t e = hipMemsetAsync(workspace, 0, need, hs);
+  {  // pointwise conv with <= 4 channels on one side: column reduction
+    const int taps1 = s->kd * s->kh * s->kw;
+    const int cs = s->cin < s->cout ? s->cin : s->cout, cb = s->cin < s->cout ? s->cout : s->cin;
+    const int E = dt == SG_BF16 ? 8 : 4;
+    if (taps1 == 1 && cs <= 4 && !s->upsample_in && cb % E == 0 && cb / E <= 256 && 256 % (cb / E) == 0) {
+      const int small_is_cin = s->cin <= s->cout ? 1 : 0;
+      const void* sm = small_is_cin ? x : dy;
+      const void* bg = small_is_cin ? dy : x;
+      const int64_t nvox = (int64_t)s->n * s->d * s->h * s->w;
+      const int rows = 256 / (cb / E);
+      int64_t nb = (nvox + rows - 1) / rows;
+      if (nb > 1024) nb = 1024;
+      float* part = reinterpret_cast<float*>(workspace);
+      if (dt == SG_BF16)
+        hipLaunchKernelGGL(pw_wgrad_partial_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, hs, (const bf16_t*)sm,
+                           (const bf16_t*)bg, part, nvox, cs, cb);
+      else
+        hipLaunchKernelGGL(pw_wgrad_partial_kernel<float>, dim3((unsigned)nb), dim3(256), 0, hs, (const float*)sm,
+                           (const float*)bg, part, nvox, cs, cb);
+      hipLaunchKernelGGL(pw_wgrad_final_kernel, dim3((unsigned)((cs * cb + 31) / 32)), dim3(256), 0, hs, part, dw, coef,
+                         (int)nb, cs, cb, small_is_cin);
+      hipError_t e0 = hipGetLastError();
+      prof.done((int)e0);
+      return (int)e0;
+    }
+  }
+  const size_t tile_bytes = (size_t)(s->kd * s->kh * s->kw) * sg_cdiv(s->cin, 32) * sg_cdiv(s->cout, 32) * 4096;
+  hipError_t e = hipMemsetAsync(workspace, 0, tile_bytes, hs);
   if (e != hipSuccess) { prof.done((int)e); return (int)e; }
   WgradArgs a;
   a.x = x; a.dy = dy; a.dwt = reinterpret_cast<float*>(workspace);
   a.cin = s->cin; a.cout = s->cout;
   a.taps = s->kd * s->kh * s->kw; a.kh = s->kh; a.kw = s->kw;
   a.ciT = sg_cdiv(s->cin, 32); a.coT = sg_cdiv(s->cout, 32);
-  int rc;
-  if (dt == SG_BF16) rc = launch_wgrad<bf16_t, 256>(a, s, hs);
+  int rc = SG_OK;
+  bool used = false;
+  if (dt == SG_BF16 && !getenv("SG_WGRAD_V1")) {
+    if (s->kd == 3 && s->kh == 3 && s->kw == 3) rc = launch_wgrad2<3, 3, 3>(a, s, hs, &used);
+    else if (s->kd == 1 && s->kh == 3 && s->kw == 3) rc = launch_wgrad2<1, 3, 3>(a, s, hs, &used);
+  }
+  if (rc == SG_OK && used) { /* done by the ping-pong kernel */ }
+  else if (rc != SG_OK) { /* fall through to the error return below */ }
+  else if (dt == SG_BF16) rc = launch_wgrad<bf16_t, 256>(a, s, hs);
   else if (dt == SG_F32) rc = launch_wgrad<float, 128>(a, s, hs);
   else rc = SG_EINVAL;
   if (rc == SG_OK) {

@@ -56,6 +56,8 @@ CONV_CASES = [
     (1, 16, 16, (5, 20, 40), (3, 3, 3)),     # non power-of-two extents (start shape (1,5,16,16) family)
     (2, 32, 64, (16, 64, 64), (3, 3, 3)),    # >= 512 tiles: persistent weight-stationary kernel, 2 cout slices
     (2, 16, 32, (17, 66, 70), (3, 3, 3)),    # same kernel, ragged extents, single K chunk
+    (2, 48, 96, (16, 64, 64), (3, 3, 3)),    # streamed-weight ping-pong kernel: 3 K chunks, 3 cout tiles over 2 blocks
+    (4, 64, 32, (2, 64, 64), (1, 3, 3)),     # same, (1,3,3) taps, one cout tile
 ]
 
 

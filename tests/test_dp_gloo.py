@@ -1,0 +1,82 @@
+"""Data-parallel layer on CPU: world_size 2 over gloo.  Covers the bucketed gradient all-reduce launched from
+autograd hooks (flat buffer, several buckets, partial parameter sets as in the freeze ops) and the variable
+broadcast, i.e. what replaces hvd.DistributedOptimizer / hvd.broadcast_global_variables
+(optuna_objective.py:179-186,328)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from saragan_amd import parallel
+    from saragan_amd.varstore import VariableStore
+    r, w, _ = parallel.init_distributed('gloo')
+    assert (r, w) == (rank, world) and parallel.size() == world
+    torch.manual_seed(100 + rank)
+    store = VariableStore('cpu', seed=7 + rank)          # different initial weights per rank
+    shapes = {'generator/a/weight': (3, 5), 'generator/a/bias': (5,), 'generator/b/weight': (7, 2), 'generator/c/bias': (9,)}
+    for k, s in shapes.items():
+        store.get(k, s, 'normal')
+    flat = store.flatten('generator/')
+    parallel.broadcast_global_variables(store, 0)
+    ref = VariableStore('cpu', seed=7)
+    for k, s in shapes.items():
+        ref.get(k, s, 'normal')
+    same = all(torch.equal(store.vars[k].data, ref.vars[k].data) for k in shapes)
+
+    red = parallel.GradientAllReducer(bucket_bytes=32)   # 8 floats per bucket: several buckets, params straddle them
+    names = list(shapes)
+    out = {}
+    for trial, active in enumerate((names, names[2:])):  # all parameters, then a "freeze" subset
+        params = [store.vars[k] for k in active]
+        offs = flat['offsets']
+        ranges = [(offs[k][0], (offs[k][1] + 3) // 4 * 4) for k in active]
+        flat['grad'].zero_()
+        for p_, k in zip(params, active):
+            o, n = offs[k]
+            p_.grad = flat['grad'][o:o + n].view(p_.shape)
+        x = torch.full((1,), float(rank + 1))
+        loss = sum((p_ * (i + 1)).sum() for i, p_ in enumerate(params)) * x
+        red.begin(flat['grad'], ranges, params)
+        torch.autograd.backward(loss, inputs=params)
+        red.finish()
+        out[trial] = {k: store.vars[k].grad.clone().numpy() for k in active}
+    q.put((rank, same, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allreduce_and_broadcast_world2():
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda t: t[0])
+    assert all(r[1] for r in res), 'broadcast did not deliver rank 0 values'
+    for trial in (0, 1):
+        names = list(res[0][2][trial])
+        for i, k in enumerate(names):
+            want = (i + 1) * (1 + 2)                       # d/dp sum over ranks of (i+1) * p * (rank+1)
+            for r in res:
+                np.testing.assert_allclose(r[2][trial][k], want)

@@ -1,0 +1,195 @@
+"""CPU tests of the host-side mirror: dataset sampling protocol (the reference's dataset.py:357-395 self-test),
+shape/phase arithmetic, schedules, parameter-count KAT through the product's own variable enumeration, the CLI,
+and that libsaragan_hip.so loads and exports every symbol include/saragan_hip.h declares."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import pgan_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    from saragan_amd import _lib
+    hdr = open(os.path.join(ROOT, 'include', 'saragan_hip.h')).read()
+    declared = set(re.findall(r'\b(sg_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'sg_stream_t'}
+    assert len(declared) >= 23
+    lib = _lib.load()                       # raises if the .so is missing or a prototype is not exported
+    for name in declared:
+        assert hasattr(lib, name), f'{name} declared in saragan_hip.h but not exported'
+        assert name in _lib.SIGNATURES, f'{name} has no ctypes prototype'
+    assert lib.sg_version().decode().startswith('saragan_hip')
+    assert b'invalid' in lib.sg_error_string(-1)
+
+
+def test_product_has_no_cpu_fallback():
+    import torch
+    from saragan_amd import functional as F
+    with pytest.raises(RuntimeError, match='GPU only'):
+        F.conv3d(torch.zeros(1, 8, 1, 4, 4), torch.zeros(1, 3, 3, 8, 8))
+    src = ''
+    for dp, _, fs in os.walk(os.path.join(ROOT, 'saragan_amd')):
+        for f in fs:
+            if f.endswith('.py'):
+                src += open(os.path.join(dp, f)).read()
+    assert 'import oracle' not in src and 'from oracle' not in src
+
+
+def test_variable_plan_matches_out_txt_kat_and_oracle():
+    from saragan_amd.networks.pgan.variables import pgan_variable_shapes, preset_specs
+    base = (1, 1, 4, 4)
+    ks, fs = preset_specs('xs', base, 8)
+    oks, ofs = O.preset_specs('xs', base, 8)
+    assert ks == oks and fs == ofs
+    want_g = [2691585, 3872002, 4424898, 4646018, 4728994]
+    want_d = [2688769, 3869441, 4422337, 4643265, 4726241]
+    for phase in range(1, 6):
+        shp = pgan_variable_shapes(phase, base, 512, ks, fs)
+        assert dict(shp) == {k: tuple(v) for k, v in O.variable_shapes(phase, base, 512, ks, fs).items()}
+        g = sum(int(np.prod(s)) for k, s in shp.items() if k.startswith('generator/'))
+        d = sum(int(np.prod(s)) for k, s in shp.items() if k.startswith('discriminator/'))
+        assert (g, d) == (want_g[phase - 1], want_d[phase - 1])
+    with pytest.raises(ValueError):
+        pgan_variable_shapes(9, base, 512, ks, fs)
+
+
+def test_ops_host_functions():
+    from saragan_amd.networks import ops
+    assert [ops.k(x) for x in (1, 2, 3, 8)] == [1, 1, 3, 3]
+    assert ops.get_kernel([4, 4, 2], [5, 3, 3]) == [3, 3, 1]
+    assert ops.calculate_gain('linear') == 1
+    assert ops.calculate_gain('leaky_relu', 0.2) == pytest.approx(np.sqrt(2 / 1.04))
+    with pytest.raises(ValueError):
+        ops.calculate_gain('leaky_relu', True)
+    with pytest.raises(ValueError):
+        ops.calculate_gain('gelu')
+    with pytest.raises(ValueError):
+        ops.act(None, 'swish')
+    with pytest.raises(ValueError):
+        ops.num_filters(1, 8, (1, 1, 4, 4), size='huge')
+    assert [ops.num_filters(l, 8, (1, 1, 4, 4), size='m') for l in (1, 3, 6)] == [1024, 256, 64]
+    a = ops.ScalarVariable(1.0, 'alpha')
+    upd = ops.alpha_update(a, 64, 1.0, 8, 2)
+    vals = [float(upd.run()) for _ in range(5)]
+    ref, r = [], 1.0
+    for _ in range(5):
+        r = O.alpha_update(r, 64, 1.0, 8, 2)
+        ref.append(r)
+    assert vals == ref and vals[-1] == 0.0
+    assert float(ops.alpha_update(ops.ScalarVariable(0.7), 0, 1.0, 8, 2).run()) == 0.0
+
+
+def test_lr_update_matches_oracle_schedule():
+    from saragan_amd import optimization as opt
+    from saragan_amd.networks.ops import ScalarVariable
+    for inc in (None, 'linear', 'exponential'):
+        for dec in (None, 'linear', 'exponential'):
+            lr, step = ScalarVariable(0.0), ScalarVariable(0, dtype=np.int64)
+            op = opt.lr_update(lr, step, 1000, 2e-3, inc, dec, 100, 200)
+            for s in (0, 50, 99, 100, 500, 800, 801, 950, 1000):
+                step.assign(s)
+                got = float(op.run())
+                assert got == pytest.approx(O.lr_update(s, 1000, 2e-3, inc, dec, 100, 200), rel=1e-6, abs=1e-12)
+
+
+def test_get_optimizer_and_optimize_step_errors():
+    import argparse
+    from saragan_amd import optimization as opt
+    a = argparse.Namespace(optimizer='Adam', d_optimizer='SGD', adam_beta1=0.0, adam_beta2=0.9, d_adam_beta1=0.0,
+                           d_adam_beta2=0.9)
+    g, d = opt.get_optimizer(1e-3, 2e-3, a)
+    assert isinstance(g, opt.AdamOptimizer) and isinstance(d, opt.GradientDescentOptimizer)
+    a.optimizer = 'Lion'
+    with pytest.raises(NotImplementedError):
+        opt.get_optimizer(1e-3, 2e-3, a)
+    with pytest.raises(ValueError):
+        opt.optimize_step(g, d, None, None, None, 8, 0.0, 1, (1, 1, 4, 4), [], [], 'leaky_relu', 0.2, 'wgan', 10.0,
+                          'sometimes', False, False, 0.01)
+
+
+def test_dataset_protocol(tmp_path):
+    """dataset.py:357-395: 10 files, batch(7) twice with and without auto-repeat."""
+    from saragan_amd.dataset import NumpyPathDataset, invert_normalize_numpy, normalize_numpy
+    d = tmp_path / '16x16'
+    d.mkdir()
+    for i in range(10):
+        np.save(d / f'{i:03d}.npy', np.full((5, 16, 16), i, dtype=np.int16))
+    ds = NumpyPathDataset(str(d) + '/', None, False, True, seed=3)
+    assert len(ds) == 10 and ds.shape == (1, 5, 16, 16)
+    b1 = ds.batch(7, auto_repeat=False)
+    b2 = ds.batch(7, auto_repeat=False)      # only 3 left: returns what is there
+    assert b1.shape == (7, 1, 5, 16, 16) and b1.dtype == np.float32 and b2.shape == (3, 1, 5, 16, 16)
+    seen = sorted(int(v) for v in np.concatenate([b1, b2])[:, 0, 0, 0, 0])
+    assert seen == list(range(10))           # every sample exactly once per epoch
+    ds = NumpyPathDataset(str(d) + '/', None, False, True, seed=3)
+    b1, b2 = ds.batch(7, True), ds.batch(7, True)   # second call refills the buffer first
+    assert b1.shape == b2.shape == (7, 1, 5, 16, 16)
+    tr, rest = ds.split_by_fraction(0.8)
+    assert (len(tr), len(rest)) == (8, 2) and tr.scratch_files == ds.scratch_files[:8]
+    x = np.arange(4.0)
+    assert np.allclose(invert_normalize_numpy(normalize_numpy(x, 1024, 1024), 1024, 1024), x)
+    with pytest.raises(Exception):
+        normalize_numpy(x, None, 2.0)
+
+
+def test_batch_mpi_partitions_the_global_batch(tmp_path):
+    """The shared-seed slicing hands rank r column r of reshape(-1, world): together the ranks see each
+    sample of an epoch exactly once (what rank-0 draw + MPI scatter guaranteed, dataset.py:307-333)."""
+    from saragan_amd.dataset import NumpyPathDataset
+    d = tmp_path / '8x8'
+    d.mkdir()
+    for i in range(12):
+        np.save(d / f'{i:03d}.npy', np.full((2, 8, 8), i, dtype=np.int16))
+    world = 3
+    ranks = [NumpyPathDataset(str(d) + '/', None, False, True, rank=r, world_size=world, seed=11) for r in range(world)]
+    ref = NumpyPathDataset(str(d) + '/', None, False, True, seed=11)
+    epoch = []
+    for _ in range(2):
+        want = ref.samplebuffer[:6]
+        ref.samplebuffer = ref.samplebuffer[6:]
+        got = [r.batch_mpi_paths(2) for r in ranks]
+        for rk in range(world):
+            assert got[rk] == [want[i] for i in range(rk, 6, world)]
+        epoch += [p for g_ in got for p in g_]
+    assert sorted(epoch) == sorted(ref.scratch_files)
+    # no auto-repeat with a short buffer: padded with None on rank 0's list, stripped per rank
+    ranks = [NumpyPathDataset(str(d) + '/', None, False, True, rank=r, world_size=5, seed=1) for r in range(5)]
+    for r in ranks:
+        r.samplebuffer = r.samplebuffer[:7]
+    got = [r.batch_mpi_paths(2, auto_repeat=False) for r in ranks]
+    assert [len(g_) for g_ in got] == [2, 2, 1, 1, 1]
+
+
+def test_utils_shape_math_and_log_line():
+    from saragan_amd import utils as U
+    assert U.get_num_phases('(1, 1, 4, 4)', '(1, 32, 128, 128)') == 5
+    assert U.get_base_shape('(1, 5, 16, 16)') == (1, 5, 16, 16)
+    assert U.get_current_input_shape(3, 4, '(1, 5, 16, 16)') == [4, 1, 20, 64, 64]
+    assert U.get_xy_dim(6, '(1,1,4,4)') == 128
+    assert U.scale_lr(1e-3, 2e-3, 'sqrt', 'linear', True, 4) == (pytest.approx(2e-3), pytest.approx(8e-3))
+    assert U.scale_lr(1e-3, 2e-3, 'sqrt', 'linear', False, 4) == (1e-3, 2e-3)
+    with pytest.raises(ValueError):
+        U.scale_lr(1e-3, 2e-3, 'cubic', 'none', True, 2)
+    line = U.format_summary_line(128, 64, 47.15, 5.9, 0.1234, -1.5, 1e-3, 2e-3, 0.5)
+    assert 'Step 000000128' in line and 'img/s 47.15' in line and 'd_loss 0.1234' in line and 'alpha 0.50' in line
+    assert U.get_num_metric_samples(None, 1, 8) == 16
+
+
+def test_cli_flags_of_the_reference_parse():
+    from saragan_amd.main import build_parser, finalize_args
+    argv = ['pgan', '/data/', '--start_shape', '(1, 5, 16, 16)', '--final_shape', '(1, 160, 512, 512)', '--scratch_path',
+            '/scratch', '--gpu', '--horovod', '--data_mean', '1024', '--data_stddev', '1024', '--starting_phase', '1',
+            '--ending_phase', '4', '--mixing_nimg', '131072', '--stabilizing_nimg', '131072', '--base_batch_size', '16',
+            '--latent_dim', '128', '--network_size', 's', '--starting_alpha', '1', '--loss_fn', 'wgan', '--gp_weight', '10',
+            '--noise_stddev', '0.01', '--d_lr_increase=linear', '--d_lr_decrease=exponential', '--d_lr_rise_niter', '32768',
+            '--d_lr_decay_niter', '98304', '--g_lr', '0.012250', '--d_lr', '0.005458', '--adam_beta1', '0.130724',
+            '--adam_beta2', '0.939014', '--calc_metrics', '--compute_FID']   # scripts/example_normal_run.jb:70-80
+    args, unknown = build_parser().parse_known_args(argv)
+    args = finalize_args(args)
+    assert unknown == ['--calc_metrics', '--compute_FID']
+    assert args.d_adam_beta1 == pytest.approx(0.130724) and args.d_optimizer == 'Adam'
+    assert args.filter_spec[0] == [128, 128] and len(args.kernel_spec) >= 5   # ops.py:223-232: 5*16*16 voxels -> list index 2

@@ -74,6 +74,32 @@ def _shape(n, d, h, w, cin, cout, k, ups=False):
     return ConvShape(n, d, h, w, cin, cout, k[0], k[1], k[2], 1 if ups else 0)
 
 
+_PACK_CACHE = {}
+
+
+def clear_pack_cache():
+    """Packed-weight images are reused while the parameter is unchanged (same storage, same version counter): the
+    four discriminator passes and their gradients all read one image per orientation.  The optimiser step bumps
+    the version; Session.run also clears the cache so that buffers do not outlive a step."""
+    _PACK_CACHE.clear()
+
+
+def _packed(w, coef, flip, shp, dt, lib, st):
+    key = (w.data_ptr(), w._version, float(coef), bool(flip), dt, shp.cin, shp.cout, shp.kd, shp.kh, shp.kw)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None:
+        return hit[0]
+    w32 = w.detach()
+    if w32.dtype != torch.float32 or not w32.is_contiguous():
+        w32 = w32.contiguous().float()
+    wp = torch.empty(lib.sg_conv3d_packed_bytes(C.byref(shp), dt), device=w.device, dtype=torch.uint8)
+    check(lib.sg_conv3d_pack_weights(_ptr(w32), float(coef), 1 if flip else 0, _ptr(wp), C.byref(shp), dt, st),
+          'sg_conv3d_pack_weights')
+    if w.is_leaf or not w.requires_grad:      # only cache long-lived tensors (parameters), not transient gradients
+        _PACK_CACHE[key] = (wp, w)   # holding w keeps its storage (and so the key) from being recycled
+    return wp
+
+
 def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel_norm=False, eps=1e-8,
              want_scale=False):
     """y = epilogue(conv3d(x, coef*w)) with w in DHWIO; `flip` selects the data-gradient weights."""
@@ -91,11 +117,8 @@ def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel
         d, h, wd = 2 * d, 2 * h, 2 * wd
     shp = _shape(n, d, h, wd, cin, cout, (kd, kh, kw), ups)
     dt = _dt(x)
-    w32 = w.detach().contiguous().float()
-    wp = torch.empty(lib.sg_conv3d_packed_bytes(C.byref(shp), dt), device=x.device, dtype=torch.uint8)
     st = _stream()
-    check(lib.sg_conv3d_pack_weights(_ptr(w32), float(coef), 1 if flip else 0, _ptr(wp), C.byref(shp), dt, st),
-          'sg_conv3d_pack_weights')
+    wp = _packed(w, coef, flip, shp, dt, lib, st)
     y = _empty_like_shape(x, cout, (d, h, wd))
     scale = None
     if pixel_norm and want_scale:
@@ -478,6 +501,8 @@ def adam_ema_(p, g, m, v, ema, lr, beta1, beta2, step, eps=1e-8, gscale=1.0, ema
     lib = _lib.load()
     _req_cuda(p, g, m, v, ema)
     lr_t = lr * math.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step) if g is not None else 0.0
+    if g is not None:
+        _PACK_CACHE.clear()   # the kernel rewrites parameters behind torch's version counters
     check(lib.sg_adam_ema(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(ema), p.numel(), float(lr_t), float(beta1),
                           float(beta2), float(eps), float(gscale), float(ema_decay), _stream()), 'sg_adam_ema')
 

@@ -143,13 +143,16 @@ def forward_simultaneous(generator, discriminator, real_image_input, latent_dim,
     gen_sample_noisy = rng.add_noise(gen_sample, noise_stddev, 'noise_fake')
     net = dict(latent_dim=latent_dim, activation=activation, kernel_spec=kernel_spec, filter_spec=filter_spec,
                param=leakiness, conditioning=conditioning)
-    disc_fake_d = discriminator(gen_sample_noisy.detach(), alpha, phase, **net).float()
+    # The reference evaluates D(stop_gradient(fake)) for the D loss and D(fake) for the G loss (loss.py:126-128,
+    # :143-144): the same forward values.  ONE pass serves both here: the D-loss gradient is only taken w.r.t. D's
+    # variables (the edge into G is never followed), the G-loss gradient only w.r.t. G's (no D weight gradients).
+    disc_fake_g = discriminator(gen_sample_noisy, alpha, phase, **net).float()
+    disc_fake_d = disc_fake_g
     disc_real = discriminator(real_image_input, alpha, phase, is_reuse=True, **net).float()
     gamma = rng.gamma(real_image_input.shape[0], real_image_input.device).to(real_image_input.dtype)
     interpolates = gamma * real_image_input + (1 - gamma) * gen_sample_noisy.detach()
     slopes = torch.sqrt(_gradient_slopes_sq(discriminator, interpolates, alpha, phase, latent_dim, activation,
                                             kernel_spec, filter_spec, leakiness, keep_w=True))
-    disc_fake_g = discriminator(gen_sample_noisy, alpha, phase, is_reuse=True, **net).float()
     if loss_fn == 'wgan':
         gradient_penalty = (slopes - 1) ** 2
         gp_loss = gp_weight * gradient_penalty

@@ -194,8 +194,8 @@ class StepGraph:
                     c['generator'], c['discriminator'], real, *net_args, c['gp_weight'], c['noise_stddev'])
                 out.update(gen_loss=gen_loss, disc_loss=disc_loss, gp_loss=gp_loss, gen_sample=gen_sample)
                 pend = []
-                for tid in train_ids:           # both gradients at the pre-step weights (optimization.py:128-163)
-                    pend.append((tid, self._backward(tid, out)))
+                for j, tid in enumerate(train_ids):   # both gradients at the pre-step weights (optimization.py:128-163)
+                    pend.append((tid, self._backward(tid, out, retain=j + 1 < len(train_ids))))
                 for tid, info in pend:
                     self._finish(tid, info, out, apply=tid in want_train)
             else:                               # alternate: D step, then G forward on the updated D
@@ -212,6 +212,7 @@ class StepGraph:
                 for tid in g_ids:
                     self._finish(tid, self._backward(tid, out), out, apply=tid in want_train)
         self.last = out
+        F.clear_pack_cache()
         res = []
         for f in fetches:
             if f.key in ('train',):
@@ -225,7 +226,7 @@ class StepGraph:
                 res.append(v.detach() if torch.is_tensor(v) else v)
         return res
 
-    def _backward(self, tid, out):
+    def _backward(self, tid, out, retain=False):
         tr = self.trains[tid]
         prefix = tr['net'] + '/'
         flat = self.store.flat[prefix]
@@ -241,7 +242,7 @@ class StepGraph:
         dist = tr['optimizer'].distributed
         if dist is not None:
             dist.begin(flat['grad'], ranges, params)
-        torch.autograd.backward(loss, inputs=params)
+        torch.autograd.backward(loss, inputs=params, retain_graph=retain)
         return dict(prefix=prefix, flat=flat, names=names, ranges=ranges, dist=dist)
 
     def _finish(self, tid, info, out, apply):

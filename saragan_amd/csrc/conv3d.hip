@@ -111,6 +111,7 @@ struct ConvFwdArgs {
   int sshift, rshift;   // v2: log2(slots per row), log2(rows per 256-byte bank row)
   int wbytes, ntiles;   // v3r: resident weight image bytes, number of spatial tiles
   unsigned long long* dbg;  // diagnostic time stamps (NULL in production)
+  int dbg_flags;            // diagnostic ablations (0 in production): 1 = no re-staging, 2 = no epilogue
   int vec_in, vec_out;
   int act, pixel_norm;
   float slope, eps;
@@ -549,6 +550,52 @@ static int launch_fwd2(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st) {
 }
 
 
+
+// Fully unrolled, software-pipelined K loop of the weight-stationary kernel (see the call site).  Template
+// recursion keeps every LDS offset and wait count an immediate.
+template <typename T, int MTW, int GC, int TAPS, int RING>
+struct sg_unrolled_k {
+  static constexpr int NS = TAPS * GC, PF = RING - 1, RPS = 1 + MTW;
+  template <int ST>
+  static __device__ __forceinline__ void load(u32x4 (&wfr)[RING], u32x4 (&xfr)[RING][MTW], const int (&xaddr)[TAPS][MTW],
+                                              int wl_off) {
+    constexpr int SL = ST % RING, tap = ST / GC, gi = ST % GC;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wfr[SL]) : "v"(wl_off), "n"(ST << 10));
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+      const int xa = xaddr[tap][mt] ^ (gi << 5);
+      asm volatile("ds_read_b128 %0, %1" : "=v"(xfr[SL][mt]) : "v"(xa));
+    }
+  }
+  template <int ST>
+  static __device__ __forceinline__ void step(f32x16 (&acc)[MTW], u32x4 (&wfr)[RING], u32x4 (&xfr)[RING][MTW],
+                                              const int (&xaddr)[TAPS][MTW], int wl_off) {
+    if constexpr (ST < NS) {
+      if constexpr (ST + PF < NS) load<ST + PF>(wfr, xfr, xaddr, wl_off);
+      constexpr int younger = (NS - 1 - ST < PF ? NS - 1 - ST : PF) * RPS;   // reads issued after step ST's
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) acc[mt] = sg_mfma_chunk<T>(wfr[ST % RING], xfr[ST % RING][mt], acc[mt]);
+      __builtin_amdgcn_sched_barrier(0);
+      step<ST + 1>(acc, wfr, xfr, xaddr, wl_off);
+    }
+  }
+  template <int ST>
+  static __device__ __forceinline__ void prologue(u32x4 (&wfr)[RING], u32x4 (&xfr)[RING][MTW],
+                                                  const int (&xaddr)[TAPS][MTW], int wl_off) {
+    if constexpr (ST < PF && ST < NS) {
+      load<ST>(wfr, xfr, xaddr, wl_off);
+      prologue<ST + 1>(wfr, xfr, xaddr, wl_off);
+    }
+  }
+  static __device__ __forceinline__ void run(f32x16 (&acc)[MTW], u32x4 (&wfr)[RING], u32x4 (&xfr)[RING][MTW],
+                                             const int (&xaddr)[TAPS][MTW], int wl_off) {
+    prologue<0>(wfr, xfr, xaddr, wl_off);
+    step<0>(acc, wfr, xfr, xaddr, wl_off);
+  }
+};
+
 // ------------------------------------------------------------------------------------------------------
 // forward, v3r: persistent, weight-stationary variant for Cin <= one channel group (32 bf16 / 16 f32 channels).
 // One block per CU owns a 32-wide slice of output channels (blockIdx.y) and walks spatial tiles.  ALL weights of
@@ -640,8 +687,8 @@ __global__ __launch_bounds__(512) void conv_fwd3r_kernel(ConvFwdArgs a) {
     int hd = (int)(q2 - q3 * g.HD);
     const int c = sl * EPP;
     const bool live = row < hv && c < a.cin;
-    it_crd[k] = live ? (hw | (hh_ << 8) | (hd << 16) | ((int)q3 << 24)) : -1;
-    it_rel[k] = live ? ((((int)q3 * g.D + hd) * g.H + hh_) * g.W + hw) * a.cin + c : 0;
+    it_crd[k] = live ? (hw | (hh_ << 8) | (hd << 16) | ((int)q3 << 24)) : 0x7F7F7F7F;   // dead: fails every range
+    it_rel[k] = live ? ((((int)q3 * g.D + hd) * g.H + hh_) * g.W + hw) * a.cin + c : -1;
   }
 
   // Halo staging by LDS-DMA: asynchronous (lands while this group runs its epilogue), no VGPRs held.  A piece
@@ -649,18 +696,37 @@ __global__ __launch_bounds__(512) void conv_fwd3r_kernel(ConvFwdArgs a) {
   auto stage_tile = [&](const sg_tile_origin& o) {
     const bool interior = !g.ups && o.d0 >= g.PD && o.h0 >= g.PH && o.w0 >= g.PW && o.d0 + g.TD + g.PD <= g.D &&
                           o.h0 + g.TH + g.PH <= g.H && o.w0 + g.TW + g.PW <= g.W && o.n0 + g.TN <= g.N;
+    const T* base = x + ((((int64_t)o.n0 * g.D + (o.d0 - g.PD)) * g.H + (o.h0 - g.PH)) * g.W + (o.w0 - g.PW)) *
+                            (int64_t)a.cin;
     if (interior) {   // every halo voxel is inside the volume: one 64-bit add per piece
-      const T* base = x + ((((int64_t)o.n0 * g.D + (o.d0 - g.PD)) * g.H + (o.h0 - g.PH)) * g.W + (o.w0 - g.PW)) *
-                              (int64_t)a.cin;
 #pragma unroll
       for (int k = 0; k < MAXIT; ++k) {
         if ((wave + 4 * k) * 64 < items) {
-          const void* src = it_crd[k] >= 0 ? (const void*)(base + it_rel[k]) : (const void*)sg_zero_page;
+          const void* src = it_rel[k] >= 0 ? (const void*)(base + it_rel[k]) : (const void*)sg_zero_page;
           sg_glds16(src, xmine + (size_t)(wave + 4 * k) * 1024);
         }
       }
-    } else {
+    } else if (!g.ups) {
+      // boundary tile: a piece is valid iff its packed halo coordinate (w,h,d,n bytes, all < 128) lies inside the
+      // per-tile range [lo, hi] in every byte; two byte-parallel subtractions with the borrow guard bit 7 test it
+      const int lo_w = max(0, g.PW - o.w0), hi_w = min(g.HW, g.W + g.PW - o.w0) - 1;
+      const int lo_h = max(0, g.PH - o.h0), hi_h = min(g.HH, g.H + g.PH - o.h0) - 1;
+      const int lo_d = max(0, g.PD - o.d0), hi_d = min(g.HD, g.D + g.PD - o.d0) - 1;
+      const int hi_n = min(g.TN, g.N - o.n0) - 1;
+      const uint32_t lo = (uint32_t)(lo_w | (lo_h << 8) | (lo_d << 16));
+      const uint32_t hi = (uint32_t)(hi_w | (hi_h << 8) | (hi_d << 16) | (hi_n << 24)) | 0x80808080u;
 #pragma unroll
+      for (int k = 0; k < MAXIT; ++k) {
+        if ((wave + 4 * k) * 64 < items) {
+          const uint32_t c_ = (uint32_t)it_crd[k];
+          const uint32_t t1 = (c_ | 0x80808080u) - lo, t2 = hi - c_;
+          const bool ok = ((t1 & t2 & 0x80808080u) == 0x80808080u);
+          const void* src = ok ? (const void*)(base + it_rel[k]) : (const void*)sg_zero_page;
+          sg_glds16(src, xmine + (size_t)(wave + 4 * k) * 1024);
+        }
+      }
+    } else {   // fused nearest-x2 gather: coordinates are halved, no shortcut
+#pragma unroll 1
       for (int k = 0; k < MAXIT; ++k) {
         if ((wave + 4 * k) * 64 < items) {
           const int crd = it_crd[k];
@@ -668,9 +734,9 @@ __global__ __launch_bounds__(512) void conv_fwd3r_kernel(ConvFwdArgs a) {
           int d = o.d0 + ((crd >> 16) & 255) - g.PD, h = o.h0 + ((crd >> 8) & 255) - g.PH,
               w = o.w0 + (crd & 255) - g.PW;
           const void* src = sg_zero_page;
-          if (crd >= 0 && n < g.N && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H &&
+          if (it_rel[k] >= 0 && n < g.N && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H &&
               (unsigned)w < (unsigned)g.W) {
-            if (g.ups) { d >>= 1; h >>= 1; w >>= 1; }
+            d >>= 1; h >>= 1; w >>= 1;
             const int row = ((wave + 4 * k) * 64 + lane) >> sshift;
             const int sl_c = ((lane & (S - 1)) ^ ((row >> rshift) & (S - 1))) * EPP;
             src = x + ((((int64_t)n * Di + d) * Hi + h) * Wi + w) * (int64_t)a.cin + sl_c;
@@ -717,32 +783,24 @@ __global__ __launch_bounds__(512) void conv_fwd3r_kernel(ConvFwdArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+          for (int i = 0; i < 16; ++i) acc[mt][i] = bias_lds[(i & 3) + 8 * (i >> 2) + 4 * hh];   // bias rides in C
+        // K loop: NS = TAPS*GC steps of (1 weight + MTW activation) fragment reads and MTW MFMAs.  The reads are
+        // inline asm so that the waits can be COUNTED: hipcc only emits lgkmcnt(0) here, which also waits for the
+        // fragments just requested PF steps ahead and exposes a full LDS round trip every few MFMAs.  LDS returns
+        // in order, so before the MFMAs of step s at most PF*(1+MTW) younger reads may still be in flight.
         constexpr int NS = TAPS * GC;
         constexpr int RING = 3, PF = RING - 1;
+        constexpr int RPS = 1 + MTW;                    // reads per step
         u32x4 wfr[RING], xfr[RING][MTW];
-        auto ld = [&](int st, int sl_) {
-          const int tap = st / GC, gi = st % GC;
-          wfr[sl_] = *reinterpret_cast<const u32x4*>(wl + (st << 10));
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt)
-            xfr[sl_][mt] = *reinterpret_cast<const u32x4*>(smem + (xaddr[tap][mt] ^ (gi << 5)));
-        };
-#pragma unroll
-        for (int st = 0; st < PF && st < NS; ++st) ld(st, st % RING);
-#pragma unroll
-        for (int st = 0; st < NS; ++st) {
-          if (st + PF < NS) ld(st + PF, (st + PF) % RING);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) acc[mt] = sg_mfma_chunk<T>(wfr[st % RING], xfr[st % RING][mt], acc[mt]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        const int wl_off = (int)(wl - smem);            // LDS byte address of this lane's weight column
+        (void)RPS; (void)NS; (void)PF;
+        sg_unrolled_k<T, MTW, GC, TAPS, RING>::run(acc, wfr, xfr, xaddr, wl_off);
       }
     } else {
-      if (p + 1 < K) stage_tile(sg_tile_of(g, (uint32_t)(first + (p + 1) * per_x)));   // into my (now idle) buffer
+      if (a.dbg_flags & 4) __builtin_amdgcn_s_setprio(3);
+      if (p + 1 < K && !((a.dbg_flags & 1) && p >= 2)) stage_tile(sg_tile_of(g, (uint32_t)(first + (p + 1) * per_x)));   // into my (now idle) buffer
       stamp();
-      if (p >= 1) {
+      if (p >= 1 && !(a.dbg_flags & 2)) {
         const sg_tile_origin o = sg_tile_of(g, (uint32_t)(first + (p - 1) * per_x));
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
@@ -750,15 +808,14 @@ __global__ __launch_bounds__(512) void conv_fwd3r_kernel(ConvFwdArgs a) {
           const int n = o.n0 + (tc >> 24), d = o.d0 + ((tc >> 16) & 255), h = o.h0 + ((tc >> 8) & 255),
                     w = o.w0 + (tc & 255);
           const bool ok = tc >= 0 && n < g.N && d < g.D && h < g.H && w < g.W;
-          float ss = 0.f;
+          if (a.act) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) {
-            float v = acc[mt][i] + bias_lds[(i & 3) + 8 * (i >> 2) + 4 * hh];
-            if (a.act) v = fmaxf(v, v * a.slope);
-            acc[mt][i] = v;
-            ss += v * v;
+            for (int i = 0; i < 16; ++i) acc[mt][i] = fmaxf(acc[mt][i], acc[mt][i] * a.slope);
           }
           if (a.pixel_norm) {
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ss += acc[mt][i] * acc[mt][i];
             ss += __shfl_xor(ss, 32);
             const float sc = rsqrtf(ss * inv_c + a.eps);
 #pragma unroll
@@ -787,6 +844,7 @@ __global__ __launch_bounds__(512) void conv_fwd3r_kernel(ConvFwdArgs a) {
         }
       }
     }
+    if (a.dbg_flags & 4) __builtin_amdgcn_s_setprio(0);
     stamp();
     __syncthreads();
   }
@@ -1130,6 +1188,7 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
   a.pixel_norm = ep ? ep->pixel_norm : 0;
   a.eps = ep ? ep->eps : 0.f;
   a.dbg = g_dbg_ts;
+  a.dbg_flags = sg_env_int("SG_DBG_FLAGS", 0);
   a.cin = s->cin; a.cout = s->cout;
   a.taps = s->kd * s->kh * s->kw; a.kh = s->kh; a.kw = s->kw;
   a.nchunk = conv_nchunk(s, dt);

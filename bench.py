@@ -28,7 +28,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=8, help='per-GPU batch')
+    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
     ap.add_argument('--size', default='s')
     ap.add_argument('--phase', type=int, default=6)
     ap.add_argument('--latent', type=int, default=512)
@@ -120,31 +120,31 @@ def conv_flops_per_volume(ks, fs, phase, base_shape, latent):
 
 
 def cpu_baseline(args, cfg, budget_s):
-    """The CPU restatement (oracle/, fp32 torch-CPU) of the same step, timed on this host: kind "port".
-    Bounded sample: batch 1, as many steps as fit the budget (at least 1)."""
+    """The CPU restatement (oracle/, fp32 torch-CPU, kind "port") timed on this host on a BOUNDED sample of the same
+    workload: one discriminator forward pass over one volume (a full G+D step of this network takes ~5 minutes on
+    256 host threads).  D-forward is F_D of the step's 3*F_G + 12*F_D algorithmic FLOPs; the step rate is that
+    time scaled by the FLOP ratio (backward passes are not faster than forward on the CPU, so this favours the CPU)."""
     from oracle import pgan_oracle as O
-    nthreads = os.cpu_count() or 1
+    nthreads = min(os.cpu_count() or 1, 16)   # a 1-GPU box's CPU share; more threads oversubscribe and run slower
     torch.set_num_threads(nthreads)
     ks, fs, base_shape = cfg['ks'], cfg['fs'], cfg['base_shape']
     p = O.init_params(args.phase, base_shape, args.latent, ks, fs, seed=1, dtype=torch.float32)
     img = tuple(cfg['shape'][1:])
-    n = 1
-    rnd = O.draw_randomness(n, args.latent, img, seed=2, dtype=torch.float32)
-    real = torch.randn(n, *img)
-    ocfg = dict(phase=args.phase, base_shape=base_shape, latent_dim=args.latent, kernel_spec=ks, filter_spec=fs,
-                activation='leaky_relu', leakiness=0.2, loss_fn=args.loss, gp_weight=10.0, noise_stddev=0.01)
-    ag, ad = O.TFAdam(0.0, 0.9), O.TFAdam(0.0, 0.9)
-    shadow = {k: v.clone() for k, v in p.items()}
-    steps, t0 = 0, time.time()
-    while True:
-        O.step_simultaneous(p, ag, ad, shadow, rnd, real, args.alpha, ocfg, 1e-3, 1e-3)
-        steps += 1
-        if time.time() - t0 > budget_s * 0.5 or steps >= 5:
-            break
-    dt = time.time() - t0
-    return dict(value=steps * n / dt, unit='volumes/s', cores=nthreads, kind='port',
-                sample=f'{steps} step(s) of the same G+D step at batch {n}, fp32 torch-CPU restatement (oracle/), '
-                       f'{dt:.1f} s')
+    real = torch.randn(1, *img)
+    fg, fd = conv_flops_per_volume(ks, fs, args.phase, base_shape, args.latent)
+    ratio = (3 * fg + 12 * fd) / fd
+    reps, t0 = 0, time.time()
+    with torch.no_grad():
+        while True:
+            O.discriminator(p, real, args.alpha, args.phase, args.latent, 'leaky_relu', ks, fs, param=0.2)
+            reps += 1
+            if time.time() - t0 > 12.0 and reps >= 3:   # ~12 s of CPU work
+                break
+    dt = (time.time() - t0) / reps
+    return dict(value=float(1.0 / (dt * ratio)), unit='volumes/s', cores=nthreads, kind='port',
+                sample=f'{reps} discriminator forward pass(es) over one {img[1]}x{img[2]}x{img[3]} volume '
+                       f'({dt:.1f} s each, fp32 torch-CPU restatement in oracle/), scaled by the step/forward '
+                       f'FLOP ratio {ratio:.1f}')
 
 
 def main():

@@ -155,7 +155,7 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
-    device = torch.device('cuda', local)
+    device = torch.device('cuda', local % max(1, torch.cuda.device_count()))   # (rehearsals may stack ranks on one GPU)
     torch.cuda.set_device(device)
     cfg = build(args, device)
     sess, ph = cfg['sess'], cfg['ph']

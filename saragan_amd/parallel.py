@@ -22,9 +22,9 @@ def init_distributed(backend=None, timeout_s=600):
     if world > 1 and not dist.is_initialized():
         import datetime
         if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-        if backend == 'nccl':
-            torch.cuda.set_device(local)
+            backend = os.environ.get('SARAGAN_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=timeout_s))
     return rank, world, local
 

@@ -1,0 +1,86 @@
+"""Data parallelism on the GPU path: two ranks (gloo over CUDA tensors, both on cuda:0 so that one GPU suffices)
+each run the HIP step on HALF of a golden fixture's batch with the gradient all-reduce of
+parallel.DistributedOptimizer; the updated weights must equal the oracle's FULL-batch step (the losses are batch
+means, so averaged half-batch gradients are the full-batch gradient): hvd.DistributedOptimizer semantics
+(optuna_objective.py:179-186)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+NAME = 'oracle_step_p3_wgan_a000.npz'
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, golden, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK='0', SARAGAN_DIST_BACKEND='gloo')
+    import saragan_amd.optimization as opt
+    from saragan_amd import parallel
+    from saragan_amd.ExtendedEMA import ExtendedEMA
+    from saragan_amd.networks import loss as L
+    from saragan_amd.networks.ops import ScalarVariable
+    from saragan_amd.networks.pgan.discriminator import discriminator
+    from saragan_amd.networks.pgan.generator import generator
+    from saragan_amd.varstore import VariableStore, set_compute_dtype, use_store
+    from tests.stepfix import BASE_SHAPE, FILTER_SPEC, KERNEL_SPEC, LATENT, load_step_fixture
+    parallel.init_distributed()
+    fx = load_step_fixture(os.path.join(golden, NAME), torch.float64)
+    n = fx['real'].shape[0] // world
+    sl = slice(rank * n, (rank + 1) * n)
+    set_compute_dtype(torch.float32)
+    store = VariableStore('cuda', seed=100 + rank)
+    L.set_random_source(L.InjectedRandom({k: v[sl].float() for k, v in fx['rnd'].items()}))
+    alpha = ScalarVariable(fx['alpha'])
+    og = parallel.DistributedOptimizer(opt.AdamOptimizer(ScalarVariable(1e-3), 0.0, 0.9))
+    od = parallel.DistributedOptimizer(opt.AdamOptimizer(ScalarVariable(1e-3), 0.0, 0.9))
+    ph = opt.Placeholder([n, 1, 1, 1, 1])
+    with use_store(store):
+        tup = opt.optimize_step(og, od, generator, discriminator, ph, LATENT, alpha, fx['phase'], BASE_SHAPE, KERNEL_SPEC,
+                                FILTER_SPEC, 'leaky_relu', 0.2, fx['loss_fn'], fx['cfg']['gp_weight'], 'simultaneous',
+                                False, False, 0.01, None)
+    if rank == 0:
+        store.load_state_dict(fx['p0'], strict=True)      # other ranks keep different weights until the broadcast
+    graph = tup[0].graph
+    ema = ExtendedEMA(list(store.vars), 0.99, graph=graph)
+    graph._ensure_flat()
+    parallel.broadcast_global_variables(store, 0)
+    ema.reset_to_variables()
+    sess = opt.Session('cuda')
+    sess.run([tup[0], tup[1]], feed_dict={ph: fx['real'][sl].float()})
+    sess.run(ema.apply())
+    torch.cuda.synchronize()
+    q.put((rank, {k: v.detach().cpu().numpy() for k, v in store.vars.items()}))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_step_equals_full_batch_oracle(golden_dir):
+    from tests.stepfix import load_step_fixture
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, golden_dir, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    fx = load_step_fixture(os.path.join(golden_dir, NAME), torch.float64)
+    for k, ref in fx['p1'].items():
+        for r in range(world):
+            np.testing.assert_allclose(res[r][k], ref.numpy(), rtol=1e-4, atol=3e-5, err_msg=f'rank {r} {k}')
+        np.testing.assert_array_equal(res[0][k], res[1][k])   # replicas stay bit-identical

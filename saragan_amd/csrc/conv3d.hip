@@ -596,6 +596,54 @@ struct sg_unrolled_k {
   }
 };
 
+
+// Same for the streamed-weight kernel (v4): one step = one tap of the current 32-byte channel chunk:
+// NTB weight fragments + MTW activation fragments, MTW*NTB MFMAs.
+template <typename T, int MTW, int NTB, int TAPS, int RING>
+struct sg_unrolled_k4 {
+  static constexpr int PF = RING - 1, RPS = NTB + MTW;
+  template <int ST>
+  static __device__ __forceinline__ void load(u32x4 (&wfr)[RING][NTB], u32x4 (&xfr)[RING][MTW],
+                                              const int (&xaddr)[TAPS][MTW], int wl_off) {
+    constexpr int SL = ST % RING;
+#pragma unroll
+    for (int nt = 0; nt < NTB; ++nt)
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wfr[SL][nt]) : "v"(wl_off), "n"((ST * NTB + nt) << 10));
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) asm volatile("ds_read_b128 %0, %1" : "=v"(xfr[SL][mt]) : "v"(xaddr[ST][mt]));
+  }
+  template <int ST>
+  static __device__ __forceinline__ void step(f32x16 (&acc)[MTW][NTB], u32x4 (&wfr)[RING][NTB], u32x4 (&xfr)[RING][MTW],
+                                              const int (&xaddr)[TAPS][MTW], int wl_off) {
+    if constexpr (ST < TAPS) {
+      if constexpr (ST + PF < TAPS) load<ST + PF>(wfr, xfr, xaddr, wl_off);
+      constexpr int younger = (TAPS - 1 - ST < PF ? TAPS - 1 - ST : PF) * RPS;
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NTB; ++nt)
+          acc[mt][nt] = sg_mfma_chunk<T>(wfr[ST % RING][nt], xfr[ST % RING][mt], acc[mt][nt]);
+      __builtin_amdgcn_sched_barrier(0);
+      step<ST + 1>(acc, wfr, xfr, xaddr, wl_off);
+    }
+  }
+  template <int ST>
+  static __device__ __forceinline__ void prologue(u32x4 (&wfr)[RING][NTB], u32x4 (&xfr)[RING][MTW],
+                                                  const int (&xaddr)[TAPS][MTW], int wl_off) {
+    if constexpr (ST < PF && ST < TAPS) {
+      load<ST>(wfr, xfr, xaddr, wl_off);
+      prologue<ST + 1>(wfr, xfr, xaddr, wl_off);
+    }
+  }
+  static __device__ __forceinline__ void run(f32x16 (&acc)[MTW][NTB], const int (&xaddr)[TAPS][MTW], int wl_off) {
+    u32x4 wfr[RING][NTB], xfr[RING][MTW];
+    prologue<0>(wfr, xfr, xaddr, wl_off);
+    step<0>(acc, wfr, xfr, xaddr, wl_off);
+  }
+};
+
 // ------------------------------------------------------------------------------------------------------
 // forward, v3r: persistent, weight-stationary variant for Cin <= one channel group (32 bf16 / 16 f32 channels).
 // One block per CU owns a 32-wide slice of output channels (blockIdx.y) and walks spatial tiles.  ALL weights of
@@ -971,7 +1019,7 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
     int hh_ = (int)(q - q2 * g.HH);
     uint32_t q3 = sg_div(q2, g.fHD);
     int hd = (int)(q2 - q3 * g.HD);
-    it_rel[k] = row < hv ? ((((int)q3 * g.D + hd) * g.H + hh_) * g.W + hw) * a.cin + sl * EPP : -1;
+    it_rel[k] = row < hv ? ((((int)q3 * g.D + hd) * g.H + hh_) * g.W + hw) * a.cin + sl * EPP : -2;   // -2: beyond the image, lane idle
   }
 
   auto tile_of_item = [&](int q) { return first + (2 * (q / ncg) + grp) * per_x; };
@@ -989,7 +1037,7 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
                               (int64_t)a.cin + c0;
 #pragma unroll
       for (int k = 0; k < MAXIT; ++k)
-        if ((wave + 4 * k) * 64 < items)
+        if ((wave + 4 * k) * 64 < items && it_rel[k] != -2)   // idle lanes write nothing: the image ends at hv rows
           sg_glds16(it_rel[k] >= 0 ? (const void*)(base + it_rel[k]) : (const void*)sg_zero_page,
                     xmine + (size_t)(wave + 4 * k) * 1024);
     } else {
@@ -1008,7 +1056,8 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
           int n = o.n0 + (int)q3, d = o.d0 + hd - g.PD, h = o.h0 + hh_ - g.PH, w = o.w0 + hw - g.PW;
           const int c = c0 + sl * EPP;
           const void* src = sg_zero_page;
-          if (row < hv && c < a.cin && n < g.N && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H &&
+          if (row >= hv) continue;
+          if (c < a.cin && n < g.N && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H &&
               (unsigned)w < (unsigned)g.W) {
             if (g.ups) { d >>= 1; h >>= 1; w >>= 1; }
             src = x + ((((int64_t)n * Di + d) * Hi + h) * Wi + w) * (int64_t)a.cin + c;
@@ -1050,30 +1099,9 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NTB; ++nt)
 #pragma unroll
-              for (int i = 0; i < 16; ++i) acc[mt][nt][i] = 0.f;
+              for (int i = 0; i < 16; ++i) acc[mt][nt][i] = bias_lds[nt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];
         }
-        constexpr int RING = 3, PF = RING - 1;
-        u32x4 wfr[RING][NTB], xfr[RING][MTW];
-        auto ld = [&](int tap, int sl_) {
-#pragma unroll
-          for (int nt = 0; nt < NTB; ++nt)
-            wfr[sl_][nt] = *reinterpret_cast<const u32x4*>(wl + ((tap * NTB + nt) << 10));
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) xfr[sl_][mt] = *reinterpret_cast<const u32x4*>(smem + xaddr[tap][mt]);
-        };
-#pragma unroll
-        for (int st = 0; st < PF && st < TAPS; ++st) ld(st, st % RING);
-#pragma unroll
-        for (int st = 0; st < TAPS; ++st) {
-          if (st + PF < TAPS) ld(st + PF, (st + PF) % RING);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NTB; ++nt)
-              acc[mt][nt] = sg_mfma_chunk<T>(wfr[st % RING][nt], xfr[st % RING][mt], acc[mt][nt]);
-          __builtin_amdgcn_sched_barrier(0);
-        }
+        sg_unrolled_k4<T, MTW, NTB, TAPS, 3>::run(acc, xaddr, (int)(wl - smem));
       }
     } else {
       // my next item is q' = (p + 1) >> 1; my previous one q' - 1 (ran in phase p - 1)
@@ -1088,17 +1116,18 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
           const int n = o.n0 + (tc >> 24), d = o.d0 + ((tc >> 16) & 255), h = o.h0 + ((tc >> 8) & 255),
                     w = o.w0 + (tc & 255);
           const bool ok = tc >= 0 && n < g.N && d < g.D && h < g.H && w < g.W;
-          float ss = 0.f;
+          if (a.act) {
 #pragma unroll
-          for (int nt = 0; nt < NTB; ++nt)
+            for (int nt = 0; nt < NTB; ++nt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              float v = acc[mt][nt][i] + bias_lds[nt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];
-              if (a.act) v = fmaxf(v, v * a.slope);
-              acc[mt][nt][i] = v;
-              ss += v * v;
-            }
+              for (int i = 0; i < 16; ++i) acc[mt][nt][i] = fmaxf(acc[mt][nt][i], acc[mt][nt][i] * a.slope);
+          }
           if (a.pixel_norm) {
+            float ss = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NTB; ++nt)
+#pragma unroll
+              for (int i = 0; i < 16; ++i) ss += acc[mt][nt][i] * acc[mt][nt][i];
             ss += __shfl_xor(ss, 32);
             const float sc = rsqrtf(ss * inv_c + a.eps);
 #pragma unroll
@@ -1151,7 +1180,7 @@ static int launch_fwd4(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, b
   const int hv = g.TN * g.HD * g.HH * g.HW;
   a.G = 1;
   a.rs = 32;
-  a.xbytes = ((hv * 32) + 1023) & ~1023;
+  a.xbytes = hv * 32;   // exact: lanes beyond the last row are masked off in the LDS-DMA
   a.wbytes = a.taps * NTB * 1024;
   if (sg_cdiv(hv * 2, 64) > 32) return SG_OK;
   const size_t lds = 2ull * a.xbytes + 2ull * a.wbytes + NTB * 128;

@@ -369,7 +369,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a) {
   }
 
   auto stage_tile = [&](const sg_tile_origin& o) {
-    const bool interior = o.d0 >= g.PD && o.h0 >= g.PH && o.w0 >= g.PW && o.d0 + g.TD + g.PD <= g.D &&
+    const bool interior = !g.ups && o.d0 >= g.PD && o.h0 >= g.PH && o.w0 >= g.PW && o.d0 + g.TD + g.PD <= g.D &&
                           o.h0 + g.TH + g.PH <= g.H && o.w0 + g.TW + g.PW <= g.W && o.n0 + g.TN <= g.N;
     const int64_t v0 = (((int64_t)o.n0 * g.D + o.d0) * g.H + o.h0) * g.W + o.w0;   // first tile voxel
     const T* ybase = dy + v0 * a.cout;
@@ -400,9 +400,15 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a) {
           const int n = o.n0 + (int)q3, d = o.d0 + hd - g.PD, h = o.h0 + hh_ - g.PH, w = o.w0 + hw - g.PW;
           const bool ok = row < hvx && c < a.cin && n < g.N && (unsigned)d < (unsigned)g.D &&
                           (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W;
-          const int rel = ((((int)q3 * g.D + hd) * g.H + hh_) * g.W + hw) * a.cin + c;
-          sg_glds16w(ok ? (const void*)(xbase + rel) : (const void*)sg_zero_page_w,
-                     xmine + (size_t)(wave + 4 * k) * 1024);
+          const void* src = sg_zero_page_w;
+          if (ok) {
+            if (g.ups)   // x is half resolution: nearest-neighbour x2 gather (conv3d(upscale3d(x)))
+              src = x + ((((int64_t)n * (g.D >> 1) + (d >> 1)) * (g.H >> 1) + (h >> 1)) * (g.W >> 1) + (w >> 1)) *
+                            (int64_t)a.cin + c;
+            else
+              src = xbase + (((((int)q3 * g.D + hd) * g.H + hh_) * g.W + hw) * a.cin + c);
+          }
+          sg_glds16w(src, xmine + (size_t)(wave + 4 * k) * 1024);
         }
       }
 #pragma unroll 1
@@ -502,7 +508,7 @@ static int launch_wgrad2(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   *used = false;
   a.g = sg_make_geom(s, 256, /*prefer_w32=*/true);
   const sg_tile_geom& g = a.g;
-  if (g.TW != 32 || g.TN != 1 || g.TD * g.TH * g.TW != 256 || s->upsample_in) return SG_OK;
+  if (g.TW != 32 || g.TN != 1 || g.TD * g.TH * g.TW != 256) return SG_OK;
   if ((s->cin % 8) || (s->cout % 8)) return SG_OK;
   if ((int64_t)s->n * s->d * s->h * s->w * (int64_t)(s->cin > s->cout ? s->cin : s->cout) >= (1ll << 31)) return SG_OK;
   const int64_t ntiles = (int64_t)g.nTn * g.nTd * g.nTh * g.nTw;

@@ -91,7 +91,8 @@ static inline int sg_pow2ceil(int v) { int p = 1; while (p < v) p <<= 1; return 
 
 // Picks the tile (powers of two clipped to the extent, TW <= 32, at most `bm` voxels) that stages the
 // fewest halo voxels over the whole tensor; small volumes fold batch samples into the tile (TN > 1).
-static inline sg_tile_geom sg_make_geom(const sg_conv_shape* s, int bm, bool prefer_w32 = false) {
+static inline sg_tile_geom sg_make_geom(const sg_conv_shape* s, int bm, bool prefer_w32 = false, int force_td = 0,
+                                        int force_th = 0) {
   sg_tile_geom g;
   g.N = s->n; g.D = s->d; g.H = s->h; g.W = s->w;
   g.PD = s->kd / 2; g.PH = s->kh / 2; g.PW = s->kw / 2;
@@ -110,6 +111,11 @@ static inline sg_tile_geom sg_make_geom(const sg_conv_shape* s, int bm, bool pre
         if (prefer_w32 && cw != (s->w < 32 ? s->w : 32)) score *= 4.0;
         if (score < best) { best = score; bd = cd; bh = chh; bw = cw; }
       }
+  if (force_td > 0 && force_th > 0) {   // caller-imposed tile (the sliding-halo kernel walks TD = 2 planes at a time)
+    bd = force_td < s->d ? force_td : s->d;
+    bh = force_th < s->h ? force_th : s->h;
+    bw = s->w < 32 ? s->w : 32;
+  }
   g.TW = bw; g.TH = bh; g.TD = bd;
   int rem = bm / (g.TW * g.TH * g.TD); if (rem < 1) rem = 1;
   g.TN = s->n < rem ? s->n : rem;

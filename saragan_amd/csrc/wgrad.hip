@@ -25,6 +25,8 @@ struct WgradArgs {
   int ntiles;
   sg_fastdiv fnp;
   int vec_x, vec_y;
+  int plane_rows;  // wgrad3: LDS rows per halo plane slot
+  int dbg_flags;   // diagnostic ablations (0 in production): 1 = stage only the first items
 };
 
 constexpr int WG_MAXT = 7;  // taps per wave
@@ -539,6 +541,334 @@ static int launch_wgrad2(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   return SG_OK;
 }
 
+
+
+// Fully unrolled, software-pipelined K loop of one 256-voxel tile for the sliding-halo kernel: a stream of
+// 16 K steps x (1 dy item + MAXT x items); every item is two transposing reads, issued PF items ahead of use with
+// COUNTED waits (LDS returns in order; hipcc would emit lgkmcnt(0) per K step and expose a full LDS round trip
+// every 7 MFMAs).  dy fragments are double buffered across K steps, x fragments live in a ring of PF + 1.
+template <int MAXT, int TH, int PF>
+struct sg_wgrad_tile {
+  static constexpr int IPS = 1 + MAXT;          // items per K step
+  static constexpr int NI = 16 * IPS;           // items per tile
+  static constexpr int RING = PF + 1;
+  typedef s16x4 frag_t;
+  struct Ctx {
+    int xl0, xl1, yl0, yl1;                     // lane parts (VGPR)
+    int sslot[2][MAXT];                         // per (td, tap): ring-slot base + tap row shift (uniform)
+    int throw_[TH];                             // per th: row offset (uniform)
+  };
+  template <int I>
+  static __device__ __forceinline__ void load(const Ctx& c, frag_t (&a0)[RING], frag_t (&a1)[RING], frag_t (&b0)[2],
+                                              frag_t (&b1)[2]) {
+    constexpr int ks = I / IPS, r = I % IPS, line = ks / 2, half = ks % 2, td = line / TH, th = line % TH;
+    if constexpr (r == 0) {
+      const int q0 = c.yl0 + ks * 16 * 64, q1 = c.yl1 + ks * 16 * 64;
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b0[ks & 1]) : "v"(q0));
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(b1[ks & 1]) : "v"(q1));
+    } else {
+      constexpr int j = r - 1, SL = (ks * MAXT + j) % RING;
+      const int off = c.sslot[td][j] + c.throw_[th] + half * 16 * 64;
+      const int p0 = c.xl0 + off, p1 = c.xl1 + off;
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a0[SL]) : "v"(p0));
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(a1[SL]) : "v"(p1));
+    }
+  }
+  template <int I>
+  static __device__ __forceinline__ void step(const Ctx& c, f32x16 (&acc)[MAXT], frag_t (&a0)[RING], frag_t (&a1)[RING],
+                                              frag_t (&b0)[2], frag_t (&b1)[2]) {
+    if constexpr (I < NI) {
+      if constexpr (I + PF < NI) load<I + PF>(c, a0, a1, b0, b1);
+      constexpr int ks = I / IPS, r = I % IPS;
+      if constexpr (r != 0) {
+        constexpr int younger = (NI - 1 - I < PF ? NI - 1 - I : PF) * 2;
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger));
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int j = r - 1, SL = (ks * MAXT + j) % RING;
+        u32x4 af, bf;
+        af[0] = __builtin_bit_cast(u32x2, a0[SL])[0]; af[1] = __builtin_bit_cast(u32x2, a0[SL])[1];
+        af[2] = __builtin_bit_cast(u32x2, a1[SL])[0]; af[3] = __builtin_bit_cast(u32x2, a1[SL])[1];
+        bf[0] = __builtin_bit_cast(u32x2, b0[ks & 1])[0]; bf[1] = __builtin_bit_cast(u32x2, b0[ks & 1])[1];
+        bf[2] = __builtin_bit_cast(u32x2, b1[ks & 1])[0]; bf[3] = __builtin_bit_cast(u32x2, b1[ks & 1])[1];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf),
+                                                        acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      step<I + 1>(c, acc, a0, a1, b0, b1);
+    }
+  }
+  template <int I>
+  static __device__ __forceinline__ void prologue(const Ctx& c, frag_t (&a0)[RING], frag_t (&a1)[RING], frag_t (&b0)[2],
+                                                  frag_t (&b1)[2]) {
+    if constexpr (I < PF && I < NI) {
+      load<I>(c, a0, a1, b0, b1);
+      prologue<I + 1>(c, a0, a1, b0, b1);
+    }
+  }
+  static __device__ __forceinline__ void run(const Ctx& c, f32x16 (&acc)[MAXT]) {
+    frag_t a0[RING], a1[RING], b0[2], b1[2];
+    prologue<0>(c, a0, a1, b0, b1);
+    step<0>(c, acc, a0, a1, b0, b1);
+  }
+};
+
+// ------------------------------------------------------------------------------------------------------
+// wgrad v3 (bf16, 3x3x3 / 1x3x3, tiles TD x TH x 32): wgrad2 with a SLIDING halo.  Tiles are walked along D
+// (columns of tiles at fixed (n, h, w)); the x halo lives in a ring of HD = TD + 2*PD plane slots, so a step
+// along D fetches only the TD new planes (half the halo for 3x3x3) instead of all HD: LDS-DMA pieces per tile
+// drop from 13 + 4 to 7 + 4 per wave, which is what bounded wgrad2 (its staging phase was longer than its
+// MFMA phase).  Group g of the ping-pong walks columns g, g+2, ... of the block's column list.
+// ------------------------------------------------------------------------------------------------------
+template <int KD, int KH, int KW>
+__global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16_t T;
+  constexpr int TAPS = KD * KH * KW;
+  constexpr int MAXT = (TAPS + 3) / 4;
+  constexpr int BM = 256, KSTEPS = BM / 16;
+  const sg_tile_geom& g = a.g;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave8 >> 2, wave = wave8 & 3;
+  const int PR = a.plane_rows;                       // LDS rows per plane slot (multiple of 16)
+  const int pbytes = PR * 64;
+  const int bufbytes = a.xbytes + a.ybytes;
+  char* xmine = smem + grp * bufbytes;
+  char* ymine = xmine + a.xbytes;
+  const T* x = reinterpret_cast<const T*>(a.x);
+  const T* dy = reinterpret_cast<const T*>(a.dy);
+  const int ci_t = blockIdx.y / a.coT, co_t = blockIdx.y % a.coT;
+  const int HDm = g.HD - 1;                          // HD is a power of two (2 or 4): slot = plane & HDm
+
+  // column schedule: XCD group xg owns a contiguous chunk of the (n, h, w) column list
+  const int ncol = g.nTn * g.nTh * g.nTw;
+  const int xg = blockIdx.x & 7, bslot = blockIdx.x >> 3;
+  const int per_x = gridDim.x >> 3;
+  const int cpx = (ncol + 7) >> 3;
+  const int c_begin = xg * cpx, c_end = min(ncol, c_begin + cpx);
+  const int cfirst = c_begin + bslot;
+  const int ncols_blk = cfirst < c_end ? (c_end - cfirst + per_x - 1) / per_x : 0;
+  const int ncols_mine = (ncols_blk + 1 - grp) >> 1;          // columns of my group: grp, grp+2, ...
+  const int items_mine = ncols_mine * g.nTd;
+  const int items_max = ((ncols_blk + 1) >> 1) * g.nTd;
+
+  const int i16 = lane & 15, q16 = lane >> 4;
+  const int qd = i16 >> 2, pp = i16 & 3;
+  const int colb = (16 * (q16 & 1) + 4 * pp) * 2;
+  const int kb = 8 * (q16 >> 1) + qd;
+  const int xl0 = (int)(xmine - smem) + kb * 64 + colb, xl1 = xl0 + 4 * 64;
+  const int yl0 = (int)(ymine - smem) + kb * 64 + colb, yl1 = yl0 + 4 * 64;
+
+  // plane-local staging tables (identical for every plane): this lane's pieces w, w+4, w+8, w+12 of a plane
+  const int prow = g.HH * g.HW;                      // live rows per plane
+  const int ppieces = PR / 16;                       // 1-KiB pieces per plane
+  constexpr int MAXP = 4, MAXY = 4;
+  int relp[MAXP];   // element offset relative to the plane's first halo voxel (h0-PH, w0-PW); -1 dead
+  int crdp[MAXP];   // packed (hw, hh) for the boundary test; dead pieces fail every range
+  int rely[MAXY];
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    const int it = (wave + 4 * k) * 64 + lane;
+    const int row = it >> 2, c = ci_t * 32 + (it & 3) * 8;
+    uint32_t q = sg_div((uint32_t)row, g.fHW);
+    const int hw = (int)(row - q * g.HW), hh_ = (int)q;
+    const bool live = row < prow && c < a.cin;
+    relp[k] = live ? (hh_ * g.W + hw) * a.cin + c : -1;
+    crdp[k] = live ? (hw | (hh_ << 8)) : 0x7F7F;
+  }
+  const int hvy = g.TD * g.TH * g.TW, ity = hvy * 4;
+#pragma unroll
+  for (int k = 0; k < MAXY; ++k) {
+    const int it = (wave + 4 * k) * 64 + lane;
+    const int row = it >> 2, c = co_t * 32 + (it & 3) * 8;
+    uint32_t q = sg_div((uint32_t)row, g.fTW);
+    int tw = (int)(row - q * g.TW);
+    uint32_t q2 = sg_div(q, g.fTH);
+    int th = (int)(q - q2 * g.TH);
+    int td = (int)q2;
+    rely[k] = (row < hvy && c < a.cout) ? ((td * g.H + th) * g.W + tw) * a.cout + c : -1;
+  }
+
+  // item q of my group -> (column, d index)
+  auto origin_of = [&](int q, int& di) {
+    const int cj = q / g.nTd;
+    di = q - cj * g.nTd;
+    const int col = cfirst + (2 * cj + grp) * per_x;
+    sg_tile_origin o;
+    uint32_t c1 = sg_div((uint32_t)col, g.fnTw);
+    o.w0 = (int)(col - c1 * g.nTw) * g.TW;
+    uint32_t c2 = sg_div(c1, g.fnTh);
+    o.h0 = (int)(c1 - c2 * g.nTh) * g.TH;
+    o.n0 = (int)c2;
+    o.d0 = di * g.TD;
+    return o;
+  };
+
+  auto stage_item = [&](int q) {
+    int di;
+    const sg_tile_origin o = origin_of(q, di);
+    // ---- x: halo planes hd in [hd_begin, HD) are new (all of them at the bottom of a column) ----
+    const int hd_begin = di == 0 ? 0 : g.HD - g.TD;
+    const bool hw_interior = !g.ups && o.h0 >= g.PH && o.w0 >= g.PW && o.h0 + g.TH + g.PH <= g.H &&
+                             o.w0 + g.TW + g.PW <= g.W;
+    const int lo_w = max(0, g.PW - o.w0), hi_w = min(g.HW, g.W + g.PW - o.w0) - 1;
+    const int lo_h = max(0, g.PH - o.h0), hi_h = min(g.HH, g.H + g.PH - o.h0) - 1;
+    const uint32_t lo = (uint32_t)(lo_w | (lo_h << 8));
+    const uint32_t hi = (uint32_t)(hi_w | (hi_h << 8)) | 0x8080u;
+    for (int hd = hd_begin; hd < g.HD; ++hd) {
+      const int gp = o.d0 - g.PD + hd;                       // global plane (d coordinate)
+      const int slot_ = (gp + 2 * g.HD) & HDm;
+      char* dst = xmine + slot_ * pbytes;
+      const bool plane_ok = gp >= 0 && gp < g.D;
+      const T* base = g.ups ? x
+                            : x + ((((int64_t)o.n0 * g.D + gp) * g.H + (o.h0 - g.PH)) * g.W + (o.w0 - g.PW)) * (int64_t)a.cin;
+#pragma unroll
+      for (int k = 0; k < MAXP; ++k) {
+        if (wave + 4 * k < ppieces) {
+          const void* src = sg_zero_page_w;
+          if (plane_ok) {
+            if (hw_interior) {
+              if (relp[k] >= 0) src = base + relp[k];
+            } else if (!g.ups) {
+              const uint32_t c_ = (uint32_t)crdp[k];
+              const uint32_t t1 = (c_ | 0x8080u) - lo, t2 = hi - c_;
+              if ((t1 & t2 & 0x8080u) == 0x8080u) src = base + relp[k];
+            } else {   // fused nearest-x2 gather
+              const int hw = crdp[k] & 255, hh_ = (crdp[k] >> 8) & 255;
+              const int h = o.h0 + hh_ - g.PH, w = o.w0 + hw - g.PW;
+              if (relp[k] >= 0 && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W) {
+                const int c = ci_t * 32 + (lane & 3) * 8;
+                src = x + ((((int64_t)o.n0 * (g.D >> 1) + (gp >> 1)) * (g.H >> 1) + (h >> 1)) * (g.W >> 1) + (w >> 1)) *
+                              (int64_t)a.cin + c;
+              }
+            }
+          }
+          sg_glds16w(src, dst + (size_t)(wave + 4 * k) * 1024);
+        }
+      }
+    }
+    // ---- dy tile ----
+    const bool y_interior = o.d0 + g.TD <= g.D && o.h0 + g.TH <= g.H && o.w0 + g.TW <= g.W;
+    const T* ybase = dy + ((((int64_t)o.n0 * g.D + o.d0) * g.H + o.h0) * g.W + o.w0) * (int64_t)a.cout;
+#pragma unroll
+    for (int k = 0; k < MAXY; ++k) {
+      if ((wave + 4 * k) * 64 < ity) {
+        const void* src = sg_zero_page_w;
+        if (rely[k] >= 0) {
+          bool ok = y_interior;
+          if (!ok) {
+            const int row = ((wave + 4 * k) * 64 + lane) >> 2;
+            uint32_t q_ = sg_div((uint32_t)row, g.fTW);
+            int tw = (int)(row - q_ * g.TW);
+            uint32_t q2 = sg_div(q_, g.fTH);
+            int th = (int)(q_ - q2 * g.TH);
+            int td = (int)q2;
+            ok = o.d0 + td < g.D && o.h0 + th < g.H && o.w0 + tw < g.W;
+          }
+          if (ok) src = ybase + rely[k];
+        }
+        sg_glds16w(src, ymine + (size_t)(wave + 4 * k) * 1024);
+      }
+    }
+  };
+
+  // per-wave taps
+  int tap_hw[MAXT], tap_kd[MAXT];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    const int tap = wave + 4 * j;
+    const int kw_i = tap % KW, kh_i = (tap / KW) % KH, kd_i = tap / (KW * KH);
+    tap_hw[j] = tap < TAPS ? (kh_i * g.HW + kw_i) * 64 : 0;
+    tap_kd[j] = tap < TAPS ? kd_i : 0;
+  }
+  f32x16 acc[MAXT];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  if (grp == 0 && items_mine > 0) stage_item(0);
+  __syncthreads();
+
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
+  const int nphase = 2 * items_max + 1;
+  for (int p = 0; p < nphase; ++p) {
+    const int q = p >> 1;
+    if ((p & 1) == grp) {
+      if (q < items_mine) {
+        const int di = q % g.nTd;
+        const int pbase = di * g.TD - g.PD + 2 * g.HD;          // plane of halo index 0 (kept non-negative)
+        typedef sg_wgrad_tile<MAXT, 4, 5> KT;
+        typename KT::Ctx c;
+        c.xl0 = xl0; c.xl1 = xl1; c.yl0 = yl0; c.yl1 = yl1;
+#pragma unroll
+        for (int td = 0; td < 2; ++td)
+#pragma unroll
+          for (int j = 0; j < MAXT; ++j) c.sslot[td][j] = ((pbase + td + tap_kd[j]) & HDm) * pbytes + tap_hw[j];
+#pragma unroll
+        for (int th = 0; th < 4; ++th) c.throw_[th] = th * g.HW * 64;
+        KT::run(c, acc);
+      }
+    } else {
+      const int qn = (p + 1) >> 1;
+      if (qn < items_mine && !((a.dbg_flags & 1) && p >= 2)) stage_item(qn);
+    }
+    __syncthreads();
+  }
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    const int tap = wave + 4 * j;
+    if (tap < TAPS && items_mine > 0) {
+      float* dst = a.dwt + ((((int64_t)tap * a.ciT + ci_t) * a.coT + co_t) << 10);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+        unsafeAtomicAdd(dst + row * 32 + r, acc[j][i]);
+      }
+    }
+  }
+}
+
+template <int KD, int KH, int KW>
+static int launch_wgrad3(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used) {
+  *used = false;
+  a.g = sg_make_geom(s, 256, /*prefer_w32=*/true, /*td=*/2, /*th=*/4);
+  const sg_tile_geom& g = a.g;
+  if (g.TW != 32 || g.TN != 1 || g.TD * g.TH * g.TW != 256) return SG_OK;
+  if (g.HD != 2 && g.HD != 4) return SG_OK;          // ring slots are addressed with a mask
+  if (g.TD != 2 || g.TH != 4) return SG_OK;           // the unrolled K loop is written for 2 x 4 x 32 tiles
+  if (g.HH > 127 || g.HW > 127) return SG_OK;
+  if ((s->cin % 8) || (s->cout % 8)) return SG_OK;
+  if ((int64_t)s->n * s->d * s->h * s->w * (int64_t)(s->cin > s->cout ? s->cin : s->cout) >= (1ll << 31)) return SG_OK;
+  const int ncol = g.nTn * g.nTh * g.nTw;
+  const int pairs = a.ciT * a.coT;
+  int gx = (256 / pairs) / 8 * 8;
+  if (gx < 8) gx = 8;
+  if (ncol < 2 * gx || g.nTd < 2) return SG_OK;      // needs >= 2 columns per block and something to slide over
+  a.gy = a.g;
+  a.ntiles = ncol * g.nTd;
+  a.rs = 64;
+  a.plane_rows = (g.HH * g.HW + 15) & ~15;
+  if (a.plane_rows / 16 > 16) return SG_OK;           // <= 4 pieces per wave per plane
+  a.xbytes = g.HD * a.plane_rows * 64;
+  a.ybytes = 256 * 64;
+  const size_t lds = 2ull * (a.xbytes + a.ybytes);
+  if (lds > 160 * 1024) return SG_OK;
+  auto kern = conv_wgrad3_kernel<KD, KH, KW>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  a.tap0 = 0; a.taps_blk = a.taps;
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);
+  SG_LAUNCH_CHECK();
+  *used = true;
+  return SG_OK;
+}
+
 extern "C" int sg_conv3d_wgrad(const void* x, const void* dy, float* dw, float coef, void* workspace,
                                size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st) {
   if (!conv_shape_ok_w(s) || !x || !dy || !dw || !workspace) return SG_EINVAL;
@@ -577,13 +907,17 @@ extern "C" int sg_conv3d_wgrad(const void* x, const void* dy, float* dw, float c
   hipError_t e = hipMemsetAsync(workspace, 0, tile_bytes, hs);
   if (e != hipSuccess) { prof.done((int)e); return (int)e; }
   WgradArgs a;
+  a.dbg_flags = getenv("SG_DBG_FLAGS") ? atoi(getenv("SG_DBG_FLAGS")) : 0;
   a.x = x; a.dy = dy; a.dwt = reinterpret_cast<float*>(workspace);
   a.cin = s->cin; a.cout = s->cout;
   a.taps = s->kd * s->kh * s->kw; a.kh = s->kh; a.kw = s->kw;
   a.ciT = sg_cdiv(s->cin, 32); a.coT = sg_cdiv(s->cout, 32);
   int rc = SG_OK;
   bool used = false;
-  if (dt == SG_BF16 && !getenv("SG_WGRAD_V1")) {
+  if (dt == SG_BF16 && !getenv("SG_WGRAD_V1") && !getenv("SG_WGRAD_NO_V3")) {
+    if (s->kd == 3 && s->kh == 3 && s->kw == 3) rc = launch_wgrad3<3, 3, 3>(a, s, hs, &used);
+  }
+  if (rc == SG_OK && !used && dt == SG_BF16 && !getenv("SG_WGRAD_V1")) {
     if (s->kd == 3 && s->kh == 3 && s->kw == 3) rc = launch_wgrad2<3, 3, 3>(a, s, hs, &used);
     else if (s->kd == 1 && s->kh == 3 && s->kw == 3) rc = launch_wgrad2<1, 3, 3>(a, s, hs, &used);
   }

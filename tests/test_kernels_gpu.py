@@ -58,6 +58,7 @@ CONV_CASES = [
     (2, 16, 32, (17, 66, 70), (3, 3, 3)),    # same kernel, ragged extents, single K chunk
     (2, 48, 96, (16, 64, 64), (3, 3, 3)),    # streamed-weight ping-pong kernel: 3 K chunks, 3 cout tiles over 2 blocks
     (4, 64, 32, (2, 64, 64), (1, 3, 3)),     # same, (1,3,3) taps, one cout tile
+    (2, 32, 32, (6, 128, 256), (3, 3, 3)),   # 512 tile columns: sliding-halo wgrad (ring of D planes), ragged D tiles
 ]
 
 

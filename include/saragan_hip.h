@@ -60,7 +60,18 @@ typedef struct {
   int32_t pixel_norm;  /* 1: y *= rsqrt(mean_c(y^2)+eps); requires cout <= 128 */
   float eps;
   float* pn_scale;     /* optional [n*d*h*w] f32: the per-voxel rsqrt factor (saved for backward) */
+  const void* mask_bits; /* optional sign words (layout below) of a tensor shaped like y: y *= (bit ? mask_slope : 1),
+                            applied last.  Fuses the LeakyReLU backward of the layer whose output gradient this
+                            data-gradient convolution produces (networks/ops.py:175-178: dx = where(y >= 0, dy,
+                            dy*alpha)) into the convolution. */
+  float mask_slope;
+  void* sign_out;        /* optional: receives the sign words of y (after bias + act) for a later mask_bits */
 } sg_conv_epilogue;
+
+/* Sign words of an NDHWC tensor t[nvox][c]: uint32 words[nvox][ceil(c/32)], bit j of word (v, k) = (t[v][32k+j] < 0),
+ * bits of channels >= c are 0.  One bit per element instead of re-reading the bf16/f32 activation in backward. */
+size_t sg_sign_words_bytes(int64_t nvox, int32_t c);
+int sg_sign_words(const void* t, void* words, int64_t nvox, int32_t c, sg_dtype dt, sg_stream_t st);
 
 const char* sg_version(void);
 const char* sg_error_string(int code);
@@ -81,6 +92,10 @@ int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_conv_shape* s
 size_t sg_conv3d_wgrad_workspace(const sg_conv_shape* s, sg_dtype dt);
 int sg_conv3d_wgrad(const void* x, const void* dy, float* dw_dhwio, float coef, void* workspace,
                     size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st);
+/* Same, and dbias[cout] (f32, overwritten) = sum_v dy[v]: the gradient of apply_bias (networks/ops.py:130-136)
+ * from the pass that reads dy anyway. */
+int sg_conv3d_wgrad_bias(const void* x, const void* dy, float* dw_dhwio, float* dbias, float coef, void* workspace,
+                         size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st);
 
 /* ---- elementwise / reductions over NDHWC -------------------------------------------------------- */
 /* y = act(x + bias[c])                       (apply_bias + act, networks/ops.py:130-136,185-192) */
@@ -91,6 +106,9 @@ int sg_bias_act_fwd(const void* x, const float* bias, void* y, int64_t nvox, int
 size_t sg_bias_act_bwd_workspace(int32_t c);
 int sg_bias_act_bwd(const void* dy, const void* y, void* dx, float* dbias, void* workspace, int64_t nvox,
                     int32_t c, float slope, sg_dtype dt, sg_stream_t st);
+/* Same with the mask taken from the sign words of y (sg_sign_words / sg_conv_epilogue.sign_out). */
+int sg_bias_act_bwd_bits(const void* dy, const void* y_sign_words, void* dx, float* dbias, void* workspace,
+                         int64_t nvox, int32_t c, float slope, sg_dtype dt, sg_stream_t st);
 /* y = x * rsqrt(mean_c(x^2) + eps); scale (optional, [nvox] f32) receives the rsqrt factor.
  * (pixel_norm, networks/ops.py:308-310) */
 int sg_pixel_norm_fwd(const void* x, void* y, float* scale, int64_t nvox, int32_t c, float eps,
@@ -101,6 +119,10 @@ int sg_pixel_norm_bwd(const void* dy, const void* y, const float* scale, void* d
 /* y[n,2d,2h,2w,c] = gain * x[n,d,h,w,c] nearest-neighbour    (upscale3d / avg_unpool3d, ops.py:250-262) */
 int sg_upscale2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
                  float gain, sg_dtype dt, sg_stream_t st);
+/* Same with a fused LeakyReLU backward: y *= (bit ? mask_slope : 1), mask_bits = sign words of a tensor shaped like
+ * y.  This is the gradient of `downscale3d(leaky_relu(.))` (pgan/discriminator.py:39-44) in one pass. */
+int sg_upscale2x_masked(const void* x, void* y, const void* mask_bits, float mask_slope, int32_t n, int32_t d,
+                        int32_t h, int32_t w, int32_t c, float gain, sg_dtype dt, sg_stream_t st);
 /* y[n,d/2,h/2,w/2,c] = gain * sum of the 2x2x2 block; gain = 1/8 is downscale3d (ops.py:265-273),
  * gain = 1 is the gradient of upscale3d (ops.py:284).  (d,h,w) = INPUT extent, all even. */
 int sg_downscale2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,

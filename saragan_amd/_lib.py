@@ -17,7 +17,8 @@ class ConvShape(C.Structure):
 
 class ConvEpilogue(C.Structure):
     _fields_ = [('bias', C.c_void_p), ('act', C.c_int32), ('slope', C.c_float), ('pixel_norm', C.c_int32),
-                ('eps', C.c_float), ('pn_scale', C.c_void_p)]
+                ('eps', C.c_float), ('pn_scale', C.c_void_p), ('mask_bits', C.c_void_p), ('mask_slope', C.c_float),
+                ('sign_out', C.c_void_p)]
 
 
 class ProfEntry(C.Structure):
@@ -37,12 +38,17 @@ SIGNATURES = {
     'sg_conv3d_fwd': (C.c_int, [_p, _p, _p, _SHP, C.POINTER(ConvEpilogue), C.c_int, _p]),
     'sg_conv3d_wgrad_workspace': (_sz, [_SHP, C.c_int]),
     'sg_conv3d_wgrad': (C.c_int, [_p, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
+    'sg_conv3d_wgrad_bias': (C.c_int, [_p, _p, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
     'sg_bias_act_fwd': (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _f, C.c_int, _p]),
     'sg_bias_act_bwd_workspace': (_sz, [_i32]),
     'sg_bias_act_bwd': (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _f, C.c_int, _p]),
+    'sg_bias_act_bwd_bits': (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _f, C.c_int, _p]),
+    'sg_sign_words_bytes': (_sz, [_i64, _i32]),
+    'sg_sign_words': (C.c_int, [_p, _p, _i64, _i32, C.c_int, _p]),
     'sg_pixel_norm_fwd': (C.c_int, [_p, _p, _p, _i64, _i32, _f, C.c_int, _p]),
     'sg_pixel_norm_bwd': (C.c_int, [_p, _p, _p, _p, _i64, _i32, C.c_int, _p]),
     'sg_upscale2x': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
+    'sg_upscale2x_masked': (C.c_int, [_p, _p, _p, _f, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
     'sg_downscale2x': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
     'sg_axpby': (C.c_int, [_p, _p, _p, _f, _f, _i64, C.c_int, _p]),
     'sg_add_noise': (C.c_int, [_p, _p, _f, _u64, _u64, _i64, C.c_int, _p]),

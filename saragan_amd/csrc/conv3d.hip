@@ -101,6 +101,9 @@ struct ConvFwdArgs {
   void* y;
   const float* bias;
   float* pn_scale;
+  const uint32_t* mask_bits;   // optional sign words [voxel][ntile]: output *= (bit ? mask_slope : 1)  (fused LeakyReLU backward)
+  uint32_t* sign_out;          // optional sign words of THIS output (after bias/act), same layout, for a later mask_bits
+  float mask_slope;
   sg_tile_geom g;
   int cin, cout, taps, kh, kw;
   int nchunk, ntile;    // K chunks of 32 B, output-channel tiles of 32
@@ -110,12 +113,38 @@ struct ConvFwdArgs {
   sg_fastdiv fnp;       // fastdiv by pieces per halo row (G*2)
   int sshift, rshift;   // v2: log2(slots per row), log2(rows per 256-byte bank row)
   int wbytes, ntiles;   // v3r: resident weight image bytes, number of spatial tiles
+  int wres;             // v4: all weight slabs resident in LDS
   unsigned long long* dbg;  // diagnostic time stamps (NULL in production)
   int dbg_flags;            // diagnostic ablations (0 in production): 1 = no re-staging, 2 = no epilogue
   int vec_in, vec_out;
   int act, pixel_norm;
   float slope, eps;
 };
+
+template <typename T> struct sg_vec4 { typedef u32x4 type; };
+template <> struct sg_vec4<bf16_t> { typedef u32x2 type; };
+
+// ---- LeakyReLU sign words.  A lane holds, of voxel r and N tile nt, the 16 channels (i&3) + 8*(i>>2) + 4*hh; its
+// partner lane r+32 holds the other 16, so one xor-32 shuffle completes the voxel's 32-bit word.
+// Written with shifts by inline constants only: literal masks (1u << k) would each occupy a register for the whole
+// persistent loop.  The sign BIT is used (x < 0 up to the sign of zero, which no accumulator path here produces).
+__device__ __forceinline__ uint32_t sg_sign_word(const f32x16& v, int hh) {
+  uint32_t b = 0u;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) b |= (__float_as_uint(v[i]) >> 31) << ((i & 3) + 8 * (i >> 2));
+  b <<= 4 * hh;
+  return b | (uint32_t)__shfl_xor((int)b, 32);
+}
+
+__device__ __forceinline__ void sg_apply_sign_word(f32x16& v, uint32_t word, int hh, float slope) {
+  const uint32_t wsh = word >> (4 * hh);
+  const uint32_t su = __float_as_uint(slope), one = 0x3F800000u;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int t = ((int)(wsh << (31 - ((i & 3) + 8 * (i >> 2))))) >> 31;   // 1-bit signed field: 0 or -1
+    v[i] *= __uint_as_float(((uint32_t)t & su) | (~(uint32_t)t & one));   // bit ? slope : 1
+  }
+}
 
 // ---- epilogue shared by both forward kernels: lane owns voxel r of each M tile and output channels
 // (i&3) + 8*(i>>2) + 4*hh of each N tile: bias, LeakyReLU and pixel-norm are lane-local (+1 shuffle).
@@ -148,8 +177,21 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MTW][NTB], const int
         for (int i = 0; i < 16; ++i) acc[mt][nt][i] *= sc;
       if (a.pn_scale != nullptr && hh == 0 && ooff[mt] >= 0) a.pn_scale[ooff[mt]] = sc;
     }
+    if (a.sign_out != nullptr) {   // uniform branch: the shuffle inside needs every lane
+#pragma unroll
+      for (int nt = 0; nt < NTB; ++nt) {
+        const uint32_t sw = sg_sign_word(acc[mt][nt], hh);
+        if (hh == 0 && ooff[mt] >= 0 && nt0 + nt < a.ntile) a.sign_out[ooff[mt] * a.ntile + nt0 + nt] = sw;
+      }
+    }
     if (ooff[mt] >= 0) {
       T* yrow = y + ooff[mt] * (int64_t)a.cout;
+      if (a.mask_bits != nullptr) {   // fused LeakyReLU backward of the layer that produced this conv's input gradient
+#pragma unroll
+        for (int nt = 0; nt < NTB; ++nt)
+          if (nt0 + nt < a.ntile)
+            sg_apply_sign_word(acc[mt][nt], a.mask_bits[ooff[mt] * a.ntile + nt0 + nt], hh, a.mask_slope);
+      }
 #pragma unroll
       for (int nt = 0; nt < NTB; ++nt) {
 #pragma unroll
@@ -846,6 +888,21 @@ __global__ __launch_bounds__(512) void conv_fwd3r_kernel(ConvFwdArgs a) {
       }
     } else {
       if (a.dbg_flags & 4) __builtin_amdgcn_s_setprio(3);
+      // fused LeakyReLU-backward mask: request the sign words of the tile I am about to store BEFORE the halo DMA
+      // is queued, so that they have landed by the time the epilogue needs them (one VGPR per M tile)
+      uint32_t mb[MTW];
+      const bool use_mask = a.mask_bits != nullptr && p >= 1 && !(a.dbg_flags & 2);
+      if (use_mask) {
+        const sg_tile_origin om = sg_tile_of(g, (uint32_t)(first + (p - 1) * per_x));
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          const int tc = tcoord[mt];
+          const int n = om.n0 + (tc >> 24), d = om.d0 + ((tc >> 16) & 255), h = om.h0 + ((tc >> 8) & 255),
+                    w = om.w0 + (tc & 255);
+          const bool ok = tc >= 0 && n < g.N && d < g.D && h < g.H && w < g.W;
+          mb[mt] = ok ? a.mask_bits[((((int64_t)n * g.D + d) * g.H + h) * g.W + w) * a.ntile + nt0] : 0u;
+        }
+      }
       if (p + 1 < K && !((a.dbg_flags & 1) && p >= 2)) stage_tile(sg_tile_of(g, (uint32_t)(first + (p + 1) * per_x)));   // into my (now idle) buffer
       stamp();
       if (p >= 1 && !(a.dbg_flags & 2)) {
@@ -871,6 +928,11 @@ __global__ __launch_bounds__(512) void conv_fwd3r_kernel(ConvFwdArgs a) {
             if (a.pn_scale != nullptr && hh == 0 && ok)
               a.pn_scale[(((int64_t)n * g.D + d) * g.H + h) * g.W + w] = sc;
           }
+          if (a.sign_out != nullptr) {
+            const uint32_t sw = sg_sign_word(acc[mt], hh);
+            if (hh == 0 && ok) a.sign_out[((((int64_t)n * g.D + d) * g.H + h) * g.W + w) * a.ntile + nt0] = sw;
+          }
+          if (use_mask) sg_apply_sign_word(acc[mt], mb[mt], hh, a.mask_slope);
           if (ok) {
             T* yrow = y + ((((int64_t)n * g.D + d) * g.H + h) * g.W + w) * (int64_t)a.cout;
 #pragma unroll
@@ -958,8 +1020,10 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
   const int r = lane & 31, hh = lane >> 5;
   // LDS map: [halo 0][halo 1][weights 0][weights 1][bias: NTB*32 floats]
   char* xmine = smem + grp * a.xbytes;
-  char* wmine = smem + 2 * a.xbytes + grp * a.wbytes;
-  float* bias_lds = reinterpret_cast<float*>(smem + 2 * a.xbytes + 2 * a.wbytes);
+  // a.wres: every chunk's weight slab stays resident ([chunk][tap][nt]); otherwise one slab per group, re-fetched
+  // per item
+  char* wmine = smem + 2 * a.xbytes + (a.wres ? 0 : grp * a.wbytes);
+  float* bias_lds = reinterpret_cast<float*>(smem + 2 * a.xbytes + (a.wres ? a.nchunk : 2) * a.wbytes);
   const T* x = reinterpret_cast<const T*>(a.x);
   const char* wp = reinterpret_cast<const char*>(a.wp);
   constexpr int rb = 32;                      // halo row bytes: one 32-byte chunk, 2 slots, f(row) = (row>>3)&1
@@ -1068,6 +1132,7 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
     }
     // weight slab of this chunk: [tap][nt] fragments
     constexpr int nfrag = TAPS * NTB;
+    if (!a.wres)
     for (int f = wave; f < nfrag; f += 4) {
       const int tap = f / NTB, nt = f - tap * NTB;
       const char* src = nt < ntb ? wp + ((((int64_t)cg * TAPS + tap) * a.ntile + (nt0 + nt)) << 10)
@@ -1079,6 +1144,17 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
   if (tid < NTB * 32) {
     const int co = nt0 * 32 + tid;
     bias_lds[tid] = (a.bias != nullptr && co < a.cout) ? a.bias[co] : 0.f;
+  }
+  if (a.wres) {   // all chunks' slabs, once, by all 8 waves
+    const int nfrag_all = ncg * TAPS * NTB;
+    for (int f = wave8; f < nfrag_all; f += 8) {
+      const int nt = f % NTB;
+      const int q_ = f / NTB;
+      const int tap = q_ % TAPS, cg = q_ / TAPS;
+      const char* src = nt < ntb ? wp + ((((int64_t)cg * TAPS + tap) * a.ntile + (nt0 + nt)) << 10)
+                                 : reinterpret_cast<const char*>(sg_zero_page);
+      sg_glds16(src + lane * 16, wmine + ((size_t)f << 10));
+    }
   }
   if (grp == 0 && items_mine > 0) stage_item(0);
   __syncthreads();
@@ -1101,14 +1177,30 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
 #pragma unroll
               for (int i = 0; i < 16; ++i) acc[mt][nt][i] = bias_lds[nt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];
         }
-        sg_unrolled_k4<T, MTW, NTB, TAPS, 3>::run(acc, xaddr, (int)(wl - smem));
+        sg_unrolled_k4<T, MTW, NTB, TAPS, 3>::run(acc, xaddr, (int)(wl - smem) + (a.wres ? (q % ncg) * a.wbytes : 0));
       }
     } else {
       // my next item is q' = (p + 1) >> 1; my previous one q' - 1 (ran in phase p - 1)
       const int qn = (p + 1) >> 1;
-      if (qn < items_mine) stage_item(qn);
       const int qp = qn - 1;
-      if (qp >= 0 && qp < items_mine && (qp % ncg) == ncg - 1) {
+      const bool closes = qp >= 0 && qp < items_mine && (qp % ncg) == ncg - 1;   // my previous item finished a tile
+      uint32_t mb[MTW][NTB];
+      const bool use_mask = a.mask_bits != nullptr && closes;
+      if (use_mask) {   // sign words of the tile about to be stored, requested ahead of the halo DMA
+        const sg_tile_origin om = sg_tile_of(g, (uint32_t)tile_of_item(qp));
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) {
+          const int tc = tcoord[mt];
+          const int n = om.n0 + (tc >> 24), d = om.d0 + ((tc >> 16) & 255), h = om.h0 + ((tc >> 8) & 255),
+                    w = om.w0 + (tc & 255);
+          const bool ok = tc >= 0 && n < g.N && d < g.D && h < g.H && w < g.W;
+          const uint32_t* mrow = a.mask_bits + ((((int64_t)n * g.D + d) * g.H + h) * g.W + w) * a.ntile + nt0;
+#pragma unroll
+          for (int nt = 0; nt < NTB; ++nt) mb[mt][nt] = (ok && nt < ntb) ? mrow[nt] : 0u;
+        }
+      }
+      if (qn < items_mine) stage_item(qn);
+      if (closes) {
         const sg_tile_origin o = sg_tile_of(g, (uint32_t)tile_of_item(qp));
 #pragma unroll
         for (int mt = 0; mt < MTW; ++mt) {
@@ -1136,6 +1228,18 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
               for (int i = 0; i < 16; ++i) acc[mt][nt][i] *= sc;
             if (a.pn_scale != nullptr && hh == 0 && ok)
               a.pn_scale[(((int64_t)n * g.D + d) * g.H + h) * g.W + w] = sc;
+          }
+          if (a.sign_out != nullptr) {
+#pragma unroll
+            for (int nt = 0; nt < NTB; ++nt) {
+              const uint32_t sw = sg_sign_word(acc[mt][nt], hh);
+              if (hh == 0 && ok && nt < ntb)
+                a.sign_out[((((int64_t)n * g.D + d) * g.H + h) * g.W + w) * a.ntile + nt0 + nt] = sw;
+            }
+          }
+          if (use_mask) {
+#pragma unroll
+            for (int nt = 0; nt < NTB; ++nt) sg_apply_sign_word(acc[mt][nt], mb[mt][nt], hh, a.mask_slope);
           }
           if (ok) {
             T* yrow = y + ((((int64_t)n * g.D + d) * g.H + h) * g.W + w) * (int64_t)a.cout;
@@ -1183,7 +1287,9 @@ static int launch_fwd4(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, b
   a.xbytes = hv * 32;   // exact: lanes beyond the last row are masked off in the LDS-DMA
   a.wbytes = a.taps * NTB * 1024;
   if (sg_cdiv(hv * 2, 64) > 32) return SG_OK;
-  const size_t lds = 2ull * a.xbytes + 2ull * a.wbytes + NTB * 128;
+  size_t lds = 2ull * a.xbytes + (size_t)a.nchunk * a.wbytes + NTB * 128;
+  a.wres = (lds <= 160 * 1024 && !sg_env_int("SG_FWD4_NO_WRES", 0)) ? 1 : 0;
+  if (!a.wres) lds = 2ull * a.xbytes + 2ull * a.wbytes + NTB * 128;
   if (lds > 160 * 1024) return SG_OK;
   a.ntiles = (int)ntiles;
   a.vec_in = 1;
@@ -1212,6 +1318,9 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
   a.x = x; a.wp = wp; a.y = y;
   a.bias = ep ? ep->bias : nullptr;
   a.pn_scale = ep ? ep->pn_scale : nullptr;
+  a.mask_bits = ep ? reinterpret_cast<const uint32_t*>(ep->mask_bits) : nullptr;
+  a.sign_out = ep ? reinterpret_cast<uint32_t*>(ep->sign_out) : nullptr;
+  a.mask_slope = ep ? ep->mask_slope : 0.f;
   a.act = ep ? ep->act : 0;
   a.slope = ep ? ep->slope : 0.f;
   a.pixel_norm = ep ? ep->pixel_norm : 0;

@@ -26,6 +26,12 @@ struct Piece {
   }
 };
 
+// sign words (include/saragan_hip.h): the E <= 8 channels of one 16-byte piece starting at channel c0 (c0 % E == 0)
+// lie in one word; bit e of the result belongs to channel c0 + e
+__device__ __forceinline__ uint32_t piece_signs(const uint32_t* __restrict__ words, int64_t vox, int nw, int c0) {
+  return words[vox * nw + (c0 >> 5)] >> (c0 & 31);
+}
+
 inline int grid_for(int64_t items, int per_block = 256, int cap = 2048) {
   int64_t b = (items + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -67,7 +73,8 @@ __global__ void bias_act_fwd_kernel(const T* __restrict__ x, const float* __rest
 template <typename T>
 __global__ __launch_bounds__(256) void bias_act_bwd_vec_kernel(const T* __restrict__ dy, const T* __restrict__ y,
                                                                T* __restrict__ dx, float* __restrict__ part,
-                                                               int64_t nvox, int c, float slope) {
+                                                               int64_t nvox, int c, float slope,
+                                                               const uint32_t* __restrict__ words) {
   constexpr int E = Piece<T>::E;
   __shared__ float red[256 * E];
   const int P = c / E;            // divides 256
@@ -85,6 +92,10 @@ __global__ __launch_bounds__(256) void bias_act_bwd_vec_kernel(const T* __restri
       yy.load(y + off);
 #pragma unroll
       for (int e = 0; e < E; ++e) g.v[e] = yy.v[e] >= 0.f ? g.v[e] : g.v[e] * slope;
+    } else if (words) {
+      const uint32_t sw = piece_signs(words, v, (c + 31) >> 5, p * E);
+#pragma unroll
+      for (int e = 0; e < E; ++e) g.v[e] = ((sw >> e) & 1u) ? g.v[e] * slope : g.v[e];
     }
     if (dx) g.store(dx + off);
 #pragma unroll
@@ -107,7 +118,8 @@ __global__ __launch_bounds__(256) void bias_act_bwd_vec_kernel(const T* __restri
 
 template <typename T>
 __global__ void bias_act_bwd_scalar_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx,
-                                           float* __restrict__ part, int64_t nvox, int c, float slope) {
+                                           float* __restrict__ part, int64_t nvox, int c, float slope,
+                                           const uint32_t* __restrict__ words) {
   // generic fallback: one thread per channel column segment; correct for any c, not tuned
   const int64_t rows_per_block = (nvox + gridDim.x - 1) / gridDim.x;
   const int64_t v0 = (int64_t)blockIdx.x * rows_per_block;
@@ -117,10 +129,24 @@ __global__ void bias_act_bwd_scalar_kernel(const T* __restrict__ dy, const T* __
     for (int64_t v = v0; v < v1; ++v) {
       float g = sg_traits<T>::to_f(dy[v * c + ch]);
       if (y) g = sg_traits<T>::to_f(y[v * c + ch]) >= 0.f ? g : g * slope;
+      else if (words && ((words[v * ((c + 31) >> 5) + (ch >> 5)] >> (ch & 31)) & 1u)) g *= slope;
       if (dx) dx[v * c + ch] = sg_traits<T>::from_f(g);
       s += g;
     }
     if (part) part[(int64_t)blockIdx.x * c + ch] = s;
+  }
+}
+
+template <typename T>
+__global__ void sign_words_kernel(const T* __restrict__ t, uint32_t* __restrict__ words, int64_t nvox, int c) {
+  const int nw = (c + 31) >> 5;
+  const int64_t total = nvox * nw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t v = i / nw;
+    const int c0 = (int)(i - v * nw) * 32;
+    uint32_t b = 0u;
+    for (int j = 0; j < 32 && c0 + j < c; ++j) b |= (sg_traits<T>::to_f(t[v * c + c0 + j]) < 0.f) ? (1u << j) : 0u;
+    words[i] = b;
   }
 }
 
@@ -227,7 +253,7 @@ __global__ void pixel_norm_scalar_kernel(const T* __restrict__ a, const T* __res
 // ---------------------------------------------------------------------------------------------------
 template <typename T, bool VEC>
 __global__ void upscale2x_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int d, int h, int w, int c,
-                                 float gain) {
+                                 float gain, const uint32_t* __restrict__ mask_bits, float mask_slope) {
   constexpr int E = VEC ? Piece<T>::E : 1;
   const int P = c / E;
   const int64_t total = (int64_t)n * (2 * d) * (2 * h) * (2 * w) * P;
@@ -246,9 +272,16 @@ __global__ void upscale2x_kernel(const T* __restrict__ x, T* __restrict__ y, int
 #pragma unroll
         for (int e = 0; e < Piece<T>::E; ++e) pc.v[e] *= gain;
       }
+      if (mask_bits) {
+        const uint32_t sw = piece_signs(mask_bits, i / P, (c + 31) >> 5, p * E);
+#pragma unroll
+        for (int e = 0; e < Piece<T>::E; ++e) pc.v[e] = ((sw >> e) & 1u) ? pc.v[e] * mask_slope : pc.v[e];
+      }
       pc.store(y + i * E);
     } else {
-      y[i] = sg_traits<T>::from_f(sg_traits<T>::to_f(x[src]) * gain);
+      float v = sg_traits<T>::to_f(x[src]) * gain;
+      if (mask_bits && ((mask_bits[(i / c) * ((c + 31) >> 5) + (p >> 5)] >> (p & 31)) & 1u)) v *= mask_slope;
+      y[i] = sg_traits<T>::from_f(v);
     }
   }
 }
@@ -460,8 +493,8 @@ extern "C" int sg_bias_act_fwd(const void* x, const float* bias, void* y, int64_
 static const int kBwdBlocks = 1024;
 extern "C" size_t sg_bias_act_bwd_workspace(int32_t c) { return (size_t)kBwdBlocks * (size_t)(c > 0 ? c : 0) * sizeof(float); }
 
-extern "C" int sg_bias_act_bwd(const void* dy, const void* y, void* dx, float* dbias, void* workspace, int64_t nvox,
-                               int32_t c, float slope, sg_dtype dt, sg_stream_t st) {
+static int bias_act_bwd_launch(const void* dy, const void* y, const uint32_t* words, void* dx, float* dbias,
+                               void* workspace, int64_t nvox, int32_t c, float slope, sg_dtype dt, sg_stream_t st) {
   if (!dy || nvox < 1 || c < 1 || (!dx && !dbias)) return SG_EINVAL;
   if (dbias && !workspace) return SG_EINVAL;
   hipStream_t hs = sg_st(st);
@@ -474,12 +507,12 @@ extern "C" int sg_bias_act_bwd(const void* dy, const void* y, void* dx, float* d
   if (vec) {
     const int rows = 256 / P;
     blocks = grid_for(nvox, rows, kBwdBlocks);
-#define L(T) hipLaunchKernelGGL((bias_act_bwd_vec_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)dy, (const T*)y, (T*)dx, part, nvox, c, slope)
+#define L(T) hipLaunchKernelGGL((bias_act_bwd_vec_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)dy, (const T*)y, (T*)dx, part, nvox, c, slope, words)
     SG_DISPATCH(dt, L(bf16_t), L(float));
 #undef L
   } else {
     blocks = grid_for(nvox, 64, kBwdBlocks);
-#define L(T) hipLaunchKernelGGL((bias_act_bwd_scalar_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)dy, (const T*)y, (T*)dx, part, nvox, c, slope)
+#define L(T) hipLaunchKernelGGL((bias_act_bwd_scalar_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)dy, (const T*)y, (T*)dx, part, nvox, c, slope, words)
     SG_DISPATCH(dt, L(bf16_t), L(float));
 #undef L
   }
@@ -488,6 +521,33 @@ extern "C" int sg_bias_act_bwd(const void* dy, const void* y, void* dx, float* d
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 31) / 32), dim3(256), 0, hs, part, dbias, blocks, c);
     SG_LAUNCH_CHECK();
   }
+  return SG_OK;
+}
+
+extern "C" int sg_bias_act_bwd(const void* dy, const void* y, void* dx, float* dbias, void* workspace, int64_t nvox,
+                               int32_t c, float slope, sg_dtype dt, sg_stream_t st) {
+  return bias_act_bwd_launch(dy, y, nullptr, dx, dbias, workspace, nvox, c, slope, dt, st);
+}
+
+extern "C" int sg_bias_act_bwd_bits(const void* dy, const void* y_sign_words, void* dx, float* dbias, void* workspace,
+                                    int64_t nvox, int32_t c, float slope, sg_dtype dt, sg_stream_t st) {
+  if (!y_sign_words) return SG_EINVAL;
+  return bias_act_bwd_launch(dy, nullptr, reinterpret_cast<const uint32_t*>(y_sign_words), dx, dbias, workspace, nvox,
+                             c, slope, dt, st);
+}
+
+extern "C" size_t sg_sign_words_bytes(int64_t nvox, int32_t c) {
+  return (nvox > 0 && c > 0) ? (size_t)nvox * (size_t)((c + 31) / 32) * 4u : 0u;
+}
+
+extern "C" int sg_sign_words(const void* t, void* words, int64_t nvox, int32_t c, sg_dtype dt, sg_stream_t st) {
+  if (!t || !words || nvox < 1 || c < 1) return SG_EINVAL;
+  hipStream_t hs = sg_st(st);
+  const int blocks = grid_for(nvox * ((c + 31) / 32));
+#define L(T) hipLaunchKernelGGL((sign_words_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)t, (uint32_t*)words, nvox, c)
+  SG_DISPATCH(dt, L(bf16_t), L(float));
+#undef L
+  SG_LAUNCH_CHECK();
   return SG_OK;
 }
 
@@ -528,13 +588,18 @@ extern "C" int sg_pixel_norm_bwd(const void* dy, const void* y, const float* sca
 
 extern "C" int sg_upscale2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
                             float gain, sg_dtype dt, sg_stream_t st) {
+  return sg_upscale2x_masked(x, y, nullptr, 0.f, n, d, h, w, c, gain, dt, st);
+}
+
+extern "C" int sg_upscale2x_masked(const void* x, void* y, const void* mask_bits, float mask_slope, int32_t n, int32_t d,
+                                   int32_t h, int32_t w, int32_t c, float gain, sg_dtype dt, sg_stream_t st) {
   if (!x || !y || n < 1 || d < 1 || h < 1 || w < 1 || c < 1) return SG_EINVAL;
   hipStream_t hs = sg_st(st);
   const int E = dt == SG_BF16 ? 8 : 4;
   const bool vec = (c % E == 0) && sg_aligned16(x) && sg_aligned16(y);
   const int64_t items = (int64_t)n * d * h * w * 8 * (vec ? c / E : c);
   const int blocks = grid_for(items, 256, 4096);
-#define L(T, V) hipLaunchKernelGGL((upscale2x_kernel<T, V>), dim3(blocks), dim3(256), 0, hs, (const T*)x, (T*)y, n, d, h, w, c, gain)
+#define L(T, V) hipLaunchKernelGGL((upscale2x_kernel<T, V>), dim3(blocks), dim3(256), 0, hs, (const T*)x, (T*)y, n, d, h, w, c, gain, (const uint32_t*)mask_bits, mask_slope)
   if (vec) SG_DISPATCH(dt, L(bf16_t, true), L(float, true));
   else SG_DISPATCH(dt, L(bf16_t, false), L(float, false));
 #undef L

@@ -26,6 +26,7 @@ struct WgradArgs {
   sg_fastdiv fnp;
   int vec_x, vec_y;
   int plane_rows;  // wgrad3: LDS rows per halo plane slot
+  float* dbias;    // optional [cout]: column sums of dy (bias gradient), accumulated by the ci_t == 0 blocks
   int dbg_flags;   // diagnostic ablations (0 in production): 1 = stage only the first items
 };
 
@@ -176,16 +177,18 @@ static int conv_shape_ok_w(const sg_conv_shape* s) {
 // ------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void pw_wgrad_partial_kernel(const T* __restrict__ small, const T* __restrict__ big,
-                                                               float* __restrict__ part, int64_t nvox, int cs, int cb) {
+                                                               float* __restrict__ part, int64_t nvox, int cs, int cb,
+                                                               int ones_extra) {
   constexpr int E = 16 / (int)sizeof(T);
   __shared__ float red[256 * E];
   const int P = cb / E, rows = 256 / P;
   const int p = threadIdx.x % P, rr = threadIdx.x / P;
-  float s[4][E];
+  float s[5][E];   // row cs (when ones_extra): the big side's plain column sums (bias gradient)
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 5; ++j)
 #pragma unroll
     for (int e = 0; e < E; ++e) s[j][e] = 0.f;
+  const int csx = cs + (ones_extra ? 1 : 0);
   for (int64_t v = (int64_t)blockIdx.x * rows + rr; v < nvox; v += (int64_t)gridDim.x * rows) {
     u32x4 raw = *reinterpret_cast<const u32x4*>(big + v * cb + (int64_t)p * E);
     const T* bt = reinterpret_cast<const T*>(&raw);
@@ -193,15 +196,15 @@ __global__ __launch_bounds__(256) void pw_wgrad_partial_kernel(const T* __restri
 #pragma unroll
     for (int e = 0; e < E; ++e) bv[e] = sg_traits<T>::to_f(bt[e]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (j < cs) {
-        const float sv = sg_traits<T>::to_f(small[v * cs + j]);
+    for (int j = 0; j < 5; ++j) {
+      if (j < csx) {
+        const float sv = j < cs ? sg_traits<T>::to_f(small[v * cs + j]) : 1.f;
 #pragma unroll
         for (int e = 0; e < E; ++e) s[j][e] += sv * bv[e];
       }
     }
   }
-  for (int j = 0; j < cs; ++j) {
+  for (int j = 0; j < csx; ++j) {
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < E; ++e) red[threadIdx.x * E + e] = s[j][e];
@@ -211,7 +214,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_partial_kernel(const T* __restri
       for (int e = 0; e < E; ++e) {
         float t = 0.f;
         for (int k = 0; k < rows; ++k) t += red[(k * P + threadIdx.x) * E + e];
-        part[((int64_t)blockIdx.x * cs + j) * cb + threadIdx.x * E + e] = t;
+        part[((int64_t)blockIdx.x * csx + j) * cb + threadIdx.x * E + e] = t;
       }
     }
   }
@@ -219,10 +222,11 @@ __global__ __launch_bounds__(256) void pw_wgrad_partial_kernel(const T* __restri
 
 // dw[ci][co] = coef * sum_b part[b][j][i]; small_is_cin: (j, i) = (ci, co) else (j, i) = (co, ci)
 __global__ __launch_bounds__(256) void pw_wgrad_final_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                             float coef, int nb, int cs, int cb, int small_is_cin) {
+                                                             float coef, int nb, int cs, int cb, int small_is_cin,
+                                                             float* __restrict__ dbias) {
   __shared__ float red[8][32];
   const int col = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
-  const int c = cs * cb;
+  const int c = (cs + (dbias ? 1 : 0)) * cb;
   float sum = 0.f;
   if (col < c)
     for (int b = rg; b < nb; b += 8) sum += part[(int64_t)b * c + col];
@@ -233,16 +237,17 @@ __global__ __launch_bounds__(256) void pw_wgrad_final_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x];
     const int j = col / cb, i = col - j * cb;
-    dw[small_is_cin ? (j * cb + i) : (i * cs + j)] = coef * t;
+    if (j < cs) dw[small_is_cin ? (j * cb + i) : (i * cs + j)] = coef * t;
+    else dbias[i] = t;
   }
 }
+
+static size_t wgrad_tile_bytes(const sg_conv_shape* s);
 
 extern "C" size_t sg_conv3d_wgrad_workspace(const sg_conv_shape* s, sg_dtype dt) {
   (void)dt;
   if (!conv_shape_ok_w(s)) return 0;
-  size_t need = (size_t)(s->kd * s->kh * s->kw) * sg_cdiv(s->cin, 32) * sg_cdiv(s->cout, 32) * 4096;
-  const size_t pw = (size_t)1024 * 4 * (size_t)(s->cin > s->cout ? s->cin : s->cout) * sizeof(float);
-  return need > pw ? need : pw;
+  return wgrad_tile_bytes(s) + sg_bias_act_bwd_workspace(s->cout);   // [tile / partial sums][bias-gradient fallback]
 }
 
 template <typename T, int BM>
@@ -556,6 +561,7 @@ struct sg_wgrad_tile {
   struct Ctx {
     int xl0, xl1, yl0, yl1;                     // lane parts (VGPR)
     int sslot[2][MAXT];                         // per (td, tap): ring-slot base + tap row shift (uniform)
+    int ones_last;                              // 1: this wave's last slot multiplies dy by ones (bias gradient)
     int throw_[TH];                             // per th: row offset (uniform)
   };
   template <int I>
@@ -588,6 +594,9 @@ struct sg_wgrad_tile {
         u32x4 af, bf;
         af[0] = __builtin_bit_cast(u32x2, a0[SL])[0]; af[1] = __builtin_bit_cast(u32x2, a0[SL])[1];
         af[2] = __builtin_bit_cast(u32x2, a1[SL])[0]; af[3] = __builtin_bit_cast(u32x2, a1[SL])[1];
+        if constexpr (j == MAXT - 1) {
+          if (c.ones_last) af = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};   // bf16 1.0 x 8
+        }
         bf[0] = __builtin_bit_cast(u32x2, b0[ks & 1])[0]; bf[1] = __builtin_bit_cast(u32x2, b0[ks & 1])[1];
         bf[2] = __builtin_bit_cast(u32x2, b1[ks & 1])[0]; bf[3] = __builtin_bit_cast(u32x2, b1[ks & 1])[1];
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf),
@@ -781,6 +790,9 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
     tap_hw[j] = tap < TAPS ? (kh_i * g.HW + kw_i) * 64 : 0;
     tap_kd[j] = tap < TAPS ? kd_i : 0;
   }
+  // bias gradient: wave 3's last slot is spare (27 = 4*7 - 1 taps, 9 = 4*3 - 3); it multiplies dy by ones
+  static_assert(3 + 4 * (MAXT - 1) >= TAPS, "no spare tap slot for the bias gradient");
+  const int ones_last = (a.dbias != nullptr && ci_t == 0 && wave == 3) ? 1 : 0;
   f32x16 acc[MAXT];
 #pragma unroll
   for (int j = 0; j < MAXT; ++j)
@@ -801,6 +813,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
         typedef sg_wgrad_tile<MAXT, 4, 5> KT;
         typename KT::Ctx c;
         c.xl0 = xl0; c.xl1 = xl1; c.yl0 = yl0; c.yl1 = yl1;
+        c.ones_last = ones_last;
 #pragma unroll
         for (int td = 0; td < 2; ++td)
 #pragma unroll
@@ -816,6 +829,8 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
     __syncthreads();
   }
   const int r = lane & 31, hh = lane >> 5;
+  if (ones_last && items_mine > 0 && hh == 0 && co_t * 32 + r < a.cout)   // row 0 of the ones product = column sums
+    unsafeAtomicAdd(a.dbias + co_t * 32 + r, acc[MAXT - 1][0]);
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
     const int tap = wave + 4 * j;
@@ -869,8 +884,19 @@ static int launch_wgrad3(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   return SG_OK;
 }
 
+static size_t wgrad_tile_bytes(const sg_conv_shape* s) {
+  const size_t need = (size_t)(s->kd * s->kh * s->kw) * sg_cdiv(s->cin, 32) * sg_cdiv(s->cout, 32) * 4096;
+  const size_t pw = (size_t)1024 * 5 * (size_t)(s->cin > s->cout ? s->cin : s->cout) * sizeof(float);
+  return ((need > pw ? need : pw) + 255) & ~(size_t)255;
+}
+
 extern "C" int sg_conv3d_wgrad(const void* x, const void* dy, float* dw, float coef, void* workspace,
                                size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st) {
+  return sg_conv3d_wgrad_bias(x, dy, dw, nullptr, coef, workspace, workspace_bytes, s, dt, st);
+}
+
+extern "C" int sg_conv3d_wgrad_bias(const void* x, const void* dy, float* dw, float* dbias, float coef, void* workspace,
+                                    size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st) {
   if (!conv_shape_ok_w(s) || !x || !dy || !dw || !workspace) return SG_EINVAL;
   if (!sg_aligned16(x) || !sg_aligned16(dy) || !sg_aligned16(workspace)) return SG_EALIGN;
   const size_t need = sg_conv3d_wgrad_workspace(s, dt);
@@ -890,23 +916,30 @@ extern "C" int sg_conv3d_wgrad(const void* x, const void* dy, float* dw, float c
       int64_t nb = (nvox + rows - 1) / rows;
       if (nb > 1024) nb = 1024;
       float* part = reinterpret_cast<float*>(workspace);
+      const int ones = (dbias != nullptr && small_is_cin) ? 1 : 0;   // the big side is dy: its column sums are the bias gradient
       if (dt == SG_BF16)
         hipLaunchKernelGGL(pw_wgrad_partial_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, hs, (const bf16_t*)sm,
-                           (const bf16_t*)bg, part, nvox, cs, cb);
+                           (const bf16_t*)bg, part, nvox, cs, cb, ones);
       else
         hipLaunchKernelGGL(pw_wgrad_partial_kernel<float>, dim3((unsigned)nb), dim3(256), 0, hs, (const float*)sm,
-                           (const float*)bg, part, nvox, cs, cb);
-      hipLaunchKernelGGL(pw_wgrad_final_kernel, dim3((unsigned)((cs * cb + 31) / 32)), dim3(256), 0, hs, part, dw, coef,
-                         (int)nb, cs, cb, small_is_cin);
-      hipError_t e0 = hipGetLastError();
-      prof.done((int)e0);
-      return (int)e0;
+                           (const float*)bg, part, nvox, cs, cb, ones);
+      hipLaunchKernelGGL(pw_wgrad_final_kernel, dim3((unsigned)(((cs + ones) * cb + 31) / 32)), dim3(256), 0, hs, part,
+                         dw, coef, (int)nb, cs, cb, small_is_cin, ones ? dbias : nullptr);
+      int e0 = (int)hipGetLastError();
+      if (e0 == 0 && dbias && !ones)   // bias lives on the small side (to_rgb): plain column sum of dy
+        e0 = sg_bias_act_bwd(dy, nullptr, nullptr, dbias, reinterpret_cast<char*>(workspace) + wgrad_tile_bytes(s), nvox,
+                             s->cout, 0.f, dt, st);
+      prof.done(e0);
+      return e0;
     }
   }
   const size_t tile_bytes = (size_t)(s->kd * s->kh * s->kw) * sg_cdiv(s->cin, 32) * sg_cdiv(s->cout, 32) * 4096;
   hipError_t e = hipMemsetAsync(workspace, 0, tile_bytes, hs);
+  if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, (size_t)s->cout * sizeof(float), hs);
   if (e != hipSuccess) { prof.done((int)e); return (int)e; }
   WgradArgs a;
+  a.dbias = dbias;
+  bool db_done = false;
   a.dbg_flags = getenv("SG_DBG_FLAGS") ? atoi(getenv("SG_DBG_FLAGS")) : 0;
   a.x = x; a.dy = dy; a.dwt = reinterpret_cast<float*>(workspace);
   a.cin = s->cin; a.cout = s->cout;
@@ -916,6 +949,7 @@ extern "C" int sg_conv3d_wgrad(const void* x, const void* dy, float* dw, float c
   bool used = false;
   if (dt == SG_BF16 && !getenv("SG_WGRAD_V1") && !getenv("SG_WGRAD_NO_V3")) {
     if (s->kd == 3 && s->kh == 3 && s->kw == 3) rc = launch_wgrad3<3, 3, 3>(a, s, hs, &used);
+    db_done = used;   // the sliding-halo kernel accumulates the bias gradient in its spare tap slot
   }
   if (rc == SG_OK && !used && dt == SG_BF16 && !getenv("SG_WGRAD_V1")) {
     if (s->kd == 3 && s->kh == 3 && s->kw == 3) rc = launch_wgrad2<3, 3, 3>(a, s, hs, &used);
@@ -935,6 +969,9 @@ extern "C" int sg_conv3d_wgrad(const void* x, const void* dy, float* dw, float c
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) rc = (int)e2;
   }
+  if (rc == SG_OK && dbias && !db_done)
+    rc = sg_bias_act_bwd(dy, nullptr, nullptr, dbias, reinterpret_cast<char*>(workspace) + wgrad_tile_bytes(s),
+                         (int64_t)s->n * s->d * s->h * s->w, s->cout, 0.f, dt, st);
   prof.done(rc);
   return rc;
 }

@@ -7,6 +7,7 @@ channels-last (torch.channels_last_3d == NDHWC); 2-D tensors [N, F] are NDHWC wi
 Each backward is itself built from these Functions, so second-order gradients (the gradient penalty of
 networks/loss.py:133-140 differentiates through D's data gradient) work.
 """
+import contextlib
 import ctypes as C
 import math
 
@@ -100,9 +101,33 @@ def _packed(w, coef, flip, shp, dt, lib, st):
     return wp
 
 
+def _empty_signs(device, n, d, h, w, c):
+    """Sign words of an NDHWC tensor (include/saragan_hip.h: sg_sign_words): int32 [n,d,h,w,ceil(c/32)]."""
+    return torch.empty((n, d, h, w, (c + 31) // 32), device=device, dtype=torch.int32)
+
+
+def _check_signs(bits, nvox, c):
+    if bits is None:
+        return
+    if bits.dtype != torch.int32 or not bits.is_contiguous() or bits.numel() != nvox * ((c + 31) // 32):
+        raise ValueError('sign words must be a contiguous int32 tensor [n,d,h,w,ceil(c/32)] of the masked tensor')
+
+
+def sign_words(t):
+    """Sign words of t (sg_sign_words): what sg_conv_epilogue.sign_out writes for a conv output."""
+    lib = _lib.load()
+    _req_cuda(t)
+    t = ndhwc(t)
+    n, c, d, h, w = _dims(t)
+    out = _empty_signs(t.device, n, d, h, w, c)
+    check(lib.sg_sign_words(_ptr(t), _ptr(out), n * d * h * w, c, _dt(t), _stream()), 'sg_sign_words')
+    return out
+
+
 def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel_norm=False, eps=1e-8,
-             want_scale=False):
-    """y = epilogue(conv3d(x, coef*w)) with w in DHWIO; `flip` selects the data-gradient weights."""
+             want_scale=False, mask_bits=None, mask_slope=0.0, want_signs=False):
+    """y = epilogue(conv3d(x, coef*w)) with w in DHWIO; `flip` selects the data-gradient weights.
+    Returns (y, pixel-norm scale or None, sign words of y or None)."""
     lib = _lib.load()
     _req_cuda(x, w, bias)
     x = ndhwc(x)
@@ -120,17 +145,20 @@ def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel
     st = _stream()
     wp = _packed(w, coef, flip, shp, dt, lib, st)
     y = _empty_like_shape(x, cout, (d, h, wd))
+    _check_signs(mask_bits, n * d * h * wd, cout)
+    signs = _empty_signs(x.device, n, d, h, wd, cout) if want_signs else None
     scale = None
     if pixel_norm and want_scale:
         scale = torch.empty(n * d * h * wd, device=x.device, dtype=torch.float32)
     b32 = bias.detach().contiguous().float() if bias is not None else None
-    ep = ConvEpilogue(_ptr(b32), 1 if act else 0, float(slope), 1 if pixel_norm else 0, float(eps), _ptr(scale))
+    ep = ConvEpilogue(_ptr(b32), 1 if act else 0, float(slope), 1 if pixel_norm else 0, float(eps), _ptr(scale),
+                      _ptr(mask_bits), float(mask_slope), _ptr(signs))
     check(lib.sg_conv3d_fwd(_ptr(x), _ptr(wp), _ptr(y), C.byref(shp), C.byref(ep), dt, st), 'sg_conv3d_fwd')
-    return y, scale
+    return y, scale, signs
 
 
-def raw_wgrad(x, dy, k, coef, ups=False):
-    """dw[kd,kh,kw,cin,cout] (f32) = coef * sum_v x[v+tap] (x) dy[v]."""
+def raw_wgrad(x, dy, k, coef, ups=False, want_db=False):
+    """dw[kd,kh,kw,cin,cout] (f32) = coef * sum_v x[v+tap] (x) dy[v]; optionally db[cout] = sum_v dy[v]."""
     lib = _lib.load()
     _req_cuda(x, dy)
     x, dy = ndhwc(x), ndhwc(dy)
@@ -143,9 +171,10 @@ def raw_wgrad(x, dy, k, coef, ups=False):
     ws_bytes = lib.sg_conv3d_wgrad_workspace(C.byref(shp), dt)
     ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
     dw = torch.empty((k[0], k[1], k[2], cin, cout), device=x.device, dtype=torch.float32)
-    check(lib.sg_conv3d_wgrad(_ptr(x), _ptr(dy), _ptr(dw), float(coef), _ptr(ws), ws_bytes, C.byref(shp), dt,
-                              _stream()), 'sg_conv3d_wgrad')
-    return dw
+    db = torch.empty(cout, device=x.device, dtype=torch.float32) if want_db else None
+    check(lib.sg_conv3d_wgrad_bias(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), float(coef), _ptr(ws), ws_bytes,
+                                   C.byref(shp), dt, _stream()), 'sg_conv3d_wgrad_bias')
+    return dw, db
 
 
 def raw_bias_act_bwd(dy, y, slope, want_dx=True, want_db=False):
@@ -153,59 +182,121 @@ def raw_bias_act_bwd(dy, y, slope, want_dx=True, want_db=False):
     dy = ndhwc(dy)
     n, c, d, h, w = _dims(dy)
     nvox = n * d * h * w
-    y = ndhwc(y) if y is not None else None
+    bits = y is not None and y.dtype == torch.int32     # the mask as sign words instead of the activation itself
+    if bits:
+        _check_signs(y, nvox, c)
+    elif y is not None:
+        y = ndhwc(y)
     dx = torch.empty_like(dy) if want_dx else None
     db = ws = None
     if want_db:
         db = torch.empty(c, device=dy.device, dtype=torch.float32)
         ws = torch.empty(lib.sg_bias_act_bwd_workspace(c), device=dy.device, dtype=torch.uint8)
-    check(lib.sg_bias_act_bwd(_ptr(dy), _ptr(y), _ptr(dx), _ptr(db), _ptr(ws), nvox, c, float(slope), _dt(dy),
-                              _stream()), 'sg_bias_act_bwd')
+    fn = lib.sg_bias_act_bwd_bits if bits else lib.sg_bias_act_bwd
+    check(fn(_ptr(dy), _ptr(y), _ptr(dx), _ptr(db), _ptr(ws), nvox, c, float(slope), _dt(dy), _stream()),
+          'sg_bias_act_bwd')
     return dx, db
 
 
 # ---------------------------------------------------------------------------------------------------
 # autograd Functions
 # ---------------------------------------------------------------------------------------------------
+_SKIP = {'ptrs': frozenset()}
+
+
+@contextlib.contextmanager
+def skip_param_grads(params):
+    """Inside this context the backward Functions do not compute gradients of the given parameters.
+    `ctx.needs_input_grad` is True for every weight that requires grad, also when the caller asked autograd for other
+    inputs only (the gradient-penalty d D/d x pass, networks/loss.py:136-139; the generator loss flowing through the
+    discriminator, optimization.py:128-163): the weight/bias-gradient kernels would run and their results be dropped."""
+    prev = _SKIP['ptrs']
+    _SKIP['ptrs'] = prev | frozenset(p.data_ptr() for p in params)
+    try:
+        yield
+    finally:
+        _SKIP['ptrs'] = prev
+
+
+def _wants(ctx, i, ptr):
+    return ctx.needs_input_grad[i] and ptr not in _SKIP['ptrs']
+
+
+class ActInfo:
+    """Bookkeeping of one LeakyReLU output `a` (created by the layer that produced it).  Consumers that are able
+    to apply the LeakyReLU-backward mask where(a >= 0, g, slope*g) inside THEIR backward kernel (the data-gradient
+    conv's epilogue, the masked up-scale) register as `premask`; if every consumer did, the producer skips its own
+    mask pass and takes the bias gradient from the weight-gradient kernel.  Evaluated at backward time, when all
+    consumers are known."""
+
+    def __init__(self, slope):
+        self.slope = float(slope)
+        self.bits = None          # sign words of `a`, written by the producing conv's epilogue
+        self.n_consumers = 0
+        self.n_premask = 0
+
+    def consume(self, premask):
+        self.n_consumers += 1
+        if premask:
+            self.n_premask += 1
+
+    def all_premask(self):
+        return self.bits is not None and self.n_consumers > 0 and self.n_consumers == self.n_premask
+
+
+def _masked_in(ctx_info):
+    return ctx_info is not None and ctx_info.all_premask()
+
+
 class _Conv(torch.autograd.Function):
-    """Plain conv3d / dense (networks/ops.py:139-150) or, with flip, its data gradient."""
+    """Plain conv3d / dense (networks/ops.py:139-150) or, with flip, its data gradient; `mask_bits` (sign words
+    of a tensor shaped like y) fuses a LeakyReLU backward into the epilogue (y *= where(bit, mask_slope, 1))."""
 
     @staticmethod
-    def forward(ctx, x, w, coef, flip, ups):
-        ctx.save_for_backward(x, w)
-        ctx.coef, ctx.flip, ctx.ups = coef, flip, ups
-        y, _ = raw_conv(x, w, coef, flip, ups)
+    def forward(ctx, x, w, coef, flip, ups, in_info=None, mask_bits=None, mask_slope=0.0):
+        ctx.save_for_backward(x, w, mask_bits)
+        ctx.coef, ctx.flip, ctx.ups, ctx.in_info, ctx.mask_slope = coef, flip, ups, in_info, mask_slope
+        y, _, _ = raw_conv(x, w, coef, flip, ups, mask_bits=mask_bits, mask_slope=mask_slope)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w = ctx.saved_tensors
+        x, w, mask_bits = ctx.saved_tensors
+        if mask_bits is not None:     # y = M * conv(x): pull the (linear) mask back onto the incoming gradient
+            gy, _ = _BiasActBwd.apply(gy, mask_bits, ctx.mask_slope, False)
         gx = gw = None
         k = tuple(w.shape[:3]) if w.dim() == 5 else (1, 1, 1)
         if ctx.needs_input_grad[0]:
-            gx = _Conv.apply(gy, w, ctx.coef, not ctx.flip, False)
+            if _masked_in(ctx.in_info) and not ctx.ups:
+                gx = _Conv.apply(gy, w, ctx.coef, not ctx.flip, False, None, ctx.in_info.bits, ctx.in_info.slope)
+            else:
+                gx = _Conv.apply(gy, w, ctx.coef, not ctx.flip, False)
             if ctx.ups:
                 gx = _Down.apply(gx, 1.0)
-        if ctx.needs_input_grad[1]:
+        if _wants(ctx, 1, w.data_ptr()):
             if ctx.flip:
                 if ctx.ups:
                     raise NotImplementedError
-                gw = _Wgrad.apply(gy, x, k, ctx.coef, False)
+                gw, _ = _Wgrad.apply(gy, x, k, ctx.coef, False, False)
             else:
-                gw = _Wgrad.apply(x, gy, k, ctx.coef, ctx.ups)
+                gw, _ = _Wgrad.apply(x, gy, k, ctx.coef, ctx.ups, False)
             gw = gw.reshape(w.shape)
-        return gx, gw, None, None, None
+        return gx, gw, None, None, None, None, None, None
 
 
 class _Wgrad(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, dy, k, coef, ups):
+    def forward(ctx, x, dy, k, coef, ups, want_db):
         ctx.save_for_backward(x, dy)
         ctx.k, ctx.coef, ctx.ups = k, coef, ups
-        return raw_wgrad(x, dy, k, coef, ups)
+        dw, db = raw_wgrad(x, dy, k, coef, ups, want_db)
+        if db is None:
+            db = dw.new_zeros(())
+        ctx.mark_non_differentiable(db)
+        return dw, db
 
     @staticmethod
-    def backward(ctx, gw):
+    def backward(ctx, gw, _gdb):
         x, dy = ctx.saved_tensors
         if ctx.ups:
             raise NotImplementedError('third-order gradient through a fused-upsample conv')
@@ -214,47 +305,61 @@ class _Wgrad(torch.autograd.Function):
             gx = _Conv.apply(dy, gw, ctx.coef, True, False)
         if ctx.needs_input_grad[1]:
             gdy = _Conv.apply(x, gw, ctx.coef, False, False)
-        return gx, gdy, None, None, None
+        return gx, gdy, None, None, None, None
 
 
 class _ConvBiasAct(torch.autograd.Function):
-    """conv3d -> apply_bias -> act [-> pixel_norm] in one kernel (networks/ops.py:130-150,185-192,308-310)."""
+    """conv3d -> apply_bias -> act [-> pixel_norm] in one kernel (networks/ops.py:130-150,185-192,308-310).
+    out_info / in_info: ActInfo of this layer's output / of the tensor it consumes (see ActInfo)."""
 
     @staticmethod
-    def forward(ctx, x, w, b, coef, ups, act, slope, pixel_norm, eps):
-        y, scale = raw_conv(x, w, coef, False, ups, bias=b, act=act, slope=slope, pixel_norm=pixel_norm, eps=eps,
-                            want_scale=True)
-        ctx.save_for_backward(x, w, y, scale)
+    def forward(ctx, x, w, b, coef, ups, act, slope, pixel_norm, eps, out_info=None, in_info=None):
+        y, scale, signs = raw_conv(x, w, coef, False, ups, bias=b, act=act, slope=slope, pixel_norm=pixel_norm,
+                                   eps=eps, want_scale=True, want_signs=act)
+        if out_info is not None:
+            out_info.bits = signs
+        ctx.save_for_backward(x, w, y if pixel_norm else None, scale, signs)
         ctx.cfg = (coef, ups, act, slope, pixel_norm)
         ctx.has_b = b is not None
+        ctx.b_ptr = b.data_ptr() if b is not None else 0
+        ctx.out_info, ctx.in_info = out_info, in_info
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w, y, scale = ctx.saved_tensors
+        x, w, y, scale, signs = ctx.saved_tensors
         coef, ups, act, slope, pixel_norm = ctx.cfg
         g = gy
         if pixel_norm:
             g = _PixelNormBwd.apply(g, y, scale)
-        want_db = ctx.has_b and ctx.needs_input_grad[2]
-        if act or want_db:
-            g, gb = _BiasActBwd.apply(g, y if act else None, slope, want_db)
-        else:
-            gb = None
+        want_db = ctx.has_b and _wants(ctx, 2, ctx.b_ptr)
+        gb = None
+        premasked = act and not pixel_norm and _masked_in(ctx.out_info)   # every consumer already applied my mask
+        if act and not premasked:
+            g, gb = _BiasActBwd.apply(g, signs, slope, want_db)
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = _Conv.apply(g, w, coef, True, False)
+            if _masked_in(ctx.in_info) and not ups:
+                gx = _Conv.apply(g, w, coef, True, False, None, ctx.in_info.bits, ctx.in_info.slope)
+            else:
+                gx = _Conv.apply(g, w, coef, True, False)
             if ups:
                 gx = _Down.apply(gx, 1.0)
-        if ctx.needs_input_grad[1]:
+        db_from_wgrad = want_db and gb is None
+        if _wants(ctx, 1, w.data_ptr()):
             k = tuple(w.shape[:3]) if w.dim() == 5 else (1, 1, 1)
-            gw = _Wgrad.apply(x, g, k, coef, ups).reshape(w.shape)
-        return gx, gw, (gb if want_db else None), None, None, None, None, None, None
+            gw, gb2 = _Wgrad.apply(x, g, k, coef, ups, db_from_wgrad)
+            gw = gw.reshape(w.shape)
+            if db_from_wgrad:
+                gb = gb2
+        elif db_from_wgrad:
+            _, gb = raw_bias_act_bwd(g, None, 0.0, want_dx=False, want_db=True)
+        return gx, gw, (gb if want_db else None), None, None, None, None, None, None, None, None
 
 
 class _BiasActBwd(torch.autograd.Function):
     """dx = where(y >= 0, dy, slope*dy) (networks/ops.py:177), db = sum_v dx.  Linear in dy: its own
-    backward is the same mask again (networks/ops.py:178)."""
+    backward is the same mask again (networks/ops.py:178).  `y` is the activation or its int32 sign words."""
 
     @staticmethod
     def forward(ctx, dy, y, slope, want_db):
@@ -286,13 +391,16 @@ class _BiasAct(torch.autograd.Function):
                                   _dt(x), _stream()), 'sg_bias_act_fwd')
         ctx.save_for_backward(y)
         ctx.act, ctx.slope, ctx.has_b = act, slope, b is not None
+        ctx.b_ptr = b.data_ptr() if b is not None else 0
         return y
 
     @staticmethod
     def backward(ctx, gy):
         (y,) = ctx.saved_tensors
-        want_db = ctx.has_b and ctx.needs_input_grad[1]
-        g, gb = _BiasActBwd.apply(gy, y if ctx.act else None, ctx.slope, want_db)
+        want_db = ctx.has_b and _wants(ctx, 1, ctx.b_ptr)
+        # y only supplies the (piecewise constant) mask: detached, or a double backward would come back through this
+        # node's own output with a materialised zero gradient and re-run the layer's whole backward for nothing
+        g, gb = _BiasActBwd.apply(gy, y.detach() if ctx.act else None, ctx.slope, want_db)
         return g, (gb if want_db else None), None, None
 
 
@@ -336,41 +444,51 @@ class _PixelNormBwd(torch.autograd.Function):
 
 
 class _Up(torch.autograd.Function):
-    """y = gain * nearest_x2(x) (upscale3d / avg_unpool3d, networks/ops.py:250-262,276-289)."""
+    """y = gain * nearest_x2(x) (upscale3d / avg_unpool3d, networks/ops.py:250-262,276-289), optionally times the
+    LeakyReLU-backward mask given by `mask_bits`, the sign words of a tensor shaped like y (the gradient of
+    downscale3d(leaky_relu(.)) in one pass)."""
 
     @staticmethod
-    def forward(ctx, x, gain):
+    def forward(ctx, x, gain, mask_bits=None, mask_slope=0.0):
         lib = _lib.load()
-        _req_cuda(x)
+        _req_cuda(x, mask_bits)
         x = ndhwc(x)
         n, c, d, h, w = _dims(x)
         y = _empty_like_shape(x, c, (2 * d, 2 * h, 2 * w))
-        check(lib.sg_upscale2x(_ptr(x), _ptr(y), n, d, h, w, c, float(gain), _dt(x), _stream()), 'sg_upscale2x')
-        ctx.gain = gain
+        _check_signs(mask_bits, 8 * n * d * h * w, c)
+        check(lib.sg_upscale2x_masked(_ptr(x), _ptr(y), _ptr(mask_bits), float(mask_slope), n, d, h, w, c, float(gain),
+                                      _dt(x), _stream()), 'sg_upscale2x_masked')
+        ctx.gain, ctx.mask_slope = gain, mask_slope
+        ctx.save_for_backward(mask_bits)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        return _Down.apply(gy, ctx.gain), None
+        (mask_bits,) = ctx.saved_tensors
+        if mask_bits is not None:
+            gy, _ = _BiasActBwd.apply(gy, mask_bits, ctx.mask_slope, False)
+        return _Down.apply(gy, ctx.gain), None, None, None
 
 
 class _Down(torch.autograd.Function):
     """y = gain * sum of each 2x2x2 block (gain 1/8: downscale3d, networks/ops.py:265-273,292-305)."""
 
     @staticmethod
-    def forward(ctx, x, gain):
+    def forward(ctx, x, gain, in_info=None):
         lib = _lib.load()
         _req_cuda(x)
         x = ndhwc(x)
         n, c, d, h, w = _dims(x)
         y = _empty_like_shape(x, c, (d // 2, h // 2, w // 2))
         check(lib.sg_downscale2x(_ptr(x), _ptr(y), n, d, h, w, c, float(gain), _dt(x), _stream()), 'sg_downscale2x')
-        ctx.gain = gain
+        ctx.gain, ctx.in_info = gain, in_info
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        return _Up.apply(gy, ctx.gain), None
+        if _masked_in(ctx.in_info):
+            return _Up.apply(gy, ctx.gain, ctx.in_info.bits, ctx.in_info.slope), None, None
+        return _Up.apply(gy, ctx.gain), None, None
 
 
 class _Axpby(torch.autograd.Function):
@@ -440,14 +558,14 @@ class _SumsqKeepW(torch.autograd.Function):
 # public functional API
 # ---------------------------------------------------------------------------------------------------
 def conv3d(x, w, coef=1.0, bias=None, act=False, slope=0.2, pixel_norm=False, eps=1e-8, upsample_in=False,
-           fuse=True):
+           fuse=True, out_info=None, in_info=None):
     """conv3d (+ optional fused nearest-x2 of the input, bias, LeakyReLU, pixel-norm)."""
     if bias is None and not act and not pixel_norm:
-        return _Conv.apply(x, w, coef, False, upsample_in)
+        return _Conv.apply(x, w, coef, False, upsample_in, in_info)
     cout = w.shape[-1]
     if fuse and (not pixel_norm or cout <= 128):
-        return _ConvBiasAct.apply(x, w, bias, coef, upsample_in, act, slope, pixel_norm, eps)
-    y = _Conv.apply(x, w, coef, False, upsample_in)
+        return _ConvBiasAct.apply(x, w, bias, coef, upsample_in, act, slope, pixel_norm, eps, out_info, in_info)
+    y = _Conv.apply(x, w, coef, False, upsample_in, in_info)
     y = _BiasAct.apply(y, bias, act, slope)
     return _PixelNorm.apply(y, eps) if pixel_norm else y
 
@@ -464,8 +582,8 @@ def upscale2x(x, gain=1.0):
     return _Up.apply(x, gain)
 
 
-def downscale2x(x, gain=0.125):
-    return _Down.apply(x, gain)
+def downscale2x(x, gain=0.125, in_info=None):
+    return _Down.apply(x, gain, in_info)
 
 
 def lerp(a, b, wa, wb):

@@ -6,7 +6,7 @@ import torch
 import torch.nn.functional as TF
 
 from .. import functional as F
-from ..varstore import compute_dtype
+from ..varstore import compute_dtype, current_store
 
 
 class RandomSource:
@@ -91,7 +91,9 @@ def _gradient_slopes_sq(discriminator, interpolates, alpha, phase, latent_dim, a
     interpolates = interpolates.detach().requires_grad_(True)
     d_int = discriminator(interpolates, alpha, phase, latent_dim=latent_dim, is_reuse=True, activation=activation,
                           kernel_spec=kernel_spec, filter_spec=filter_spec, param=leakiness)
-    (gradients,) = torch.autograd.grad(d_int, interpolates, grad_outputs=torch.ones_like(d_int), create_graph=True)
+    with F.skip_param_grads(p for _, p in current_store().trainable('discriminator/')):   # only d/dx is asked for
+        (gradients,) = torch.autograd.grad(d_int, interpolates, grad_outputs=torch.ones_like(d_int),
+                                           create_graph=True)
     ss = F.sumsq_keep_w(gradients)          # [N, W] f32
     return ss if keep_w else ss.sum(dim=1)
 

@@ -43,6 +43,8 @@ class _LazyConv:
         self.pn = False
         self.eps = 1e-8
         self.stage = 0   # 0 conv, 1 +bias, 2 +act, 3 +pixel_norm
+        self.in_info = None    # ActInfo of the LeakyReLU output this conv consumes (fused mask in my data gradient)
+        self.act_info = None   # ActInfo of MY output when it ends in a LeakyReLU (and no pixel-norm)
         self._v = None
 
     @property
@@ -53,13 +55,28 @@ class _LazyConv:
 
     def value(self):
         if self._v is None:
+            out_info = self.act_info if (self.act and not self.pn) else None
             self._v = F.conv3d(self.x, self.w, self.coef, bias=self.bias, act=self.act, slope=self.slope,
-                               pixel_norm=self.pn, eps=self.eps, upsample_in=self.ups)
+                               pixel_norm=self.pn, eps=self.eps, upsample_in=self.ups, out_info=out_info,
+                               in_info=self.in_info)
         return self._v
 
 
+def _consume(x, premask=False):
+    """Materialises a handle for one consumer and returns (tensor, ActInfo-or-None).  `premask` says that this
+    consumer applies the producer's LeakyReLU-backward mask inside its own backward kernel (F.ActInfo)."""
+    if isinstance(x, _LazyConv):
+        info = x.act_info if (x.act and not x.pn) else None
+        if info is not None:
+            info.consume(premask)
+        return x.value(), (info if premask else None)
+    if isinstance(x, _LazyUp):
+        return x.value(), None
+    return x, None
+
+
 def _val(x):
-    return x.value() if isinstance(x, (_LazyUp, _LazyConv)) else x
+    return _consume(x, False)[0]
 
 
 # ---- reference functions -----------------------------------------------------------------------------
@@ -187,15 +204,24 @@ def dense(x, fmaps, activation, lrmul=1, param=None):
 def conv3d(x, fmaps, kernel, activation, param=None, lrmul=1):
     """networks/ops.py:147-150."""
     ups = isinstance(x, _LazyUp) and x._v is None
-    xin = x.x if ups else _val(x)
-    w = get_weight([*kernel, x.shape[1], fmaps], activation, param=param, lrmul=lrmul)
-    return _LazyConv(xin.to(compute_dtype()), w.var, w.coef, ups)
+    cin = x.shape[1]
+    if ups:
+        xin, in_info = x.x, None
+    else:
+        xin, in_info = _consume(x, premask=True)
+    w = get_weight([*kernel, cin, fmaps], activation, param=param, lrmul=lrmul)
+    if xin.dtype != compute_dtype():
+        xin, in_info = xin.to(compute_dtype()), None
+    lz = _LazyConv(xin, w.var, w.coef, ups)
+    lz.in_info = in_info
+    return lz
 
 
 def leaky_relu(x, alpha_lr=0.2):
     """networks/ops.py:167-182 (mask taken from the output, subgradient 1 at 0)."""
     if isinstance(x, _LazyConv) and x.stage <= 1 and x._v is None:
         x.act, x.slope, x.stage = True, float(alpha_lr), 2
+        x.act_info = F.ActInfo(alpha_lr)
         return x
     return F.bias_act(_val(x), None, True, float(alpha_lr))
 
@@ -254,12 +280,13 @@ def avg_unpool3d(x, factor=2, gain=1):
 
 def avg_pool3d(x, factor=2, gain=1):
     """networks/ops.py:265-273."""
-    x = _val(x)
     if factor == 1:
+        x = _val(x)
         return x if gain == 1 else F.lerp(x, None, float(gain), 0.0)
     if factor != 2:
         raise NotImplementedError('only factor 2 is used by the pgan path')
-    return F.downscale2x(x, float(gain) / 8.0)
+    x, in_info = _consume(x, premask=True)     # its gradient (an up-scale) can carry the producer's LeakyReLU mask
+    return F.downscale2x(x, float(gain) / 8.0, in_info)
 
 
 def upscale3d(x, factor=2):

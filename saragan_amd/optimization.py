@@ -242,7 +242,9 @@ class StepGraph:
         dist = tr['optimizer'].distributed
         if dist is not None:
             dist.begin(flat['grad'], ranges, params)
-        torch.autograd.backward(loss, inputs=params, retain_graph=retain)
+        other = 'discriminator/' if tr['net'] == 'generator' else 'generator/'
+        with F.skip_param_grads(p for _, p in self.store.trainable(other)):   # e.g. D's weights under the G loss
+            torch.autograd.backward(loss, inputs=params, retain_graph=retain)
         return dict(prefix=prefix, flat=flat, names=names, ranges=ranges, dist=dist)
 
     def _finish(self, tid, info, out, apply):

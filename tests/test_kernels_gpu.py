@@ -125,6 +125,160 @@ def test_conv3d_fused_epilogue_and_upsample(dtype):
                                        err_msg=f'grad {nm} fuse={fuse}')
 
 
+def _ref_sign_words(t):
+    """CPU restatement of the sign-word layout (include/saragan_hip.h): int32 [n,d,h,w,ceil(c/32)]."""
+    t = t.permute(0, 2, 3, 4, 1).contiguous()
+    c = t.shape[-1]
+    nw = (c + 31) // 32
+    neg = torch.zeros((*t.shape[:-1], nw * 32), dtype=torch.int64)
+    neg[..., :c] = (t < 0).to(torch.int64)
+    words = (neg.reshape(*t.shape[:-1], nw, 32) << torch.arange(32)).sum(-1)
+    return torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
+
+
+MASK_CASES = [
+    (2, 16, 32, (4, 8, 8), (3, 3, 3)),       # generic kernels
+    (2, 24, 40, (3, 5, 7), (3, 3, 3)),       # padded-row fallback kernel, ragged
+    (2, 16, 1, (4, 8, 8), (1, 1, 1)),        # point-wise weight gradient with the ones channel
+    (2, 1, 16, (4, 8, 8), (1, 1, 1)),
+    (2, 32, 32, (16, 64, 64), (3, 3, 3)),    # persistent weight-stationary kernel; sliding-halo wgrad with the ones tap
+    (2, 64, 32, (8, 64, 64), (3, 3, 3)),     # streamed ping-pong kernel, one cout tile; 2 cin tiles in wgrad
+    (2, 64, 64, (8, 32, 64), (3, 3, 3)),     # streamed ping-pong kernel, two cout tiles
+]
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('case', MASK_CASES)
+def test_conv_mask_epilogue_and_wgrad_bias(case, dtype):
+    """sg_conv_epilogue.mask_bits / sign_out (LeakyReLU backward fused into the data-gradient conv through sign
+    words) and sg_conv3d_wgrad_bias (bias gradient from the weight-gradient kernel)."""
+    from saragan_amd import functional as F
+    n, cin, cout, sp, k = case
+    x = rnd((n, cin, *sp), 11, dtype)
+    w = rnd((*k, cin, cout), 12, dtype)
+    m = rnd((n, cout, *sp), 13, dtype)
+    m[:, :, 0, 0, :3] = 0.0                      # a >= 0 counts as the positive side (where(a >= 0, ...))
+    coef = O.runtime_coef(w.shape, 'leaky_relu', 0.2)
+    wq = (w * coef).to(dtype).double() / coef if dtype == torch.bfloat16 else w
+    ref = O.conv3d(x, wq, 'leaky_relu', 0.2) * torch.where(m >= 0, 1.0, 0.2)
+    mbits = F.sign_words(cl(m, dtype))
+    ref_words = _ref_sign_words(m)
+    assert torch.equal(mbits.cpu(), ref_words), 'sg_sign_words'
+    got, _, _ = F.raw_conv(cl(x, dtype), w.float().to(dev()), coef, False, False, mask_bits=mbits, mask_slope=0.2)
+    close(got, ref, dtype, 'masked fwd')
+    # sign words written by the epilogue itself (bias + LeakyReLU layer): must equal the signs of the stored output
+    b = rnd((cout,), 16, torch.float32) * 0.5
+    yb, _, sg = F.raw_conv(cl(x, dtype), w.float().to(dev()), coef, False, False, bias=b.float().to(dev()), act=True,
+                           slope=0.2, want_signs=True)
+    pre = O.apply_bias(O.conv3d(x, wq, 'leaky_relu', 0.2), b.double())
+    sure = (pre.abs() > 1e-3 * pre.abs().max())                 # away from zero the sign is not a rounding matter
+    diff = (_ref_sign_words(yb.double().cpu()) ^ sg.cpu())
+    assert int(diff.ne(0).sum()) == 0, 'sign_out differs from the signs of the stored activation'
+    assert torch.equal((yb.double().cpu() < 0) & sure, (pre < 0) & sure)
+    # flipped (data-gradient) weights with the mask, as the backward pass uses it
+    gy = rnd((n, cout, *sp), 14, dtype)
+    mx = rnd((n, cin, *sp), 15, dtype)
+    xr = x.clone().requires_grad_(True)
+    (gxr,) = torch.autograd.grad(O.conv3d(xr, wq, 'leaky_relu', 0.2), [xr], gy)
+    got, _, _ = F.raw_conv(cl(gy, dtype), w.float().to(dev()), coef, True, False, mask_bits=F.sign_words(cl(mx, dtype)),
+                           mask_slope=0.2)
+    close(got, gxr * torch.where(mx >= 0, 1.0, 0.2), dtype, 'masked dgrad')
+    # weight + bias gradient in one call
+    dw, db = F.raw_wgrad(cl(x, dtype), cl(gy, dtype), k, coef, False, want_db=True)
+    wr = wq.clone().requires_grad_(True)
+    (gwr,) = torch.autograd.grad(O.conv3d(x, wr, 'leaky_relu', 0.2), [wr], gy)
+    rt, at = (1e-4, 1e-5) if dtype == torch.float32 else (2e-3, 2e-3)
+    np.testing.assert_allclose(dw.double().cpu().numpy(), gwr.numpy(), rtol=rt, atol=at * gwr.abs().max().item())
+    dbr = gy.sum((0, 2, 3, 4)).numpy()
+    np.testing.assert_allclose(db.double().cpu().numpy(), dbr, rtol=rt, atol=at * max(1.0, np.abs(dbr).max()))
+
+
+@pytest.mark.parametrize('dtype', DT)
+def test_upscale2x_masked(dtype):
+    from saragan_amd import functional as F
+    x = rnd((2, 16, 3, 4, 5), 21, dtype)
+    m = rnd((2, 16, 6, 8, 10), 22, dtype)
+    ref = 0.125 * O.upscale3d(x) * torch.where(m >= 0, 1.0, 0.2)
+    got = F._Up.apply(cl(x, dtype), 0.125, F.sign_words(cl(m, dtype)), 0.2)
+    close(got, ref, dtype)
+    # the stand-alone LeakyReLU backward with sign words instead of the activation
+    g = rnd((2, 16, 6, 8, 10), 23, dtype)
+    dx, db = F.raw_bias_act_bwd(cl(g, dtype), F.sign_words(cl(m, dtype)), 0.2, True, True)
+    refdx = g * torch.where(m >= 0, 1.0, 0.2)
+    close(dx, refdx, dtype)
+    np.testing.assert_allclose(db.double().cpu().numpy(), refdx.sum((0, 2, 3, 4)).numpy(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('big', [False, True])
+def test_fused_mask_chain_first_and_second_order(big, dtype):
+    """Discriminator-block shaped chain conv-bias-lrelu -> conv-bias-lrelu -> downscale built through the ops layer,
+    where the LeakyReLU backward of each layer runs inside its consumer's backward kernel: first-order gradients and
+    the gradient-penalty style second-order gradients against the oracle."""
+    from saragan_amd import varstore
+    from saragan_amd.networks import ops
+    n, c0, c1, c2, sp = (2, 32, 32, 64, (8, 64, 64)) if big else (2, 8, 16, 16, (2, 4, 8))
+    x = rnd((n, c0, *sp), 31, dtype) 
+    w1 = rnd((3, 3, 3, c0, c1), 32, dtype)
+    w2 = rnd((3, 3, 3, c1, c2), 33, dtype)
+    b1 = rnd((c1,), 34, torch.float32) * 0.3
+    b2 = rnd((c2,), 35, torch.float32) * 0.3
+
+    def stored(h):   # the kernels store activations in `dtype`: same values (hence the same LeakyReLU masks) here
+        return h + (h.detach().to(dtype).double() - h.detach())
+
+    def ref_chain(xr, w1r, w2r, b1r, b2r):
+        h = stored(O.act(O.apply_bias(O.conv3d(xr, w1r, 'leaky_relu', 0.2), b1r), 'leaky_relu', 0.2))
+        h = stored(O.act(O.apply_bias(O.conv3d(h, w2r, 'leaky_relu', 0.2), b2r), 'leaky_relu', 0.2))
+        return O.downscale3d(h)
+
+    c1f = O.runtime_coef(w1.shape, 'leaky_relu', 0.2)
+    c2f = O.runtime_coef(w2.shape, 'leaky_relu', 0.2)
+    q = (lambda w, c: (w * c).to(dtype).double() / c) if dtype == torch.bfloat16 else (lambda w, c: w)
+    rv = [t.clone().requires_grad_(True) for t in (x, q(w1, c1f), q(w2, c2f), b1.double(), b2.double())]
+    yr = ref_chain(*rv)
+    gy = rnd(tuple(yr.shape), 36, dtype)
+    g1r = torch.autograd.grad(yr, rv, gy, create_graph=True)
+    pen_r = (g1r[0] ** 2).sum()
+    g2r = torch.autograd.grad(pen_r, rv[1:], allow_unused=True)
+
+    store = varstore.VariableStore(dev())
+    old_dt = varstore.compute_dtype()
+    varstore.set_compute_dtype(dtype)
+
+    def layer(name, h, fmaps):
+        with varstore.variable_scope(name):
+            return ops.act(ops.apply_bias(ops.conv3d(h, fmaps, (3, 3, 3), 'leaky_relu', param=0.2)), 'leaky_relu', 0.2)
+
+    try:
+        with varstore.use_store(store):
+            xg = cl(x, dtype).requires_grad_(True)
+            layer('l2', layer('l1', xg, c1), c2)         # creates the variables
+            store.load_state_dict({'l1/weight': w1, 'l2/weight': w2, 'l1/bias': b1, 'l2/bias': b2}, strict=True)
+            yg = ops.materialize(ops.downscale3d(layer('l2', layer('l1', xg, c1), c2)))
+        pv = store.vars
+        gv = [xg, pv['l1/weight'], pv['l2/weight'], pv['l1/bias'], pv['l2/bias']]
+        close(yg, yr, dtype, 'chain fwd')
+        g1 = torch.autograd.grad(yg, gv, cl(gy, dtype), create_graph=True)
+        pen = (g1[0].float() ** 2).sum()
+        g2 = torch.autograd.grad(pen, gv[1:], allow_unused=True)
+    finally:
+        varstore.set_compute_dtype(old_dt)
+    rt, at = (2e-4, 2e-5) if dtype == torch.float32 else (3e-2, 3e-2)
+    for a, r, nm in zip(g1, g1r, 'x w1 w2 b1 b2'.split()):
+        ref = r.detach().numpy()
+        np.testing.assert_allclose(a.detach().double().cpu().numpy(), ref, rtol=rt, atol=at * np.abs(ref).max(),
+                                   err_msg=f'first-order {nm}')
+    for a, r, nm in zip(g2, g2r, 'w1 w2 b1 b2'.split()):
+        if r is None or a is None:   # the penalty is piecewise constant in the biases: "unused" or exactly zero
+            for t in (a, r):
+                assert t is None or float(t.abs().max()) == 0.0, nm
+            continue
+        ref = r.detach().numpy()
+        np.testing.assert_allclose(a.detach().double().cpu().numpy(), ref, rtol=rt, atol=at * np.abs(ref).max(),
+                                   err_msg=f'second-order {nm}')
+
+
 @pytest.mark.parametrize('dtype', DT)
 def test_dense(dtype):
     from saragan_amd import functional as F

@@ -31,6 +31,8 @@ def main():
     ap.add_argument('--which', default='fwd,wgrad')
     ap.add_argument('--iters', type=int, default=10)
     ap.add_argument('--shapes', default='')
+    ap.add_argument('--mask', action='store_true', help='fwd: data-gradient style epilogue (no bias/act, mask_bits)')
+    ap.add_argument('--signs', action='store_true', help='fwd: also write the sign words of the output')
     a = ap.parse_args()
     lib = _lib.load()
     dt = _lib.SG_BF16 if a.dtype == 'bf16' else _lib.SG_F32
@@ -49,7 +51,13 @@ def main():
         _lib.check(lib.sg_conv3d_pack_weights(wt.data_ptr(), 0.05, 0, wp.data_ptr(), C.byref(shp), dt, st))
         y = torch.empty(n, d, h, w, cout, device=dev, dtype=tdt)
         bias = torch.zeros(cout, device=dev)
-        ep = ConvEpilogue(bias.data_ptr(), 1, 0.2, 0, 1e-8, None)
+        nw = (cout + 31) // 32
+        mbits = torch.randint(-2**31, 2**31 - 1, (n, d, h, w, nw), device=dev, dtype=torch.int32)
+        sout = torch.empty((n, d, h, w, nw), device=dev, dtype=torch.int32)
+        if a.mask:
+            ep = ConvEpilogue(None, 0, 0.2, 0, 1e-8, None, mbits.data_ptr(), 0.2, None)
+        else:
+            ep = ConvEpilogue(bias.data_ptr(), 1, 0.2, 0, 1e-8, None, None, 0.0, sout.data_ptr() if a.signs else None)
         flops = 2.0 * n * d * h * w * cin * cout * k[0] * k[1] * k[2]
         res = {}
         if 'fwd' in a.which:
@@ -63,6 +71,14 @@ def main():
             def g():
                 _lib.check(lib.sg_conv3d_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), 1.0, ws.data_ptr(), wsb, C.byref(shp), dt, st))
             res['wgrad'] = timeit(g, a.iters)
+        if 'wgb' in a.which:
+            wsb = lib.sg_conv3d_wgrad_workspace(C.byref(shp), dt)
+            ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+            dw = torch.empty(*k, cin, cout, device=dev)
+            dbias = torch.empty(cout, device=dev)
+            def gb():
+                _lib.check(lib.sg_conv3d_wgrad_bias(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), dbias.data_ptr(), 1.0, ws.data_ptr(), wsb, C.byref(shp), dt, st))
+            res['wgb'] = timeit(gb, a.iters)
         line = f'{si}: {d}x{h}x{w} {cin:4d}->{cout:4d} k{k} n={n}'
         for kk, ms in res.items():
             line += f' | {kk} {ms:8.3f} ms {flops / ms / 1e9:8.1f} TF/s'

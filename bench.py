@@ -147,6 +147,26 @@ def cpu_baseline(args, cfg, budget_s):
                        f'FLOP ratio {ratio:.1f}')
 
 
+def pmc_traffic(entry, dtype):
+    """Bytes per launch that crossed the L2's memory side for this (kind, shape), from the committed rocprofv3 counter
+    passes (profiles/r01_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_probe.py + tools/pmc_summary.py; the
+    counters cannot be read from inside this process).  Mean over the epilogue variants measured; None when this
+    shape / batch / dtype was not part of the counter run."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
+    if not os.path.exists(path):
+        return None
+    tab = json.load(open(path))
+    if tab.get('dtype') != dtype:
+        return None
+    s = entry.shape
+    key = dict(n=s.n, d=s.d, h=s.h, w=s.w, cin=s.cin, cout=s.cout, k=[s.kd, s.kh, s.kw])
+    kind = 'fwd' if entry.kind == 0 else 'wgrad'
+    hits = [e['traffic_bytes'] for e in tab['entries'] if e['kind'] == kind and e['shape'] == key]
+    if not hits or s.upsample_in:
+        return None
+    return round(sum(hits) / len(hits))
+
+
 def main():
     args = parse()
     from saragan_amd import _lib, parallel
@@ -217,7 +237,7 @@ def main():
         ach = best.flops_per_launch / (avg_ms * 1e-3) / 1e12
         s = best.shape
         roof = dict(bound='mfma', achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
-                    traffic=None,
+                    traffic=pmc_traffic(best, args.dtype),
                     kernel=('conv_fwd_kernel' if best.kind == 0 else 'conv_wgrad_kernel'),
                     shape=dict(n=s.n, d=s.d, h=s.h, w=s.w, cin=s.cin, cout=s.cout, k=[s.kd, s.kh, s.kw],
                                upsample_in=s.upsample_in),

@@ -137,6 +137,47 @@ __global__ void bias_act_bwd_scalar_kernel(const T* __restrict__ dy, const T* __
   }
 }
 
+// c <= 8 channels that do not form 16-byte pieces (to_rgb / from_rgb sides, c = 1..7): one voxel per thread per
+// step, channel sums in registers, one LDS tree per block.
+template <typename T>
+__global__ __launch_bounds__(256) void bias_act_bwd_small_kernel(const T* __restrict__ dy, const T* __restrict__ y,
+                                                                 T* __restrict__ dx, float* __restrict__ part,
+                                                                 int64_t nvox, int c, float slope,
+                                                                 const uint32_t* __restrict__ words) {
+  __shared__ float red[4][8];
+  float s[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s[e] = 0.f;
+  for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nvox; v += (int64_t)gridDim.x * 256) {
+    const uint32_t sw = words ? words[v] : 0u;     // c <= 8 < 32: one word per voxel
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (e < c) {
+        float g = sg_traits<T>::to_f(dy[v * c + e]);
+        if (y) g = sg_traits<T>::to_f(y[v * c + e]) >= 0.f ? g : g * slope;
+        else if ((sw >> e) & 1u) g *= slope;
+        if (dx) dx[v * c + e] = sg_traits<T>::from_f(g);
+        s[e] += g;
+      }
+    }
+  }
+  if (part) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s[e] += __shfl_xor(s[e], o);
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wave][e] = s[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < c) part[(int64_t)blockIdx.x * c + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] +
+                                                                      red[2][threadIdx.x] + red[3][threadIdx.x];
+  }
+}
+
 template <typename T>
 __global__ void sign_words_kernel(const T* __restrict__ t, uint32_t* __restrict__ words, int64_t nvox, int c) {
   const int nw = (c + 31) >> 5;
@@ -508,6 +549,11 @@ static int bias_act_bwd_launch(const void* dy, const void* y, const uint32_t* wo
     const int rows = 256 / P;
     blocks = grid_for(nvox, rows, kBwdBlocks);
 #define L(T) hipLaunchKernelGGL((bias_act_bwd_vec_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)dy, (const T*)y, (T*)dx, part, nvox, c, slope, words)
+    SG_DISPATCH(dt, L(bf16_t), L(float));
+#undef L
+  } else if (c <= 8) {
+    blocks = grid_for(nvox, 256, kBwdBlocks);
+#define L(T) hipLaunchKernelGGL((bias_act_bwd_small_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)dy, (const T*)y, (T*)dx, part, nvox, c, slope, words)
     SG_DISPATCH(dt, L(bf16_t), L(float));
 #undef L
   } else {

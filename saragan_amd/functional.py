@@ -10,6 +10,7 @@ networks/loss.py:133-140 differentiates through D's data gradient) work.
 import contextlib
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -201,6 +202,7 @@ def raw_bias_act_bwd(dy, y, slope, want_dx=True, want_db=False):
 # ---------------------------------------------------------------------------------------------------
 # autograd Functions
 # ---------------------------------------------------------------------------------------------------
+_NO_SIGN_WORDS = bool(int(os.environ.get('SARAGAN_NO_SIGN_WORDS', '0')))   # diagnostic: activation-based masks only
 _SKIP = {'ptrs': frozenset()}
 
 
@@ -315,10 +317,10 @@ class _ConvBiasAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, coef, ups, act, slope, pixel_norm, eps, out_info=None, in_info=None):
         y, scale, signs = raw_conv(x, w, coef, False, ups, bias=b, act=act, slope=slope, pixel_norm=pixel_norm,
-                                   eps=eps, want_scale=True, want_signs=act)
+                                   eps=eps, want_scale=True, want_signs=act and not _NO_SIGN_WORDS)
         if out_info is not None:
             out_info.bits = signs
-        ctx.save_for_backward(x, w, y if pixel_norm else None, scale, signs)
+        ctx.save_for_backward(x, w, y if (pixel_norm or (act and signs is None)) else None, scale, signs)
         ctx.cfg = (coef, ups, act, slope, pixel_norm)
         ctx.has_b = b is not None
         ctx.b_ptr = b.data_ptr() if b is not None else 0
@@ -336,7 +338,7 @@ class _ConvBiasAct(torch.autograd.Function):
         gb = None
         premasked = act and not pixel_norm and _masked_in(ctx.out_info)   # every consumer already applied my mask
         if act and not premasked:
-            g, gb = _BiasActBwd.apply(g, signs, slope, want_db)
+            g, gb = _BiasActBwd.apply(g, signs if signs is not None else y.detach(), slope, want_db)
         gx = gw = None
         if ctx.needs_input_grad[0]:
             if _masked_in(ctx.in_info) and not ups:

@@ -244,7 +244,9 @@ def main():
                     launches=int(best.launches), avg_ms=round(avg_ms, 4),
                     flops_per_launch=best.flops_per_launch)
     fg, fd = conv_flops_per_volume(cfg['ks'], cfg['fs'], args.phase, cfg['base_shape'], args.latent)
-    step_gf = (3 * fg + 12 * fd) / 1e9
+    # executed conv work: G fwd+dgrad+wgrad; D: 3 forwards, 3 (wgan: the G loss reuses the D-loss data gradient)
+    # or 4 data-gradient passes, 2 weight-gradient passes, 2 convs of the GP double backward + its weight gradient
+    step_gf = (3 * fg + (11 if args.loss == 'wgan' else 12) * fd) / 1e9
     total_conv_ms = sum(ents[i].total_ms for i in range(n_ent.value))
     out = dict(metric='3D volumes/sec/node (G+D step) at 128x128x32', value=round(value, 3), unit='volumes/s',
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),

@@ -46,6 +46,26 @@ class InjectedRandom(RandomSource):
 
 
 _RANDOM = {'src': None}
+_LINK = {'on': False}
+
+
+class linear_generator_link:
+    """Context for callers that run BOTH backward passes of forward_simultaneous themselves (optimization.StepGraph).
+    With the wgan loss d gen_loss / d D(fake) = -1/N = -(d disc_loss / d D(fake)) element for element, and the
+    discriminator's data-gradient chain is linear in its upstream gradient, so the gradient of gen_loss at the
+    discriminator's INPUT is exactly minus what the disc_loss backward delivers there.  Inside this context the fake
+    batch enters D through a detached leaf and gen_loss carries `.sg_link = (gen_sample_noisy, leaf, -1.0)`: the
+    caller back-propagates disc_loss to `leaf` along with D's variables and then starts the generator's backward at
+    gen_sample_noisy with factor * leaf.grad — one whole data-gradient pass through D less per step
+    (optimization.py:128-163 computes the two tf.gradients separately).  Only exact for a uniform factor (wgan);
+    the logistic loss keeps the general path."""
+
+    def __enter__(self):
+        self.prev = _LINK['on']
+        _LINK['on'] = True
+
+    def __exit__(self, *a):
+        _LINK['on'] = self.prev
 
 
 def set_random_source(src):
@@ -148,7 +168,9 @@ def forward_simultaneous(generator, discriminator, real_image_input, latent_dim,
     # The reference evaluates D(stop_gradient(fake)) for the D loss and D(fake) for the G loss (loss.py:126-128,
     # :143-144): the same forward values.  ONE pass serves both here: the D-loss gradient is only taken w.r.t. D's
     # variables (the edge into G is never followed), the G-loss gradient only w.r.t. G's (no D weight gradients).
-    disc_fake_g = discriminator(gen_sample_noisy, alpha, phase, **net).float()
+    link = _LINK['on'] and loss_fn == 'wgan' and gen_sample_noisy.requires_grad
+    fake_in = gen_sample_noisy.detach().requires_grad_(True) if link else gen_sample_noisy
+    disc_fake_g = discriminator(fake_in, alpha, phase, **net).float()
     disc_fake_d = disc_fake_g
     disc_real = discriminator(real_image_input, alpha, phase, is_reuse=True, **net).float()
     gamma = rng.gamma(real_image_input.shape[0], real_image_input.device).to(real_image_input.dtype)
@@ -162,6 +184,8 @@ def forward_simultaneous(generator, discriminator, real_image_input, latent_dim,
         drift_loss = 1e-3 * disc_real ** 2
         disc_loss = torch.mean(disc_loss + gp_loss + drift_loss)
         gen_loss = -torch.mean(disc_fake_g)
+        if link:
+            gen_loss.sg_link = (gen_sample_noisy, fake_in, -1.0)
     elif loss_fn == 'logistic':
         gradient_penalty = torch.mean(slopes ** 2)
         gp_loss = gp_weight * gradient_penalty

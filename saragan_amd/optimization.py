@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import functional as F
-from .networks.loss import forward_discriminator, forward_generator, forward_simultaneous
+from .networks.loss import forward_discriminator, forward_generator, forward_simultaneous, linear_generator_link
 from .networks.ops import Op, ScalarVariable
 from .networks.pgan.variables import pgan_variable_shapes
 from .varstore import current_store, use_store
@@ -190,9 +190,17 @@ class StepGraph:
             net_args = (c['latent_dim'], alpha, c['phase'], c['base_shape'], c['kernel_spec'], c['filter_spec'],
                         c['activation'], c['leakiness'], c['loss_fn'])
             if c['optim_strategy'] == 'simultaneous':
-                gen_loss, disc_loss, gp_loss, gen_sample = forward_simultaneous(
-                    c['generator'], c['discriminator'], real, *net_args, c['gp_weight'], c['noise_stddev'])
+                nets = {self.trains[t]['net'] for t in train_ids}
+                if nets >= {'generator', 'discriminator'}:
+                    with linear_generator_link():   # wgan: G's gradient through D comes out of D's own backward
+                        gen_loss, disc_loss, gp_loss, gen_sample = forward_simultaneous(
+                            c['generator'], c['discriminator'], real, *net_args, c['gp_weight'], c['noise_stddev'])
+                else:
+                    gen_loss, disc_loss, gp_loss, gen_sample = forward_simultaneous(
+                        c['generator'], c['discriminator'], real, *net_args, c['gp_weight'], c['noise_stddev'])
                 out.update(gen_loss=gen_loss, disc_loss=disc_loss, gp_loss=gp_loss, gen_sample=gen_sample)
+                if hasattr(gen_loss, 'sg_link'):    # the discriminator's backward must run first: it feeds G's
+                    train_ids = sorted(train_ids, key=lambda t: self.trains[t]['net'] != 'discriminator')
                 pend = []
                 for j, tid in enumerate(train_ids):   # both gradients at the pre-step weights (optimization.py:128-163)
                     pend.append((tid, self._backward(tid, out, retain=j + 1 < len(train_ids))))
@@ -243,8 +251,18 @@ class StepGraph:
         if dist is not None:
             dist.begin(flat['grad'], ranges, params)
         other = 'discriminator/' if tr['net'] == 'generator' else 'generator/'
+        link = getattr(out['gen_loss'], 'sg_link', None) if 'gen_loss' in out else None
         with F.skip_param_grads(p for _, p in self.store.trainable(other)):   # e.g. D's weights under the G loss
-            torch.autograd.backward(loss, inputs=params, retain_graph=retain)
+            if link is None:
+                torch.autograd.backward(loss, inputs=params, retain_graph=retain)
+            elif tr['net'] == 'discriminator':   # also deliver d disc_loss / d fake for the generator's backward
+                link[1].grad = None
+                torch.autograd.backward(loss, inputs=params + [link[1]], retain_graph=retain)
+            else:
+                start, leaf, factor = link
+                if leaf.grad is None:
+                    raise RuntimeError('linked generator backward before the discriminator backward')
+                torch.autograd.backward(start, grad_tensors=leaf.grad * factor, inputs=params, retain_graph=retain)
         return dict(prefix=prefix, flat=flat, names=names, ranges=ranges, dist=dist)
 
     def _finish(self, tid, info, out, apply):

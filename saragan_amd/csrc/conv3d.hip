@@ -146,6 +146,28 @@ __device__ __forceinline__ void sg_apply_sign_word(f32x16& v, uint32_t word, int
   }
 }
 
+// ---- 16 contiguous bytes per lane for the bf16 store of a 32-channel tile row.  After the MFMA lane (r, hh) holds
+// channels 8*qd + 4*hh + e; v_permlane32_swap exchanges the qd-odd part of the lower half-wave with the qd-even part
+// of the upper one, after which lane hh = 0 holds channels 16j + 0..7 and hh = 1 channels 16j + 8..15: two
+// dwordx4 stores per M tile instead of four dwordx2 (the off-phase is bound by vector-memory instructions).
+__device__ __forceinline__ uint32_t sg_pack_bf16(float lo, float hi) {
+  bf16_t t[2] = {sg_traits<bf16_t>::from_f(lo), sg_traits<bf16_t>::from_f(hi)};
+  return *reinterpret_cast<uint32_t*>(t);
+}
+
+__device__ __forceinline__ void sg_store_tile_row_bf16(bf16_t* row32, const f32x16& v, int hh, bool ok) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const uint32_t a0 = sg_pack_bf16(v[8 * j + 0], v[8 * j + 1]), a1 = sg_pack_bf16(v[8 * j + 2], v[8 * j + 3]);
+    const uint32_t b0 = sg_pack_bf16(v[8 * j + 4], v[8 * j + 5]), b1 = sg_pack_bf16(v[8 * j + 6], v[8 * j + 7]);
+    const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+    u32x4 out;
+    out[0] = s0[0]; out[1] = s1[0]; out[2] = s0[1]; out[3] = s1[1];
+    if (ok) *reinterpret_cast<u32x4*>(row32 + 16 * j + 8 * hh) = out;
+  }
+}
+
 // ---- epilogue shared by both forward kernels: lane owns voxel r of each M tile and output channels
 // (i&3) + 8*(i>>2) + 4*hh of each N tile: bias, LeakyReLU and pixel-norm are lane-local (+1 shuffle).
 template <typename T, int MTW, int NTB>
@@ -1001,6 +1023,383 @@ static int launch_fwd3r(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
 
 
 // ------------------------------------------------------------------------------------------------------
+// forward, v3s: v3r with a SLIDING halo (3x3x3 taps, Cin <= one channel group, tile fixed at 2 x 4 x 32 voxels).
+// In-kernel stamps of v3r show its off-phase (13 LDS-DMA pieces per wave ~3.3-5k cycles + epilogue 2.5k) longer
+// than the 4.5k-cycle MFMA phase: the MFMA group idles 2-4k cycles per tile.  Here a wave group walks a column of
+// tiles along D and keeps the halo as a ring of four D planes (slot = plane & 3): a step fetches only the TWO new
+// planes (6.5 pieces per wave).  Wave w owns H row w of the tile and its two M tiles are the tile's two D planes,
+// so the ring slot of every fragment read, (kd + mt + ROT) & 3 with ROT = 3 (even step) / 1 (odd step), is a
+// compile-time ds_read offset and a lane needs 9*GC halo addresses instead of 27*2.
+// ------------------------------------------------------------------------------------------------------
+template <typename T, int GC, int ROT, int RING>
+struct sg_unrolled_ks {
+  static constexpr int NS = 27 * GC, PF = RING - 1, RPS = 3;
+  static constexpr int PB = (GC == 1 ? 224 : 208) * GC * 32;   // bytes per plane slot: 204 live rows padded to whole 1-KiB pieces
+  template <int ST>
+  static __device__ __forceinline__ void load(u32x4 (&wfr)[RING], u32x4 (&xfr)[RING][2], const int (&xa)[9][GC],
+                                              int wl_off) {
+    constexpr int SL = ST % RING, tap = ST / GC, gi = ST % GC, kd = tap / 9, khw = tap % 9;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wfr[SL]) : "v"(wl_off), "n"(ST << 10));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xfr[SL][0]) : "v"(xa[khw][gi]), "n"(((kd + 0 + ROT) & 3) * PB));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xfr[SL][1]) : "v"(xa[khw][gi]), "n"(((kd + 1 + ROT) & 3) * PB));
+  }
+  template <int ST>
+  static __device__ __forceinline__ void step(f32x16 (&acc)[2], u32x4 (&wfr)[RING], u32x4 (&xfr)[RING][2],
+                                              const int (&xa)[9][GC], int wl_off) {
+    if constexpr (ST < NS) {
+      if constexpr (ST + PF < NS) load<ST + PF>(wfr, xfr, xa, wl_off);
+      constexpr int younger = (NS - 1 - ST < PF ? NS - 1 - ST : PF) * RPS;
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger));
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = sg_mfma_chunk<T>(wfr[ST % RING], xfr[ST % RING][0], acc[0]);
+      acc[1] = sg_mfma_chunk<T>(wfr[ST % RING], xfr[ST % RING][1], acc[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      step<ST + 1>(acc, wfr, xfr, xa, wl_off);
+    }
+  }
+  template <int ST>
+  static __device__ __forceinline__ void prologue(u32x4 (&wfr)[RING], u32x4 (&xfr)[RING][2], const int (&xa)[9][GC],
+                                                  int wl_off) {
+    if constexpr (ST < PF && ST < NS) {
+      load<ST>(wfr, xfr, xa, wl_off);
+      prologue<ST + 1>(wfr, xfr, xa, wl_off);
+    }
+  }
+  static __device__ __forceinline__ void run(f32x16 (&acc)[2], const int (&xa)[9][GC], int wl_off) {
+    u32x4 wfr[RING], xfr[RING][2];
+    prologue<0>(wfr, xfr, xa, wl_off);
+    step<0>(acc, wfr, xfr, xa, wl_off);
+  }
+};
+
+template <typename T, int GC>
+__global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TAPS = 27;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int EPP = 16 / ES;
+  constexpr int S = GC * 2;                          // 16-byte slots per halo row
+  constexpr int sshift = GC == 1 ? 1 : 2;
+  constexpr int rshift = GC == 1 ? 3 : 2;            // rows per 256-byte bank row
+  constexpr int rb = GC * 32;
+  constexpr int PR = GC == 1 ? 224 : 208, PB = PR * rb, PPIECES = PB / 1024;   // 13 (GC=2) / 7 (GC=1) pieces per plane
+  static_assert(PB % 1024 == 0 && PB == sg_unrolled_ks<T, GC, 1, 3>::PB, "plane slot must be whole pieces");
+  constexpr int RINGB = 4 * PB;
+  constexpr uint32_t DEAD = 0x80000000u;             // byte offset beyond every buffer: loads return 0, stores drop
+  const sg_tile_geom& g = a.g;                       // TN=1, TD=2, TH=4, TW=32, HD=4, HH=6, HW=34 (host-checked)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave8 >> 2, wave = wave8 & 3;
+  const int r = lane & 31, hh = lane >> 5;
+  // LDS map: [ring of group 0][ring of group 1][resident weights: [tap][gi] 1-KiB fragments][bias: 32 floats]
+  char* xmine = smem + grp * RINGB;
+  char* wlds = smem + 2 * RINGB;
+  const char* wp = reinterpret_cast<const char*>(a.wp);
+  const int nt0 = blockIdx.y;
+  // Everything global goes through buffer resources: a scalar base, a scalar per-tile / per-plane offset and a
+  // 32-bit per-lane offset computed once.  The off-phase of this kernel was bound by the INSTRUCTIONS of 64-bit
+  // address arithmetic and pointer selects (~1000 per tile), not by memory; dead lanes simply carry DEAD.
+  const int64_t nvox = (int64_t)g.N * g.D * g.H * g.W;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)(nvox * a.cin * ES), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(nvox * a.cout * ES), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.mask_bits), 0, (int)(nvox * a.ntile * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(a.sign_out, 0, (int)(nvox * a.ntile * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(a.pn_scale, 0, (int)(nvox * 4), 0x00020000);
+
+  // column schedule: a block walks PAIRS of H-adjacent tile columns along D, wave group g taking the column with
+  // tile row 2*k + g, one phase apart: the two halo rows the pair shares are fetched twice within ~2 us on the same
+  // CU and the second fetch is an L2 hit (dealt independently, H-neighbours drift apart and every overlap row came
+  // from HBM again: fetch 1.55x the input, now 1.02x, PMC).  XCD group xg owns a contiguous chunk of the pair list.
+  const int nTh2 = (g.nTh + 1) >> 1;
+  const int npair = g.nTn * nTh2 * g.nTw;
+  const int xg = blockIdx.x & 7, bslot = blockIdx.x >> 3;
+  const int per_x = gridDim.x >> 3;
+  const int cpx = (npair + 7) >> 3;
+  const int c_begin = xg * cpx, c_end = min(npair, c_begin + cpx);
+  const int cfirst = c_begin + bslot;
+  const int ncols_blk = cfirst < c_end ? (c_end - cfirst + per_x - 1) / per_x : 0;
+  const int items_mine = ncols_blk * g.nTd;
+
+  // fragment addresses inside a plane slot: voxel (h = wave + kh, w = r + kw), channel chunk gi, half hh
+  int xa[9][GC];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int row = (wave + kh) * 34 + r + kw;
+      const int f = (row >> rshift) & (S - 1);
+#pragma unroll
+      for (int gi = 0; gi < GC; ++gi)
+        xa[kh * 3 + kw][gi] = grp * RINGB + row * rb + (((2 * gi + hh) ^ f) << 4);
+    }
+  // plane-local staging table: this lane's 16-byte pieces of 1-KiB blocks wave, wave+4, ... of a plane.  The halo
+  // goes global -> registers -> LDS (the loads of a whole step stay in flight across the epilogue).
+  constexpr int MAXP = (PPIECES + 3) / 4;
+  uint32_t relb[MAXP];   // byte offset of my piece relative to the plane's first halo voxel (h0-1, w0-1); dead: huge
+  int crdp[MAXP];        // packed (hw, hh) for the boundary test; dead pieces fail every range
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    const int it = (wave + 4 * k) * 64 + lane;
+    const int row = it >> sshift, p = it & (S - 1);
+    const int hh_ = row / 34, hw = row - hh_ * 34;
+    const int c = p * EPP;
+    const bool live = row < 204 && c < a.cin && (wave + 4 * k) < PPIECES;
+    relb[k] = live ? (uint32_t)(((hh_ * g.W + hw) * a.cin + c) * ES) : 0xC0000000u;   // stays >= DEAD after + tile offset
+    crdp[k] = live ? (hw | (hh_ << 8)) : 0x7F7F;
+  }
+  // LDS position of my piece inside its 1-KiB block: slot p of row lands at p ^ f(row), and f(row) only depends on
+  // the lane because a block is a whole number of 256-byte bank rows
+  const int wofs = (lane >> sshift) * rb + (((lane & (S - 1)) ^ ((lane >> (sshift + rshift)) & (S - 1))) << 4);
+  // my two output voxels (d = mt, h = wave, w = r of the tile): byte / word offsets relative to the tile origin
+  uint32_t yvo[2], svo[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int v = (mt * g.H + wave) * g.W + r;
+    yvo[mt] = (uint32_t)((v * a.cout + nt0 * 32) * ES);
+    svo[mt] = (uint32_t)(v * a.ntile + nt0) * 4u;
+  }
+  const uint32_t plane_bytes = (uint32_t)(g.H * g.W * a.cin * ES);
+
+  struct Item { int n0, d0, h0, w0, di; };
+  auto item_of = [&](int q) {
+    Item o;
+    const int cj = q / g.nTd;
+    o.di = q - cj * g.nTd;
+    const int pr = cfirst + cj * per_x;
+    const int c1 = (int)sg_div((uint32_t)pr, g.fnTw);
+    o.w0 = (pr - c1 * g.nTw) * 32;
+    const int c2 = c1 / nTh2;
+    o.h0 = (2 * (c1 - c2 * nTh2) + grp) * 4;         // may lie beyond H for the last odd row: a dead column
+    o.n0 = c2;
+    o.d0 = o.di * 2;
+    return o;
+  };
+
+  // per-lane offsets of my pieces for the tile at o (same for all of its planes)
+  auto piece_offsets = [&](const Item& o, uint32_t (&vk)[MAXP]) {
+    const int tile_off = ((o.h0 - 1) * g.W + (o.w0 - 1)) * a.cin * ES;   // may be negative: only dead lanes go below 0
+    const bool hw_interior = o.h0 >= 1 && o.w0 >= 1 && o.h0 + 5 <= g.H && o.w0 + 33 <= g.W;
+    if (hw_interior) {
+#pragma unroll
+      for (int k = 0; k < MAXP; ++k) vk[k] = relb[k] + (uint32_t)tile_off;
+    } else {
+      const int lo_w = max(0, 1 - o.w0), hi_w = min(34, g.W + 1 - o.w0) - 1;
+      const int lo_h = max(0, 1 - o.h0), hi_h = min(6, g.H + 1 - o.h0) - 1;   // hi_h < 0 for a dead column
+      const uint32_t lo = (uint32_t)(lo_w | (lo_h << 8));
+      const uint32_t hi = (uint32_t)(hi_w | ((hi_h & 0x7F) << 8)) | 0x8080u;
+#pragma unroll
+      for (int k = 0; k < MAXP; ++k) {
+        const uint32_t c_ = (uint32_t)crdp[k];
+        const uint32_t t1 = (c_ | 0x8080u) - lo, t2 = hi - c_;
+        vk[k] = ((t1 & t2 & 0x8080u) == 0x8080u && hi_h >= 0) ? relb[k] + (uint32_t)tile_off : DEAD;
+      }
+    }
+  };
+  auto load_planes = [&](const Item& o, int hd0, const uint32_t (&vk)[MAXP], u32x4 (&stg)[2][MAXP]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gp = o.d0 - 1 + hd0 + j;             // global D plane
+      const bool plane_ok = gp >= 0 && gp < g.D;
+      const uint32_t soff = plane_ok ? (uint32_t)(o.n0 * g.D + gp) * plane_bytes : 0u;
+#pragma unroll
+      for (int k = 0; k < MAXP; ++k)
+        if (wave + 4 * k < PPIECES)
+          stg[j][k] = __builtin_amdgcn_raw_buffer_load_b128(rx, plane_ok ? vk[k] : DEAD, soff, 0);
+    }
+  };
+  auto store_planes = [&](const Item& o, int hd0, const u32x4 (&stg)[2][MAXP]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int gp = o.d0 - 1 + hd0 + j;
+      char* dst = xmine + ((gp + 8) & 3) * PB + wofs;
+#pragma unroll
+      for (int k = 0; k < MAXP; ++k)
+        if (wave + 4 * k < PPIECES) *reinterpret_cast<u32x4*>(dst + (wave + 4 * k) * 1024) = stg[j][k];
+    }
+  };
+
+  // resident weights (all 8 waves) and bias
+  {
+    constexpr int nfrag = TAPS * GC;
+    for (int f = wave8; f < nfrag; f += 8) {
+      const int tap = f / GC, gi = f - tap * GC;
+      const char* src = gi < a.nchunk ? wp + ((((int64_t)gi * TAPS + tap) * a.ntile + nt0) << 10)
+                                      : reinterpret_cast<const char*>(sg_zero_page);
+      sg_glds16(src + (gi < a.nchunk ? lane * 16 : 0), wlds + ((size_t)f << 10));
+    }
+  }
+  float* bias_lds = reinterpret_cast<float*>(wlds + TAPS * GC * 1024);
+  if (tid < 32) {
+    const int co = nt0 * 32 + tid;
+    bias_lds[tid] = (a.bias != nullptr && co < a.cout) ? a.bias[co] : 0.f;
+  }
+  u32x4 stg[2][MAXP];
+  uint32_t vk[MAXP];
+  if (grp == 0 && items_mine > 0) {   // the very first tile of group 0: all four planes, latency exposed once
+    const Item o0 = item_of(0);
+    piece_offsets(o0, vk);
+    load_planes(o0, 0, vk, stg);
+    store_planes(o0, 0, stg);
+    load_planes(o0, 2, vk, stg);
+    store_planes(o0, 2, stg);
+  }
+  __syncthreads();
+
+  const int wl_off = (int)(wlds - smem) + lane * 16;
+  const float inv_c = 1.f / (float)a.cout;
+  const bool wide_store = ES == 2 && (a.cout % 8 == 0) && nt0 * 32 + 32 <= a.cout && !(a.dbg_flags & 16);
+  f32x16 acc[2];
+
+  int dbgi = 0;
+  auto stamp = [&]() {
+    if (a.dbg != nullptr && blockIdx.x == 8 && blockIdx.y == 0 && lane == 0 && wave == 0 && dbgi < 120)
+      a.dbg[grp * 128 + dbgi] = __builtin_amdgcn_s_memtime();
+    ++dbgi;
+  };
+  const int nphase = 2 * items_mine + 1;
+  for (int p = 0; p < nphase; ++p) {
+    const int q = p >> 1;
+    stamp();
+    if ((p & 1) == grp) {
+      if (q < items_mine) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[mt][i] = bias_lds[(i & 3) + 8 * (i >> 2) + 4 * hh];   // bias rides in C
+        const int di = q % g.nTd;
+        if (a.dbg_flags & 8) { /* diagnostic: no MFMA phase */ }
+        else if (di & 1) sg_unrolled_ks<T, GC, 1, 3>::run(acc, xa, wl_off);
+        else sg_unrolled_ks<T, GC, 3, 3>::run(acc, xa, wl_off);
+      }
+    } else {
+      const int qn = (p + 1) >> 1, qp = qn - 1;      // my next / previous item
+      const bool closes = qp >= 0 && qp < items_mine && !(a.dbg_flags & 2);
+      const Item o = item_of(closes ? qp : 0);
+      // W is a multiple of 32 and a wave owns one H row, an M tile one D plane: store predicates are uniform
+      const bool row_ok = closes && o.h0 + wave < g.H;
+      const uint32_t tile_vox = (uint32_t)(((o.n0 * g.D + o.d0) * g.H + o.h0) * g.W + o.w0);
+      const uint32_t ysoff = tile_vox * (uint32_t)(a.cout * ES), ssoff = tile_vox * (uint32_t)(a.ntile * 4);
+      uint32_t mb[2];
+      const bool use_mask = a.mask_bits != nullptr && closes;
+      if (use_mask) {   // sign words of the tile about to be stored, requested ahead of everything else
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          mb[mt] = __builtin_amdgcn_raw_buffer_load_b32(rm, (row_ok && o.d0 + mt < g.D) ? svo[mt] : DEAD, ssoff, 0);
+      }
+      // next tile's new halo planes: loads issued now, written to the ring after the epilogue
+      const bool restage = qn < items_mine && !((a.dbg_flags & 1) && p >= 2);
+      const Item on = item_of(restage ? qn : 0);
+      if (restage) {
+        piece_offsets(on, vk);
+        if (on.di == 0) {   // bottom of a column: the two lower planes first, straight through
+          load_planes(on, 0, vk, stg);
+          store_planes(on, 0, stg);
+        }
+        load_planes(on, 2, vk, stg);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      stamp();
+      if (closes) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          const bool ok = row_ok && o.d0 + mt < g.D;   // uniform
+          if (a.act) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][i] = fmaxf(acc[mt][i], acc[mt][i] * a.slope);
+          }
+          if (a.pixel_norm) {
+            float ss = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) ss += acc[mt][i] * acc[mt][i];
+            ss += __shfl_xor(ss, 32);
+            const float sc = rsqrtf(ss * inv_c + a.eps);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][i] *= sc;
+            if (a.pn_scale != nullptr && ok)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc), rp, hh == 0 ? (svo[mt] - nt0 * 4u) / (uint32_t)a.ntile : DEAD,
+                                                    tile_vox * 4u, 0);
+          }
+          if (a.sign_out != nullptr) {
+            const uint32_t sw = sg_sign_word(acc[mt], hh);
+            if (ok) __builtin_amdgcn_raw_buffer_store_b32(sw, rs_, hh == 0 ? svo[mt] : DEAD, ssoff, 0);
+          }
+          if (use_mask) sg_apply_sign_word(acc[mt], mb[mt], hh, a.mask_slope);
+          if (wide_store) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {   // 16 contiguous bytes per lane (see sg_store_tile_row_bf16)
+              const uint32_t a0 = sg_pack_bf16(acc[mt][8 * j + 0], acc[mt][8 * j + 1]), a1 = sg_pack_bf16(acc[mt][8 * j + 2], acc[mt][8 * j + 3]);
+              const uint32_t b0 = sg_pack_bf16(acc[mt][8 * j + 4], acc[mt][8 * j + 5]), b1 = sg_pack_bf16(acc[mt][8 * j + 6], acc[mt][8 * j + 7]);
+              const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+              const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+              u32x4 out;
+              out[0] = s0[0]; out[1] = s1[0]; out[2] = s0[1]; out[3] = s1[1];
+              if (ok) __builtin_amdgcn_raw_buffer_store_b128(out, ry, yvo[mt] + (uint32_t)((16 * j + 8 * hh) * 2), ysoff, 0);
+            }
+          } else if (ok) {
+            T* yrow = reinterpret_cast<T*>(a.y) + ((int64_t)tile_vox + (int64_t)(mt * g.H + wave) * g.W + r) * (int64_t)a.cout;
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+              const int co = nt0 * 32 + 8 * qd + 4 * hh;
+              if (a.vec_out && co + 4 <= a.cout) {
+                T tmp[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) tmp[e] = sg_traits<T>::from_f(acc[mt][qd * 4 + e]);
+                if (sizeof(T) == 2) *reinterpret_cast<u32x2*>(yrow + co) = *reinterpret_cast<u32x2*>(tmp);
+                else *reinterpret_cast<u32x4*>(yrow + co) = *reinterpret_cast<u32x4*>(tmp);
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (co + e < a.cout) yrow[co + e] = sg_traits<T>::from_f(acc[mt][qd * 4 + e]);
+              }
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (restage) store_planes(on, 2, stg);
+    }
+    stamp();
+    __syncthreads();
+  }
+}
+
+template <typename T, int GC>
+static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used) {
+  *used = false;
+  if (s->upsample_in || s->kd != 3 || s->kh != 3 || s->kw != 3) return SG_OK;
+  if (s->d < 4 || (s->w % 32) != 0) return SG_OK;   // needs >= 2 steps per column; full 32-wide rows
+  a.g = sg_make_geom(s, 256, /*prefer_w32=*/true, /*td=*/2, /*th=*/4);
+  const sg_tile_geom& g = a.g;
+  if (g.TN != 1 || g.TD != 2 || g.TH != 4 || g.TW != 32 || g.HD != 4 || g.HH != 6 || g.HW != 34) return SG_OK;
+  {   // buffer addressing: every tensor this kernel touches must stay below 2 GiB
+    const int64_t nvox = (int64_t)s->n * s->d * s->h * s->w;
+    const int es = (int)sizeof(T);
+    if (nvox * s->cin * es >= (1ll << 31) || nvox * s->cout * es >= (1ll << 31) || nvox * a.ntile * 4 >= (1ll << 31)) return SG_OK;
+  }
+  int gx = (256 / a.ntile) / 8 * 8;
+  if (gx < 8) gx = 8;
+  if (g.nTn * ((g.nTh + 1) / 2) * g.nTw < gx) return SG_OK;   // at least one column pair per block
+  constexpr int PB = (GC == 1 ? 224 : 208) * GC * 32;
+  const size_t lds = 8ull * PB + 27ull * GC * 1024 + 128;
+  if (lds > 160 * 1024) return SG_OK;
+  a.G = GC;
+  a.rs = GC * 32;
+  a.vec_in = 1;
+  a.vec_out = (s->cout % 4 == 0) ? 1 : 0;
+  auto kern = conv_fwd3s_kernel<T, GC>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.ntile), dim3(512), lds, st, a);
+  SG_LAUNCH_CHECK();
+  *used = true;
+  return SG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // forward, v4: persistent 8-wave ping-pong for ANY channel count (multiples of the 16-byte piece): the K loop
 // runs in 32-byte channel chunks (16 bf16 / 8 f32 channels).  A work item is (tile, chunk); group g = item
 // parity owns halo buffer g and weight buffer g.  While group g runs the 27 x MTW x NTB MFMAs of its item, the
@@ -1341,6 +1740,11 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     bool used = false;
     rc = SG_OK;
     const bool k333 = s->kd == 3 && s->kh == 3 && s->kw == 3, k133 = s->kd == 1 && s->kh == 3 && s->kw == 3;
+    if (dt == SG_BF16 && k333 && !sg_env_int("SG_FWD_NO_V3S", 0)) {   // sliding-halo variant where its tile fits
+      if (a.nchunk == 2) rc = launch_fwd3s<bf16_t, 2>(a, s, hs, &used);
+      else if (a.nchunk == 1) rc = launch_fwd3s<bf16_t, 1>(a, s, hs, &used);
+      if (rc != SG_OK || used) { prof.done(rc); return rc; }
+    }
     if (dt == SG_BF16) {
       if (k333 && a.nchunk == 2) rc = launch_fwd3r<bf16_t, 2, 2, 3, 3, 3>(a, s, hs, &used);
       else if (k333 && a.nchunk == 1) rc = launch_fwd3r<bf16_t, 2, 1, 3, 3, 3>(a, s, hs, &used);

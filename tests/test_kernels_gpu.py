@@ -58,7 +58,9 @@ CONV_CASES = [
     (2, 16, 32, (17, 66, 70), (3, 3, 3)),    # same kernel, ragged extents, single K chunk
     (2, 48, 96, (16, 64, 64), (3, 3, 3)),    # streamed-weight ping-pong kernel: 3 K chunks, 3 cout tiles over 2 blocks
     (4, 64, 32, (2, 64, 64), (1, 3, 3)),     # same, (1,3,3) taps, one cout tile
-    (2, 32, 32, (6, 128, 256), (3, 3, 3)),   # 512 tile columns: sliding-halo wgrad (ring of D planes), ragged D tiles
+    (2, 32, 32, (6, 128, 256), (3, 3, 3)),   # 512 tile columns: sliding-halo wgrad and forward (ring of D planes)
+    (2, 16, 32, (5, 126, 256), (3, 3, 3)),   # sliding-halo forward, one 32-byte chunk, ragged D and H
+    (2, 32, 64, (4, 64, 256), (3, 3, 3)),    # sliding-halo forward, two cout slices
 ]
 
 
@@ -144,6 +146,7 @@ MASK_CASES = [
     (2, 32, 32, (16, 64, 64), (3, 3, 3)),    # persistent weight-stationary kernel; sliding-halo wgrad with the ones tap
     (2, 64, 32, (8, 64, 64), (3, 3, 3)),     # streamed ping-pong kernel, one cout tile; 2 cin tiles in wgrad
     (2, 64, 64, (8, 32, 64), (3, 3, 3)),     # streamed ping-pong kernel, two cout tiles
+    (2, 32, 32, (5, 128, 256), (3, 3, 3)),   # sliding-halo forward kernel (mask words, sign_out), ragged D
 ]
 
 

@@ -5,7 +5,7 @@ from saragan_amd._lib import ConvEpilogue, ConvShape
 lib = _lib.load()
 lib.sg_debug_set_ts_buffer.argtypes = [C.c_void_p]
 dev = torch.device('cuda:0')
-n, d, h, w, cin, cout = 8, 32, 128, 128, 32, 32
+n, d, h, w, cin, cout = int(os.environ.get('TS_N', '16')), 32, 128, 128, int(os.environ.get('TS_CIN', '32')), int(os.environ.get('TS_COUT', '32'))
 shp = ConvShape(n, d, h, w, cin, cout, 3, 3, 3, 0)
 dt = _lib.SG_BF16
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -20,12 +20,16 @@ for _ in range(3):
     _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep), dt, st))
 ts = torch.zeros(256, dtype=torch.int64, device=dev)
 lib.sg_debug_set_ts_buffer(ts.data_ptr())
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
 _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep), dt, st))
+e1.record()
 torch.cuda.synchronize()
+print('kernel ms', e0.elapsed_time(e1))
 lib.sg_debug_set_ts_buffer(None)
 t = ts.cpu().numpy()
 for g in range(2):
     v = t[g * 128:(g + 1) * 128]
     v = v[v > 0]
-    print('group', g, 'n', len(v))
+    print('group', g, 'n', len(v), 'span', int(v[-1] - v[0]) if len(v) else 0)
     print(' deltas:', [int(b - a) for a, b in zip(v[:40], v[1:41])])

@@ -1706,6 +1706,150 @@ static int launch_fwd4(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, b
   return SG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// pointwise (1x1x1) convolutions with <= 4 channels on one side: from_rgb / to_rgb and their data gradients
+// (pgan/generator.py:13-16, pgan/discriminator.py:9-12).  One side of the product is the whole HBM traffic
+// (32-64 channels per voxel against 1), so these are streaming kernels, not GEMMs: 16 bytes per lane on the wide
+// side, weights (read from the packed MFMA image, i.e. the same rounded values) in registers.
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ float sg_packed_w(const char* wp, int ntile, int cin_j, int cout_c) {
+  constexpr int CH = sg_traits<T>::CH, ES = (int)sizeof(T);
+  const int chunk = cin_j / CH, hh = (cin_j % CH) / (CH / 2), e = cin_j % (CH / 2);
+  const char* frag = wp + ((int64_t)(chunk * ntile + (cout_c >> 5)) << 10);
+  return sg_traits<T>::to_f(*reinterpret_cast<const T*>(frag + ((cout_c & 31) + 32 * hh) * 16 + e * ES));
+}
+
+// cin <= 4: y[v][c] = epilogue(sum_j x[v][j] * w[j][c] + b[c]); thread owns one 16-byte piece of couts (fixed)
+template <typename T>
+__global__ __launch_bounds__(256) void pw_fwd_small_cin_kernel(ConvFwdArgs a, int64_t nvox) {
+  constexpr int E = 16 / (int)sizeof(T);
+  const int P = a.cout / E;                     // pieces per voxel, divides 256
+  const int p = threadIdx.x % P;
+  const int c0 = p * E;
+  const char* wp = reinterpret_cast<const char*>(a.wp);
+  float w[4][E], b[E];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < E; ++e) w[j][e] = j < a.cin ? sg_packed_w<T>(wp, a.ntile, j, c0 + e) : 0.f;
+#pragma unroll
+  for (int e = 0; e < E; ++e) b[e] = a.bias ? a.bias[c0 + e] : 0.f;
+  const T* x = reinterpret_cast<const T*>(a.x);
+  T* y = reinterpret_cast<T*>(a.y);
+  const int rows = 256 / P;
+  const int tpw = P < 32 / E ? P : 32 / E;      // threads per 32-channel sign word (adjacent lanes; powers of two)
+  const int64_t nv_pad = (nvox + rows - 1) / rows * rows;   // whole waves stay in the loop for the shuffles
+  for (int64_t v = (int64_t)blockIdx.x * rows + threadIdx.x / P; v < nv_pad; v += (int64_t)gridDim.x * rows) {
+    const bool live = v < nvox;
+    float xv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xv[j] = (live && j < a.cin) ? sg_traits<T>::to_f(x[v * a.cin + j]) : 0.f;
+    float o[E];
+    uint32_t neg = 0u;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      float t = b[e];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t = fmaf(xv[j], w[j][e], t);
+      if (a.act) t = fmaxf(t, t * a.slope);
+      neg |= (t < 0.f ? 1u : 0u) << e;
+      o[e] = t;
+    }
+    if (a.sign_out != nullptr) {                // the TPW threads of a word are adjacent lanes
+      uint32_t wbits = neg << ((p % tpw) * E);
+      for (int sh = 1; sh < tpw; sh <<= 1) wbits |= (uint32_t)__shfl_xor((int)wbits, sh);
+      if (live && p % tpw == 0) a.sign_out[v * a.ntile + (c0 >> 5)] = wbits;
+    }
+    if (!live) continue;
+    if (a.mask_bits != nullptr) {
+      const uint32_t mw = a.mask_bits[v * a.ntile + (c0 >> 5)] >> (c0 & 31);
+#pragma unroll
+      for (int e = 0; e < E; ++e) o[e] = ((mw >> e) & 1u) ? o[e] * a.mask_slope : o[e];
+    }
+    u32x4 raw;
+    T* t = reinterpret_cast<T*>(&raw);
+#pragma unroll
+    for (int e = 0; e < E; ++e) t[e] = sg_traits<T>::from_f(o[e]);
+    *reinterpret_cast<u32x4*>(y + v * a.cout + c0) = raw;
+  }
+}
+
+// cout <= 4: y[v][c] = epilogue(sum_k x[v][k] * w[k][c] + b[c]); the P = cin/E threads of a voxel are adjacent lanes
+template <typename T>
+__global__ __launch_bounds__(256) void pw_fwd_small_cout_kernel(ConvFwdArgs a, int64_t nvox) {
+  constexpr int E = 16 / (int)sizeof(T);
+  const int P = a.cin / E;                      // power of two <= 64
+  const int p = threadIdx.x % P;
+  const char* wp = reinterpret_cast<const char*>(a.wp);
+  float w[E][4];
+#pragma unroll
+  for (int e = 0; e < E; ++e)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w[e][c] = c < a.cout ? sg_packed_w<T>(wp, a.ntile, p * E + e, c) : 0.f;
+  const T* x = reinterpret_cast<const T*>(a.x);
+  T* y = reinterpret_cast<T*>(a.y);
+  const int rows = 256 / P;
+  const int64_t nv_pad = (nvox + rows - 1) / rows * rows;   // whole waves stay in the loop for the shuffles
+  for (int64_t v = (int64_t)blockIdx.x * rows + threadIdx.x / P; v < nv_pad; v += (int64_t)gridDim.x * rows) {
+    const bool live = v < nvox;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      u32x4 raw = *reinterpret_cast<const u32x4*>(x + v * a.cin + p * E);
+      const T* t = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const float xv = sg_traits<T>::to_f(t[e]);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) s[c] = fmaf(xv, w[e][c], s[c]);
+      }
+    }
+    for (int sh = 1; sh < P; sh <<= 1)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s[c] += __shfl_xor(s[c], sh);
+    if (live && p == 0) {
+      uint32_t neg = 0u;
+      const uint32_t mw = a.mask_bits ? a.mask_bits[v] : 0u;   // cout <= 4: one word per voxel
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c < a.cout) {
+          float t = s[c] + (a.bias ? a.bias[c] : 0.f);
+          if (a.act) t = fmaxf(t, t * a.slope);
+          neg |= (t < 0.f ? 1u : 0u) << c;
+          if ((mw >> c) & 1u) t *= a.mask_slope;
+          y[v * a.cout + c] = sg_traits<T>::from_f(t);
+        }
+      }
+      if (a.sign_out != nullptr) a.sign_out[v] = neg;
+    }
+  }
+}
+
+template <typename T>
+static int launch_pw_fwd(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used) {
+  *used = false;
+  constexpr int E = 16 / (int)sizeof(T);
+  if (a.taps != 1 || s->upsample_in || a.pixel_norm) return SG_OK;
+  const int64_t nvox = (int64_t)s->n * s->d * s->h * s->w;
+  if (s->cin <= 4 && s->cout % E == 0 && 256 % (s->cout / E) == 0 && s->cout / E <= 256 &&
+      ((s->cout / E) & (s->cout / E - 1)) == 0) {
+    const int rows = 256 / (s->cout / E);
+    int64_t nb = (nvox + rows - 1) / rows;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(pw_fwd_small_cin_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, a, nvox);
+    SG_LAUNCH_CHECK();
+    *used = true;
+  } else if (s->cout <= 4 && s->cin % E == 0 && (s->cin / E) <= 64 && ((s->cin / E) & (s->cin / E - 1)) == 0) {
+    const int rows = 256 / (s->cin / E);
+    int64_t nb = (nvox + rows - 1) / rows;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(pw_fwd_small_cout_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, a, nvox);
+    SG_LAUNCH_CHECK();
+    *used = true;
+  }
+  return SG_OK;
+}
+
 static unsigned long long* g_dbg_ts = nullptr;
 extern "C" __attribute__((visibility("default"))) void sg_debug_set_ts_buffer(void* p) { g_dbg_ts = (unsigned long long*)p; }
 
@@ -1735,6 +1879,11 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
   int rc;
   hipStream_t hs = sg_st(st);
   const int es = dt == SG_BF16 ? 2 : 4;
+  if (!sg_env_int("SG_FWD_NO_PW", 0)) {   // streaming kernels for the 1x1x1 layers with <= 4 channels on one side
+    bool used = false;
+    rc = dt == SG_BF16 ? launch_pw_fwd<bf16_t>(a, s, hs, &used) : launch_pw_fwd<float>(a, s, hs, &used);
+    if (rc != SG_OK || used) { prof.done(rc); return rc; }
+  }
   const bool v2 = ((s->cin * es) % 16 == 0) && !sg_env_int("SG_FWD_V1", 0);
   if (v2 && !sg_env_int("SG_FWD_NO_V3", 0) && (!a.pixel_norm || a.ntile == 1)) {
     bool used = false;

@@ -1825,12 +1825,81 @@ __global__ __launch_bounds__(256) void pw_fwd_small_cout_kernel(ConvFwdArgs a, i
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// dense layers on <= 32 "voxels" (the batch): y[v][c] = epilogue(sum_k x[v][k] w[k][c] + b[c]), e.g. D's
+// 8192 -> 512 (pgan/discriminator.py:60-63).  The whole cost is streaming the weight image once: one block of 16
+// waves per 32-channel output tile, wave w takes K chunks w, w+16, ... (8 loads in flight), 1-KiB weight fragments
+// straight from the packed image into the MFMA A operand, partial tiles summed through LDS.
+// ------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(1024) void dense_small_m_kernel(ConvFwdArgs a, int nvox) {
+  __shared__ float red[16][16][64];             // [wave][acc element][lane]
+  constexpr int CH = sg_traits<T>::CH;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int nt0 = blockIdx.x;
+  const char* wp = reinterpret_cast<const char*>(a.wp) + ((int64_t)nt0 << 10) + lane * 16;
+  const T* x = reinterpret_cast<const T*>(a.x);
+  const bool vlive = r < nvox;
+  const T* xrow = x + (int64_t)(vlive ? r : 0) * a.cin + hh * (CH / 2);
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  constexpr int U = 8;
+  for (int q0 = wave; q0 < a.nchunk; q0 += 16 * U) {
+    u32x4 wf[U], xf[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int q = q0 + 16 * u;
+      const bool ok = q < a.nchunk;
+      wf[u] = ok ? *reinterpret_cast<const u32x4*>(wp + ((int64_t)q * a.ntile << 10)) : u32x4{0u, 0u, 0u, 0u};
+      xf[u] = (ok && vlive) ? *reinterpret_cast<const u32x4*>(xrow + q * CH) : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc = sg_mfma_chunk<T>(wf[u], xf[u], acc);
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) red[wave][i][lane] = acc[i];
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) t += red[w][i][lane];
+      const int co = nt0 * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if (a.bias != nullptr && co < a.cout) t += a.bias[co];
+      if (a.act) t = fmaxf(t, t * a.slope);
+      acc[i] = t;
+    }
+    if (a.sign_out != nullptr) {
+      const uint32_t sw = sg_sign_word(acc, hh);
+      if (hh == 0 && vlive) a.sign_out[(int64_t)r * a.ntile + nt0] = sw;
+    }
+    if (a.mask_bits != nullptr && vlive) sg_apply_sign_word(acc, a.mask_bits[(int64_t)r * a.ntile + nt0], hh, a.mask_slope);
+    if (vlive) {
+      T* yrow = reinterpret_cast<T*>(a.y) + (int64_t)r * a.cout;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int co = nt0 * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (co < a.cout) yrow[co] = sg_traits<T>::from_f(acc[i]);
+      }
+    }
+  }
+}
+
 template <typename T>
 static int launch_pw_fwd(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used) {
   *used = false;
   constexpr int E = 16 / (int)sizeof(T);
   if (a.taps != 1 || s->upsample_in || a.pixel_norm) return SG_OK;
   const int64_t nvox = (int64_t)s->n * s->d * s->h * s->w;
+  if (nvox <= 32 && s->cin % sg_traits<T>::CH == 0 && a.nchunk >= 64 && !sg_env_int("SG_FWD_NO_DENSE", 0)) {
+    hipLaunchKernelGGL(dense_small_m_kernel<T>, dim3((unsigned)a.ntile), dim3(1024), 0, st, a, (int)nvox);
+    SG_LAUNCH_CHECK();
+    *used = true;
+    return SG_OK;
+  }
   if (s->cin <= 4 && s->cout % E == 0 && 256 % (s->cout / E) == 0 && s->cout / E <= 256 &&
       ((s->cout / E) & (s->cout / E - 1)) == 0) {
     const int rows = 256 / (s->cout / E);

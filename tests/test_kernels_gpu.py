@@ -283,22 +283,27 @@ def test_fused_mask_chain_first_and_second_order(big, dtype):
 
 
 @pytest.mark.parametrize('dtype', DT)
-def test_dense(dtype):
+@pytest.mark.parametrize('shape', [(5, 48, 20), (16, 2048, 96)])   # the second: streamed-weight small-batch kernel
+def test_dense(shape, dtype):
     from saragan_amd import functional as F
-    x = rnd((5, 48), 8, dtype)
-    w = rnd((48, 20), 9, dtype)
+    n, cin, cout = shape
+    x = rnd((n, cin), 8, dtype)
+    w = rnd((cin, cout), 9, dtype)
+    b = rnd((cout,), 10, torch.float32) * 0.5
     coef = O.runtime_coef(w.shape, 'leaky_relu', 0.2)
     wq = (w * coef).to(dtype).double() / coef
-    xr, wr = x.clone().requires_grad_(True), wq.clone().requires_grad_(True)
-    yr = O.dense(xr, wr, 'leaky_relu', 0.2)
+    xr, wr, br = x.clone().requires_grad_(True), wq.clone().requires_grad_(True), b.double().requires_grad_(True)
+    yr = O.act(O.apply_bias(O.dense(xr, wr, 'leaky_relu', 0.2), br), 'leaky_relu', 0.2)
     gy = rnd(tuple(yr.shape), 10, dtype)
-    gxr, gwr = torch.autograd.grad(yr, [xr, wr], gy)
+    gxr, gwr, gbr = torch.autograd.grad(yr, [xr, wr, br], gy)
     xg, wg = cl(x, dtype).requires_grad_(True), w.float().to(dev()).requires_grad_(True)
-    yg = F.conv3d(xg, wg, coef)
-    close(yg, yr, dtype)
-    gxg, gwg = torch.autograd.grad(yg, [xg, wg], cl(gy, dtype))
-    close(gxg, gxr, dtype)
+    bg = b.float().to(dev()).requires_grad_(True)
+    yg = F.conv3d(xg, wg, coef, bias=bg, act=True, slope=0.2)
+    close(yg.reshape(n, cout), yr, dtype)
+    gxg, gwg, gbg = torch.autograd.grad(yg, [xg, wg, bg], cl(gy, dtype).reshape(yg.shape))
+    close(gxg.reshape(n, cin), gxr, dtype)
     np.testing.assert_allclose(gwg.double().cpu().numpy(), gwr.numpy(), rtol=2e-3, atol=2e-3 * float(gwr.abs().max()))
+    np.testing.assert_allclose(gbg.double().cpu().numpy(), gbr.numpy(), rtol=2e-3, atol=2e-3 * float(gbr.abs().max()))
 
 
 @pytest.mark.parametrize('dtype', DT)

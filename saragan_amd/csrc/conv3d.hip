@@ -1099,12 +1099,14 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   // Everything global goes through buffer resources: a scalar base, a scalar per-tile / per-plane offset and a
   // 32-bit per-lane offset computed once.  The off-phase of this kernel was bound by the INSTRUCTIONS of 64-bit
   // address arithmetic and pointer selects (~1000 per tile), not by memory; dead lanes simply carry DEAD.
-  const int64_t nvox = (int64_t)g.N * g.D * g.H * g.W;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)(nvox * a.cin * ES), 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(nvox * a.cout * ES), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(a.mask_bits), 0, (int)(nvox * a.ntile * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_ = __builtin_amdgcn_make_buffer_rsrc(a.sign_out, 0, (int)(nvox * a.ntile * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(a.pn_scale, 0, (int)(nvox * 4), 0x00020000);
+  // The resources are rebased per batch sample (one 64-bit scalar add per tile), so only ONE SAMPLE of each tensor
+  // has to stay below 2 GiB.
+  const int64_t svox = (int64_t)g.D * g.H * g.W;           // voxels per sample
+  auto rsrc_of = [&](const void* base, int64_t sample_bytes, int n0) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + n0 * sample_bytes, 0,
+                                             (int)sample_bytes, 0x00020000);
+  };
+  const int64_t xsb = svox * a.cin * ES, ysb = svox * a.cout * ES, wsb = svox * a.ntile * 4, psb = svox * 4;
 
   // column schedule: a block walks PAIRS of H-adjacent tile columns along D, wave group g taking the column with
   // tile row 2*k + g, one phase apart: the two halo rows the pair shares are fetched twice within ~2 us on the same
@@ -1196,11 +1198,12 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
     }
   };
   auto load_planes = [&](const Item& o, int hd0, const uint32_t (&vk)[MAXP], u32x4 (&stg)[2][MAXP]) {
+    const __amdgpu_buffer_rsrc_t rx = rsrc_of(a.x, xsb, o.n0);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int gp = o.d0 - 1 + hd0 + j;             // global D plane
       const bool plane_ok = gp >= 0 && gp < g.D;
-      const uint32_t soff = plane_ok ? (uint32_t)(o.n0 * g.D + gp) * plane_bytes : 0u;
+      const uint32_t soff = plane_ok ? (uint32_t)gp * plane_bytes : 0u;
 #pragma unroll
       for (int k = 0; k < MAXP; ++k)
         if (wave + 4 * k < PPIECES)
@@ -1277,7 +1280,9 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
       const Item o = item_of(closes ? qp : 0);
       // W is a multiple of 32 and a wave owns one H row, an M tile one D plane: store predicates are uniform
       const bool row_ok = closes && o.h0 + wave < g.H;
-      const uint32_t tile_vox = (uint32_t)(((o.n0 * g.D + o.d0) * g.H + o.h0) * g.W + o.w0);
+      const uint32_t tile_vox = (uint32_t)((o.d0 * g.H + o.h0) * g.W + o.w0);   // within sample o.n0
+      const __amdgpu_buffer_rsrc_t ry = rsrc_of(a.y, ysb, o.n0), rm = rsrc_of(a.mask_bits, wsb, o.n0),
+                                   rs_ = rsrc_of(a.sign_out, wsb, o.n0), rp = rsrc_of(a.pn_scale, psb, o.n0);
       const uint32_t ysoff = tile_vox * (uint32_t)(a.cout * ES), ssoff = tile_vox * (uint32_t)(a.ntile * 4);
       uint32_t mb[2];
       const bool use_mask = a.mask_bits != nullptr && closes;
@@ -1336,7 +1341,8 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
               if (ok) __builtin_amdgcn_raw_buffer_store_b128(out, ry, yvo[mt] + (uint32_t)((16 * j + 8 * hh) * 2), ysoff, 0);
             }
           } else if (ok) {
-            T* yrow = reinterpret_cast<T*>(a.y) + ((int64_t)tile_vox + (int64_t)(mt * g.H + wave) * g.W + r) * (int64_t)a.cout;
+            T* yrow = reinterpret_cast<T*>(a.y) +
+                      (o.n0 * svox + (int64_t)tile_vox + (int64_t)(mt * g.H + wave) * g.W + r) * (int64_t)a.cout;
 #pragma unroll
             for (int qd = 0; qd < 4; ++qd) {
               const int co = nt0 * 32 + 8 * qd + 4 * hh;
@@ -1371,10 +1377,10 @@ static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
   a.g = sg_make_geom(s, 256, /*prefer_w32=*/true, /*td=*/2, /*th=*/4);
   const sg_tile_geom& g = a.g;
   if (g.TN != 1 || g.TD != 2 || g.TH != 4 || g.TW != 32 || g.HD != 4 || g.HH != 6 || g.HW != 34) return SG_OK;
-  {   // buffer addressing: every tensor this kernel touches must stay below 2 GiB
-    const int64_t nvox = (int64_t)s->n * s->d * s->h * s->w;
+  {   // buffer addressing (rebased per sample): one sample of every tensor this kernel touches stays below 2 GiB
+    const int64_t svox = (int64_t)s->d * s->h * s->w;
     const int es = (int)sizeof(T);
-    if (nvox * s->cin * es >= (1ll << 31) || nvox * s->cout * es >= (1ll << 31) || nvox * a.ntile * 4 >= (1ll << 31)) return SG_OK;
+    if (svox * s->cin * es >= (1ll << 31) || svox * s->cout * es >= (1ll << 31) || svox * a.ntile * 4 >= (1ll << 31)) return SG_OK;
   }
   int gx = (256 / a.ntile) / 8 * 8;
   if (gx < 8) gx = 8;

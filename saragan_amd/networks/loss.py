@@ -2,6 +2,8 @@
 the reference's signatures and return tuples.  Random draws go through a RandomSource so that parity tests can
 inject z, both noise tensors and gamma (TF and torch RNG streams cannot be matched); by default z/gamma come from
 the torch CUDA generator and the instance noise from the library's Philox kernel (sg_add_noise)."""
+import os
+
 import torch
 import torch.nn.functional as TF
 
@@ -47,6 +49,7 @@ class InjectedRandom(RandomSource):
 
 _RANDOM = {'src': None}
 _LINK = {'on': False}
+_NO_BATCHED_D = bool(int(os.environ.get('SARAGAN_NO_BATCHED_D', '0')))   # diagnostic: separate D(real) / D(fake) passes
 
 
 class linear_generator_link:
@@ -169,10 +172,20 @@ def forward_simultaneous(generator, discriminator, real_image_input, latent_dim,
     # :143-144): the same forward values.  ONE pass serves both here: the D-loss gradient is only taken w.r.t. D's
     # variables (the edge into G is never followed), the G-loss gradient only w.r.t. G's (no D weight gradients).
     link = _LINK['on'] and loss_fn == 'wgan' and gen_sample_noisy.requires_grad
-    fake_in = gen_sample_noisy.detach().requires_grad_(True) if link else gen_sample_noisy
-    disc_fake_g = discriminator(fake_in, alpha, phase, **net).float()
-    disc_fake_d = disc_fake_g
-    disc_real = discriminator(real_image_input, alpha, phase, is_reuse=True, **net).float()
+    if link and not _NO_BATCHED_D:
+        # The pgan discriminator has no op that couples batch samples (its minibatch-stddev layer is disabled,
+        # pgan/discriminator.py:50), so D(real) and D(fake) are ONE pass over the concatenated batch: a third fewer
+        # launches in D's forward and backward, twice the tiles for the low-resolution layers.
+        fake_in = gen_sample_noisy.detach().requires_grad_(True)
+        n_real = real_image_input.shape[0]
+        both = discriminator(torch.cat([real_image_input, fake_in], dim=0), alpha, phase, **net).float()
+        disc_real, disc_fake_g = both[:n_real], both[n_real:]
+        disc_fake_d = disc_fake_g
+    else:
+        fake_in = gen_sample_noisy.detach().requires_grad_(True) if link else gen_sample_noisy
+        disc_fake_g = discriminator(fake_in, alpha, phase, **net).float()
+        disc_fake_d = disc_fake_g
+        disc_real = discriminator(real_image_input, alpha, phase, is_reuse=True, **net).float()
     gamma = rng.gamma(real_image_input.shape[0], real_image_input.device).to(real_image_input.dtype)
     interpolates = gamma * real_image_input + (1 - gamma) * gen_sample_noisy.detach()
     slopes = torch.sqrt(_gradient_slopes_sq(discriminator, interpolates, alpha, phase, latent_dim, activation,

@@ -114,6 +114,7 @@ struct ConvFwdArgs {
   int sshift, rshift;   // v2: log2(slots per row), log2(rows per 256-byte bank row)
   int wbytes, ntiles;   // v3r: resident weight image bytes, number of spatial tiles
   int wres;             // v4: all weight slabs resident in LDS
+  int lean;             // v4: input below 2 GiB and no fused up-sampling: buffer addressing for the halo
   unsigned long long* dbg;  // diagnostic time stamps (NULL in production)
   int dbg_flags;            // diagnostic ablations (0 in production): 1 = no re-staging, 2 = no epilogue
   int vec_in, vec_out;
@@ -1476,6 +1477,7 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
   const int items = hv * 2;
   constexpr int MAXIT = 8;
   int it_rel[MAXIT];   // element offset (chunk 0) relative to the tile's first halo voxel, -1 dead
+  int it_crd[MAXIT];
   const int Di = g.ups ? (g.D >> 1) : g.D, Hi = g.ups ? (g.H >> 1) : g.H, Wi = g.ups ? (g.W >> 1) : g.W;
 #pragma unroll
   for (int k = 0; k < MAXIT; ++k) {
@@ -1489,7 +1491,12 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
     uint32_t q3 = sg_div(q2, g.fHD);
     int hd = (int)(q2 - q3 * g.HD);
     it_rel[k] = row < hv ? ((((int)q3 * g.D + hd) * g.H + hh_) * g.W + hw) * a.cin + sl * EPP : -2;   // -2: beyond the image, lane idle
+    // packed halo coordinate for the boundary test (bytes w,h,d,n, all < 128); bit 31 = second 16-byte slot
+    it_crd[k] = row < hv ? (hw | (hh_ << 8) | (hd << 16) | ((int)q3 << 24) | (sl << 31)) : 0x7F7F7F7F;
   }
+  constexpr uint32_t DEAD = 0x80000000u;        // byte offset beyond the buffer: the load returns zeros
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(a.x), 0, a.lean ? (int)((int64_t)g.N * g.D * g.H * g.W * a.cin * (int)sizeof(T)) : 0, 0x00020000);
 
   auto tile_of_item = [&](int q) { return first + (2 * (q / ncg) + grp) * per_x; };
 
@@ -1509,6 +1516,30 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
         if ((wave + 4 * k) * 64 < items && it_rel[k] != -2)   // idle lanes write nothing: the image ends at hv rows
           sg_glds16(it_rel[k] >= 0 ? (const void*)(base + it_rel[k]) : (const void*)sg_zero_page,
                     xmine + (size_t)(wave + 4 * k) * 1024);
+    } else if (a.lean) {
+      // boundary tile: a piece is valid iff its packed halo coordinate lies inside the per-tile range in every byte
+      // (two byte-parallel subtractions, guard bit 7) and its channels exist; everything else reads zeros through
+      // the buffer's bounds check.  (At <= 64^2 every tile is a W-boundary tile: this IS the common path there.)
+      const int lo_w = max(0, g.PW - o.w0), hi_w = min(g.HW, g.W + g.PW - o.w0) - 1;
+      const int lo_h = max(0, g.PH - o.h0), hi_h = min(g.HH, g.H + g.PH - o.h0) - 1;
+      const int lo_d = max(0, g.PD - o.d0), hi_d = min(g.HD, g.D + g.PD - o.d0) - 1;
+      const int hi_n = min(g.TN, g.N - o.n0) - 1;
+      const uint32_t lo = (uint32_t)(lo_w | (lo_h << 8) | (lo_d << 16));
+      const uint32_t hi = (uint32_t)(hi_w | (hi_h << 8) | (hi_d << 16) | (hi_n << 24)) | 0x80808080u;
+      const int tile_off = (int)((((((int64_t)o.n0 * g.D + (o.d0 - g.PD)) * g.H + (o.h0 - g.PH)) * g.W + (o.w0 - g.PW)) *
+                                      (int64_t)a.cin + c0) * (int)sizeof(T));
+      const bool tail = c0 + CH > a.cin;                 // the second slot's channels may not exist
+#pragma unroll
+      for (int k = 0; k < MAXIT; ++k) {
+        if ((wave + 4 * k) * 64 < items && it_rel[k] != -2) {
+          const uint32_t c_ = (uint32_t)it_crd[k] & 0x7FFFFFFFu;
+          const uint32_t t1 = (c_ | 0x80808080u) - lo, t2 = hi - c_;
+          bool ok = (t1 & t2 & 0x80808080u) == 0x80808080u;
+          if (tail) ok = ok && (c0 + (int)((uint32_t)it_crd[k] >> 31) * EPP < a.cin);
+          const uint32_t vo = ok ? (uint32_t)(it_rel[k] * (int)sizeof(T) + tile_off) : DEAD;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xmine + (size_t)(wave + 4 * k) * 1024), 16, vo, 0, 0, 0);
+        }
+      }
     } else {
 #pragma unroll 1
       for (int k = 0; k < MAXIT; ++k) {
@@ -1690,6 +1721,8 @@ static int launch_fwd4(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, b
   a.G = 1;
   a.rs = 32;
   a.xbytes = hv * 32;   // exact: lanes beyond the last row are masked off in the LDS-DMA
+  a.lean = (!s->upsample_in && (int64_t)s->n * s->d * s->h * s->w * (int64_t)s->cin * (int64_t)sizeof(T) < (1ll << 31) &&
+            !sg_env_int("SG_FWD4_NO_LEAN", 0)) ? 1 : 0;
   a.wbytes = a.taps * NTB * 1024;
   if (sg_cdiv(hv * 2, 64) > 32) return SG_OK;
   size_t lds = 2ull * a.xbytes + (size_t)a.nchunk * a.wbytes + NTB * 128;

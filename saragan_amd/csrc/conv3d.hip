@@ -1426,9 +1426,12 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
   const int r = lane & 31, hh = lane >> 5;
   // LDS map: [halo 0][halo 1][weights 0][weights 1][bias: NTB*32 floats]
   char* xmine = smem + grp * a.xbytes;
-  // a.wres: every chunk's weight slab stays resident ([chunk][tap][nt]); otherwise one slab per group, re-fetched
-  // per item
-  char* wmine = smem + 2 * a.xbytes + (a.wres ? 0 : grp * a.wbytes);
+  // a.wres: every chunk's weight slab stays resident ([chunk][tap][nt]).  Otherwise two slab buffers SHARED by the
+  // wave groups: both groups walk the chunks in lockstep (item j of either group uses chunk j % ncg, group 1 one
+  // phase after group 0), so slab j sits in buffer j & 1 for two phases while each of the two off-phases fetches
+  // one half of slab j+1 into the other buffer -- half the weight DMA of a private slab per group and item, which
+  // at 54 KiB per item was more LDS-DMA than the MFMA phase could cover.
+  char* wmine = smem + 2 * a.xbytes;
   float* bias_lds = reinterpret_cast<float*>(smem + 2 * a.xbytes + (a.wres ? a.nchunk : 2) * a.wbytes);
   const T* x = reinterpret_cast<const T*>(a.x);
   const char* wp = reinterpret_cast<const char*>(a.wp);
@@ -1566,14 +1569,16 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
         }
       }
     }
-    // weight slab of this chunk: [tap][nt] fragments
-    constexpr int nfrag = TAPS * NTB;
-    if (!a.wres)
-    for (int f = wave; f < nfrag; f += 4) {
+  };
+  // fragments [f0, f1) of the slab of item j ([tap][nt] order) into buffer j & 1, by the 4 waves of my group
+  auto stage_slab = [&](int j, int f0, int f1, int w, int nw) {
+    const int cg = j % ncg;
+    char* dst = wmine + (j & 1) * a.wbytes;
+    for (int f = f0 + w; f < f1; f += nw) {
       const int tap = f / NTB, nt = f - tap * NTB;
       const char* src = nt < ntb ? wp + ((((int64_t)cg * TAPS + tap) * a.ntile + (nt0 + nt)) << 10)
                                  : reinterpret_cast<const char*>(sg_zero_page);
-      sg_glds16(src + lane * 16, wmine + ((size_t)f << 10));
+      sg_glds16(src + lane * 16, dst + ((size_t)f << 10));
     }
   };
 
@@ -1592,6 +1597,7 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
       sg_glds16(src + lane * 16, wmine + ((size_t)f << 10));
     }
   }
+  if (!a.wres && items_max > 0) stage_slab(0, 0, TAPS * NTB, wave8, 8);
   if (grp == 0 && items_mine > 0) stage_item(0);
   __syncthreads();
 
@@ -1613,7 +1619,7 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
 #pragma unroll
               for (int i = 0; i < 16; ++i) acc[mt][nt][i] = bias_lds[nt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];
         }
-        sg_unrolled_k4<T, MTW, NTB, TAPS, 3>::run(acc, xaddr, (int)(wl - smem) + (a.wres ? (q % ncg) * a.wbytes : 0));
+        sg_unrolled_k4<T, MTW, NTB, TAPS, 3>::run(acc, xaddr, (int)(wl - smem) + (a.wres ? (q % ncg) : (q & 1)) * a.wbytes);
       }
     } else {
       // my next item is q' = (p + 1) >> 1; my previous one q' - 1 (ran in phase p - 1)
@@ -1636,6 +1642,10 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
         }
       }
       if (qn < items_mine) stage_item(qn);
+      if (!a.wres && (p >> 1) + 1 < items_max) {   // my half of the next item's slab (phase parity picks the half)
+        constexpr int nfrag = TAPS * NTB, hf = (nfrag + 1) / 2;
+        stage_slab((p >> 1) + 1, (p & 1) ? hf : 0, (p & 1) ? nfrag : hf, wave, 4);
+      }
       if (closes) {
         const sg_tile_origin o = sg_tile_of(g, (uint32_t)tile_of_item(qp));
 #pragma unroll

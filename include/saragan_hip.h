@@ -116,6 +116,12 @@ int sg_pixel_norm_fwd(const void* x, void* y, float* scale, int64_t nvox, int32_
 /* dx = scale * (dy - y * mean_c(dy*y)),  y = forward OUTPUT, scale = forward rsqrt factor. */
 int sg_pixel_norm_bwd(const void* dy, const void* y, const float* scale, void* dx, int64_t nvox,
                       int32_t c, sg_dtype dt, sg_stream_t st);
+/* Gradient of y = pixel_norm(leaky_relu(z + b)) (one generator stage, pgan/generator.py:49-71) in one pass:
+ * dz = mask(sign words of y) * pixel_norm_bwd(dy), dbias (optional, [c] f32) = sum_v dz.
+ * workspace >= sg_bias_act_bwd_workspace(c) when dbias is given. */
+int sg_pixel_norm_act_bwd(const void* dy, const void* y, const float* scale, const void* y_sign_words, float slope,
+                          void* dz, float* dbias, void* workspace, int64_t nvox, int32_t c, sg_dtype dt,
+                          sg_stream_t st);
 /* y[n,2d,2h,2w,c] = gain * x[n,d,h,w,c] nearest-neighbour    (upscale3d / avg_unpool3d, ops.py:250-262) */
 int sg_upscale2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
                  float gain, sg_dtype dt, sg_stream_t st);

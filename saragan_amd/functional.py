@@ -203,6 +203,18 @@ def raw_bias_act_bwd(dy, y, slope, want_dx=True, want_db=False):
 # autograd Functions
 # ---------------------------------------------------------------------------------------------------
 _NO_SIGN_WORDS = bool(int(os.environ.get('SARAGAN_NO_SIGN_WORDS', '0')))   # diagnostic: activation-based masks only
+_ZERO = {}
+
+
+def _zero_scalar(like):
+    """A shared 0-d placeholder for 'no bias gradient' outputs (a fresh new_zeros(()) is one fill launch each,
+    ~60 per step)."""
+    z = _ZERO.get(like.device)
+    if z is None:
+        z = _ZERO[like.device] = torch.zeros((), device=like.device, dtype=torch.float32)
+    return z.detach()    # a new tensor object over the same storage: autograd may tag it per Function
+
+
 _SKIP = {'ptrs': frozenset()}
 
 
@@ -293,7 +305,7 @@ class _Wgrad(torch.autograd.Function):
         ctx.k, ctx.coef, ctx.ups = k, coef, ups
         dw, db = raw_wgrad(x, dy, k, coef, ups, want_db)
         if db is None:
-            db = dw.new_zeros(())
+            db = _zero_scalar(dw)
         ctx.mark_non_differentiable(db)
         return dw, db
 
@@ -332,12 +344,17 @@ class _ConvBiasAct(torch.autograd.Function):
         x, w, y, scale, signs = ctx.saved_tensors
         coef, ups, act, slope, pixel_norm = ctx.cfg
         g = gy
-        if pixel_norm:
-            g = _PixelNormBwd.apply(g, y, scale)
         want_db = ctx.has_b and _wants(ctx, 2, ctx.b_ptr)
         gb = None
+        fused_pn_act = pixel_norm and act and signs is not None
+        if fused_pn_act:
+            g, gb = _PnActBwd.apply(g, y.detach(), scale, signs, slope, want_db)
+            if not want_db:
+                gb = None
+        elif pixel_norm:
+            g = _PixelNormBwd.apply(g, y, scale)
         premasked = act and not pixel_norm and _masked_in(ctx.out_info)   # every consumer already applied my mask
-        if act and not premasked:
+        if act and not premasked and not fused_pn_act:
             g, gb = _BiasActBwd.apply(g, signs if signs is not None else y.detach(), slope, want_db)
         gx = gw = None
         if ctx.needs_input_grad[0]:
@@ -369,7 +386,7 @@ class _BiasActBwd(torch.autograd.Function):
         ctx.save_for_backward(y)
         ctx.slope = slope
         if db is None:
-            db = dy.new_zeros(())
+            db = _zero_scalar(dy)
         ctx.mark_non_differentiable(db)
         return dx, db
 
@@ -442,6 +459,34 @@ class _PixelNormBwd(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        raise NotImplementedError('second-order gradient through pixel_norm is not part of the pgan step')
+
+
+class _PnActBwd(torch.autograd.Function):
+    """dz, db of y = pixel_norm(leaky_relu(z + b)) from dy in one pass (sg_pixel_norm_act_bwd); once-differentiable
+    like _PixelNormBwd."""
+
+    @staticmethod
+    def forward(ctx, gy, y, scale, signs, slope, want_db):
+        lib = _lib.load()
+        gy, y = ndhwc(gy), ndhwc(y)
+        n, c, d, h, w = _dims(gy)
+        nvox = n * d * h * w
+        _check_signs(signs, nvox, c)
+        dz = torch.empty_like(gy)
+        db = ws = None
+        if want_db:
+            db = torch.empty(c, device=gy.device, dtype=torch.float32)
+            ws = torch.empty(lib.sg_bias_act_bwd_workspace(c), device=gy.device, dtype=torch.uint8)
+        check(lib.sg_pixel_norm_act_bwd(_ptr(gy), _ptr(y), _ptr(scale), _ptr(signs), float(slope), _ptr(dz), _ptr(db),
+                                        _ptr(ws), nvox, c, _dt(gy), _stream()), 'sg_pixel_norm_act_bwd')
+        if db is None:
+            db = _zero_scalar(gy)
+        ctx.mark_non_differentiable(db)
+        return dz, db
+
+    @staticmethod
+    def backward(ctx, g, _gdb):
         raise NotImplementedError('second-order gradient through pixel_norm is not part of the pgan step')
 
 

@@ -1073,6 +1073,58 @@ struct sg_unrolled_ks {
   }
 };
 
+// Same K loop with each halo fragment read ONCE for both M tiles: the tile's two M tiles are consecutive D planes,
+// so halo plane p (0..3) is tap kd = p of M tile 0 and tap kd = p - 1 of M tile 1.  Step s = (kh, kw, chunk) * 4 + p:
+// reads X[p] and, for p < 3, W[kd = p]; MFMAs acc0 += W[p] X[p] (p <= 2) and acc1 += W[p-1] X[p] (p >= 1).
+// 7 fragment reads per 6 MFMAs instead of 9: the MFMA phases run at the board's power cap, and LDS reads are a
+// large part of what they burn.
+template <typename T, int GC, int ROT, int RING>
+struct sg_unrolled_ks2 {
+  static constexpr int NG = 9 * GC, NS = NG * 4, PF = RING - 2;
+  static constexpr int PB = (GC == 1 ? 224 : 208) * GC * 32;
+  static constexpr int nloads(int st) { return st >= NS ? 0 : ((st & 3) < 3 ? 2 : 1); }
+  static constexpr int younger(int st) {   // reads issued after step st's own loads at the time step st computes
+    int n = 0;
+    for (int t = st + 1; t <= st + PF; ++t) n += nloads(t);
+    return n;
+  }
+  template <int ST>
+  static __device__ __forceinline__ void load(u32x4 (&wfr)[RING], u32x4 (&xfr)[RING], const int (&xa)[9][GC], int wl_off) {
+    constexpr int SL = ST % RING, grp_ = ST >> 2, pl = ST & 3, khw = grp_ / GC, gi = grp_ % GC;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xfr[SL]) : "v"(xa[khw][gi]), "n"(((pl + ROT) & 3) * PB));
+    if constexpr (pl < 3) {   // weight fragment of tap (kd = pl, kh, kw), chunk gi: image order [tap][gi]
+      constexpr int frag = (pl * 9 + khw) * GC + gi;
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wfr[SL]) : "v"(wl_off), "n"(frag << 10));
+    }
+  }
+  template <int ST>
+  static __device__ __forceinline__ void step(f32x16 (&acc)[2], u32x4 (&wfr)[RING], u32x4 (&xfr)[RING],
+                                              const int (&xa)[9][GC], int wl_off) {
+    if constexpr (ST < NS) {
+      if constexpr (ST + PF < NS) load<ST + PF>(wfr, xfr, xa, wl_off);
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger(ST)));
+      __builtin_amdgcn_sched_barrier(0);
+      constexpr int pl = ST & 3;
+      if constexpr (pl <= 2) acc[0] = sg_mfma_chunk<T>(wfr[ST % RING], xfr[ST % RING], acc[0]);
+      if constexpr (pl >= 1) acc[1] = sg_mfma_chunk<T>(wfr[(ST - 1) % RING], xfr[ST % RING], acc[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      step<ST + 1>(acc, wfr, xfr, xa, wl_off);
+    }
+  }
+  template <int ST>
+  static __device__ __forceinline__ void prologue(u32x4 (&wfr)[RING], u32x4 (&xfr)[RING], const int (&xa)[9][GC], int wl_off) {
+    if constexpr (ST < PF && ST < NS) {
+      load<ST>(wfr, xfr, xa, wl_off);
+      prologue<ST + 1>(wfr, xfr, xa, wl_off);
+    }
+  }
+  static __device__ __forceinline__ void run(f32x16 (&acc)[2], const int (&xa)[9][GC], int wl_off) {
+    u32x4 wfr[RING], xfr[RING];
+    prologue<0>(wfr, xfr, xa, wl_off);
+    step<0>(acc, wfr, xfr, xa, wl_off);
+  }
+};
+
 template <typename T, int GC>
 __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1272,8 +1324,11 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
           for (int i = 0; i < 16; ++i) acc[mt][i] = bias_lds[(i & 3) + 8 * (i >> 2) + 4 * hh];   // bias rides in C
         const int di = q % g.nTd;
         if (a.dbg_flags & 8) { /* diagnostic: no MFMA phase */ }
-        else if (di & 1) sg_unrolled_ks<T, GC, 1, 3>::run(acc, xa, wl_off);
-        else sg_unrolled_ks<T, GC, 3, 3>::run(acc, xa, wl_off);
+        else if (a.dbg_flags & 32) {   // diagnostic: the 9-reads-per-6-MFMAs loop
+          if (di & 1) sg_unrolled_ks<T, GC, 1, 3>::run(acc, xa, wl_off);
+          else sg_unrolled_ks<T, GC, 3, 3>::run(acc, xa, wl_off);
+        } else if (di & 1) sg_unrolled_ks2<T, GC, 1, 6>::run(acc, xa, wl_off);
+        else sg_unrolled_ks2<T, GC, 3, 6>::run(acc, xa, wl_off);
       }
     } else {
       const int qn = (p + 1) >> 1, qp = qn - 1;      // my next / previous item

@@ -77,9 +77,12 @@ __global__ __launch_bounds__(256) void bias_act_bwd_vec_kernel(const T* __restri
                                                                const uint32_t* __restrict__ words) {
   constexpr int E = Piece<T>::E;
   __shared__ float red[256 * E];
-  const int P = c / E;            // divides 256
+  // more than 256 pieces per row (dense layers, c = 8192): blockIdx.y selects a 256-piece channel slice
+  const int Pall = c / E;
+  const int P = Pall > 256 ? 256 : Pall;   // divides 256
+  const int pofs = blockIdx.y * 256;
   const int rows = 256 / P;       // voxel rows per block step
-  const int p = threadIdx.x % P, rr = threadIdx.x / P;
+  const int p = pofs + threadIdx.x % P, rr = threadIdx.x / P;
   float s[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) s[e] = 0.f;
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_vec_kernel(const T* __restri
       for (int e = 0; e < E; ++e) {
         float t = 0.f;
         for (int k = 0; k < rows; ++k) t += red[(k * P + threadIdx.x) * E + e];
-        part[(int64_t)blockIdx.x * c + threadIdx.x * E + e] = t;
+        part[(int64_t)blockIdx.x * c + (pofs + threadIdx.x) * E + e] = t;
       }
     }
   }
@@ -374,6 +377,41 @@ __global__ void upscale2x_kernel(const T* __restrict__ x, T* __restrict__ y, int
   }
 }
 
+// Row-wise variant for the vector case: one block per output row (n, od, oh) -- scalar index arithmetic once per
+// block instead of 64-bit divisions per 16-byte piece (the flat kernel reached 3 TB/s).
+template <typename T>
+__global__ __launch_bounds__(256) void upscale2x_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int d, int h, int w,
+                                                             int c, float gain, const uint32_t* __restrict__ mask_bits,
+                                                             float mask_slope, int64_t nrows) {
+  constexpr int E = Piece<T>::E;
+  const int P = c / E, nw = (c + 31) >> 5;
+  const int per_row = 2 * w * P;
+  for (int64_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+    const int oh = (int)(row % (2 * h));
+    const int64_t q = row / (2 * h);
+    const int od = (int)(q % (2 * d));
+    const int64_t nn = q / (2 * d);
+    const T* xrow = x + (((nn * d + (od >> 1)) * h + (oh >> 1)) * (int64_t)w) * c;
+    T* yrow = y + row * (int64_t)(2 * w) * c;
+    const uint32_t* mrow = mask_bits ? mask_bits + row * (int64_t)(2 * w) * nw : nullptr;
+    for (int i = threadIdx.x; i < per_row; i += 256) {
+      const int ow = i / P, p = i - ow * P;
+      Piece<T> pc;
+      pc.load(xrow + (int64_t)(ow >> 1) * c + p * E);
+      if (gain != 1.f) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) pc.v[e] *= gain;
+      }
+      if (mrow) {
+        const uint32_t sw = mrow[ow * nw + ((p * E) >> 5)] >> ((p * E) & 31);
+#pragma unroll
+        for (int e = 0; e < E; ++e) pc.v[e] = ((sw >> e) & 1u) ? pc.v[e] * mask_slope : pc.v[e];
+      }
+      pc.store(yrow + (int64_t)i * E);
+    }
+  }
+}
+
 template <typename T, bool VEC>
 __global__ void downscale2x_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int d, int h, int w, int c,
                                    float gain) {
@@ -588,14 +626,15 @@ static int bias_act_bwd_launch(const void* dy, const void* y, const uint32_t* wo
   hipStream_t hs = sg_st(st);
   const int E = dt == SG_BF16 ? 8 : 4;
   const int P = c / E;
-  const bool vec = (c % E == 0) && P <= 256 && (256 % P == 0) && sg_aligned16(dy) && (!y || sg_aligned16(y)) &&
-                   (!dx || sg_aligned16(dx));
+  const bool vec = (c % E == 0) && ((P <= 256 && 256 % P == 0) || P % 256 == 0) && sg_aligned16(dy) &&
+                   (!y || sg_aligned16(y)) && (!dx || sg_aligned16(dx));
   float* part = dbias ? reinterpret_cast<float*>(workspace) : nullptr;
   int blocks;
   if (vec) {
-    const int rows = 256 / P;
+    const int rows = P >= 256 ? 1 : 256 / P;
+    const int ny = P > 256 ? P / 256 : 1;
     blocks = grid_for(nvox, rows, kBwdBlocks);
-#define L(T) hipLaunchKernelGGL((bias_act_bwd_vec_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)dy, (const T*)y, (T*)dx, part, nvox, c, slope, words)
+#define L(T) hipLaunchKernelGGL((bias_act_bwd_vec_kernel<T>), dim3(blocks, ny), dim3(256), 0, hs, (const T*)dy, (const T*)y, (T*)dx, part, nvox, c, slope, words)
     SG_DISPATCH(dt, L(bf16_t), L(float));
 #undef L
   } else if (c <= 8) {
@@ -719,6 +758,15 @@ extern "C" int sg_upscale2x_masked(const void* x, void* y, const void* mask_bits
   hipStream_t hs = sg_st(st);
   const int E = dt == SG_BF16 ? 8 : 4;
   const bool vec = (c % E == 0) && sg_aligned16(x) && sg_aligned16(y);
+  if (vec && 2 * w * (c / E) >= 128) {   // enough pieces per output row to fill a block
+    const int64_t nrows = (int64_t)n * 2 * d * 2 * h;
+    const int rb = (int)(nrows < 16384 ? nrows : 16384);
+#define LR(T) hipLaunchKernelGGL((upscale2x_rows_kernel<T>), dim3(rb), dim3(256), 0, hs, (const T*)x, (T*)y, d, h, w, c, gain, (const uint32_t*)mask_bits, mask_slope, nrows)
+    SG_DISPATCH(dt, LR(bf16_t), LR(float));
+#undef LR
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+  }
   const int64_t items = (int64_t)n * d * h * w * 8 * (vec ? c / E : c);
   const int blocks = grid_for(items, 256, 4096);
 #define L(T, V) hipLaunchKernelGGL((upscale2x_kernel<T, V>), dim3(blocks), dim3(256), 0, hs, (const T*)x, (T*)y, n, d, h, w, c, gain, (const uint32_t*)mask_bits, mask_slope)

@@ -197,15 +197,17 @@ def test_conv_mask_epilogue_and_wgrad_bias(case, dtype):
 
 
 @pytest.mark.parametrize('dtype', DT)
-def test_upscale2x_masked(dtype):
+@pytest.mark.parametrize('shape', [(2, 16, 3, 4, 5), (2, 64, 2, 3, 16)])   # flat kernel / row-wise kernel
+def test_upscale2x_masked(shape, dtype):
     from saragan_amd import functional as F
-    x = rnd((2, 16, 3, 4, 5), 21, dtype)
-    m = rnd((2, 16, 6, 8, 10), 22, dtype)
+    n_, c_, d_, h_, w_ = shape
+    x = rnd(shape, 21, dtype)
+    m = rnd((n_, c_, 2 * d_, 2 * h_, 2 * w_), 22, dtype)
     ref = 0.125 * O.upscale3d(x) * torch.where(m >= 0, 1.0, 0.2)
     got = F._Up.apply(cl(x, dtype), 0.125, F.sign_words(cl(m, dtype)), 0.2)
     close(got, ref, dtype)
     # the stand-alone LeakyReLU backward with sign words instead of the activation
-    g = rnd((2, 16, 6, 8, 10), 23, dtype)
+    g = rnd(tuple(m.shape), 23, dtype)
     dx, db = F.raw_bias_act_bwd(cl(g, dtype), F.sign_words(cl(m, dtype)), 0.2, True, True)
     refdx = g * torch.where(m >= 0, 1.0, 0.2)
     close(dx, refdx, dtype)
@@ -307,7 +309,7 @@ def test_dense(shape, dtype):
 
 
 @pytest.mark.parametrize('dtype', DT)
-@pytest.mark.parametrize('c', [1, 8, 12, 32, 256])
+@pytest.mark.parametrize('c', [1, 8, 12, 32, 256, 4096])
 def test_elementwise_ops(dtype, c):
     from saragan_amd import functional as F
     x = rnd((3, c, 2, 4, 6), 11, dtype)

@@ -15,18 +15,22 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from saragan_amd import _lib  # noqa: E402
 from saragan_amd._lib import ConvEpilogue, ConvShape  # noqa: E402
 
-SHAPES = [  # (d,h,w), cin, cout  (all 3x3x3), the >= 2 ms/step entries of `bench.py --dump-prof`
-    ((32, 128, 128), 32, 32),
-    ((32, 128, 128), 32, 64),
-    ((32, 128, 128), 64, 32),
-    ((16, 64, 64), 64, 64),
-    ((16, 64, 64), 64, 128),
-    ((8, 32, 32), 128, 128),
+SHAPES = [  # n, (d,h,w), cin, cout  (all 3x3x3): the >= 1 ms/step entries of `bench.py --dump-prof`; n = 32 is the
+    # concatenated real+fake batch of the discriminator, n = 16 the generator / gradient-penalty passes
+    (32, (32, 128, 128), 64, 32),
+    (32, (32, 128, 128), 32, 32),
+    (32, (32, 128, 128), 32, 64),
+    (16, (32, 128, 128), 32, 32),
+    (16, (32, 128, 128), 32, 64),
+    (16, (32, 128, 128), 64, 32),
+    (32, (16, 64, 64), 64, 64),
+    (32, (16, 64, 64), 64, 128),
+    (32, (16, 64, 64), 128, 64),
+    (32, (8, 32, 32), 128, 128),
 ]
 
 
 def main():
-    n = int(os.environ.get('PROBE_BATCH', '16'))
     lib = _lib.load()
     dt = _lib.SG_BF16
     dev = torch.device('cuda:0')
@@ -40,7 +44,7 @@ def main():
         _lib.check(lib.sg_axpby(a.data_ptr(), b.data_ptr(), o.data_ptr(), 1.0, 0.5, numel, dt, st))
     torch.cuda.synchronize()
     del a, b, o
-    for (d, h, w), cin, cout in SHAPES:
+    for n, (d, h, w), cin, cout in SHAPES:
         shp = ConvShape(n, d, h, w, cin, cout, 3, 3, 3, 0)
         x = torch.randn(n, d, h, w, cin, device=dev).to(torch.bfloat16)
         dy = torch.randn(n, d, h, w, cout, device=dev).to(torch.bfloat16)

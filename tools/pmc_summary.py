@@ -31,12 +31,11 @@ def main():
         return [r for r in rows if any(k in r['Kernel_Name'] for k in ('conv_fwd', 'conv_wgrad'))]
     cr, cw = convs(R), convs(W)
     assert len(cr) == len(cw) == 6 * len(SHAPES), (len(cr), len(cw))
-    n = 16
-    res = {'unit': 'bytes per launch', 'batch': n, 'dtype': 'bf16',
+    res = {'unit': 'bytes per launch', 'dtype': 'bf16',
            'correction': 'FETCH_SIZE KiB x 2 (gfx950 wide reads), WRITE_SIZE KiB x 1',
            'calibration': {'axpby_read_GiB': 2 * cal_r[-1] / (1 << 20), 'axpby_write_GiB': cal_w[-1] / (1 << 20)},
            'entries': []}
-    for i, ((d, h, w), cin, cout) in enumerate(SHAPES):
+    for i, (n, (d, h, w), cin, cout) in enumerate(SHAPES):
         blk_r, blk_w = cr[6 * i:6 * i + 6], cw[6 * i:6 * i + 6]
         vox = n * d * h * w
         for j, (kind, variant) in enumerate((('fwd', 'bias+lrelu+sign_out'), ('fwd', 'mask_bits'), ('wgrad', 'with dbias'))):

@@ -74,6 +74,10 @@ def load():
         raise ImportError(
             f'{LIB_PATH} not found: build it with `python -m saragan_amd.build` (hipcc, gfx950). '
             'There is no CPU or PyTorch fallback for the HIP path.')
+    # torch first: it ships its own libamdhip64, and the library must bind to THAT runtime (device memory and
+    # streams come from torch).  Loaded the other way round, the system ROCm runtime initialises first and the
+    # process ends up with two HIP runtimes, one of which sees no device.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported

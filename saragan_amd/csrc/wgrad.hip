@@ -361,8 +361,12 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a) {
   const int qd = i16 >> 2, pp = i16 & 3;
   const int colb = (16 * (q16 & 1) + 4 * pp) * 2;
   const int kb = 8 * (q16 >> 1) + qd;
-  // lane-constant byte offsets of the two reads of a K step (rows kb, kb+4 of the 16-voxel run)
-  const int xl0 = (int)(xmine - smem) + kb * 64 + colb, xl1 = xl0 + 4 * 64;
+  // lane-constant byte offsets of the two reads of a K step (voxels kb, kb+4 of the 16-voxel run).  In the halo
+  // image a run narrower than 16 voxels (tiles with TW = 4 or 8: the low-resolution layers) continues on the next
+  // H row, HW rows further; the dy image is voxel-linear.
+  const int twr = g.TW < 16 ? g.TW : 16;
+  auto xrow = [&](int kk) { return ((kk / twr) * g.HW + (kk % twr)) * 64; };
+  const int xl0 = (int)(xmine - smem) + xrow(kb) + colb, xl1 = (int)(xmine - smem) + xrow(kb + 4) + colb;
   const int yl0 = (int)(ymine - smem) + kb * 64 + colb, yl1 = yl0 + 4 * 64;
 
   // halo staging tables: element offset relative to the tile's first halo voxel (-1: dead piece)
@@ -482,30 +486,31 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a) {
   for (int p = 0; p <= K; ++p) {
     if ((p & 1) == grp) {
       if (p < K) {
-        int td = 0, th = 0;
-        for (int line = 0; line < KSTEPS / 2; ++line) {      // one (td, th) line of 32 voxels = 2 K steps
-          const int xl = ((td * g.HH + th) * g.HW) * 64;
-          if (++th == g.TH) { th = 0; ++td; }
+        for (int run = 0; run < KSTEPS; ++run) {               // 16 consecutive tile voxels = one K step
+          const uint32_t m0 = (uint32_t)run * 16u;
+          const uint32_t q1 = sg_div(m0, g.fTW);
+          const int tw0 = (int)(m0 - q1 * g.TW);
+          const uint32_t q2 = sg_div(q1, g.fTH);
+          const int th = (int)(q1 - q2 * g.TH);
+          const uint32_t q3 = sg_div(q2, g.fTD);
+          const int td = (int)(q2 - q3 * g.TD);
+          const int xline = ((((int)q3 * g.HD + td) * g.HH + th) * g.HW + tw0) * 64;
+          const int yline = run * 16 * 64;
+          s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(smem + yl0 + yline));
+          s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(smem + yl1 + yline));
+          u32x4 bf;
+          bf[0] = __builtin_bit_cast(u32x2, b0)[0]; bf[1] = __builtin_bit_cast(u32x2, b0)[1];
+          bf[2] = __builtin_bit_cast(u32x2, b1)[0]; bf[3] = __builtin_bit_cast(u32x2, b1)[1];
 #pragma unroll
-          for (int half = 0; half < 2; ++half) {
-            const int xline = xl + half * 16 * 64;
-            const int yline = (line * 2 + half) * 16 * 64;
-            s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(smem + yl0 + yline));
-            s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(smem + yl1 + yline));
-            u32x4 bf;
-            bf[0] = __builtin_bit_cast(u32x2, b0)[0]; bf[1] = __builtin_bit_cast(u32x2, b0)[1];
-            bf[2] = __builtin_bit_cast(u32x2, b1)[0]; bf[3] = __builtin_bit_cast(u32x2, b1)[1];
-#pragma unroll
-            for (int j = 0; j < MAXT; ++j) {
-              if (wave + 4 * j < TAPS) {
-                s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(smem + xl0 + xline + tapoff[j]));
-                s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(smem + xl1 + xline + tapoff[j]));
-                u32x4 af;
-                af[0] = __builtin_bit_cast(u32x2, a0)[0]; af[1] = __builtin_bit_cast(u32x2, a0)[1];
-                af[2] = __builtin_bit_cast(u32x2, a1)[0]; af[3] = __builtin_bit_cast(u32x2, a1)[1];
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af),
-                                                                __builtin_bit_cast(bf16x8, bf), acc[j], 0, 0, 0);
-              }
+          for (int j = 0; j < MAXT; ++j) {
+            if (wave + 4 * j < TAPS) {
+              s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(smem + xl0 + xline + tapoff[j]));
+              s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(smem + xl1 + xline + tapoff[j]));
+              u32x4 af;
+              af[0] = __builtin_bit_cast(u32x2, a0)[0]; af[1] = __builtin_bit_cast(u32x2, a0)[1];
+              af[2] = __builtin_bit_cast(u32x2, a1)[0]; af[3] = __builtin_bit_cast(u32x2, a1)[1];
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af),
+                                                              __builtin_bit_cast(bf16x8, bf), acc[j], 0, 0, 0);
             }
           }
         }
@@ -535,7 +540,10 @@ static int launch_wgrad2(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   *used = false;
   a.g = sg_make_geom(s, 256, /*prefer_w32=*/true);
   const sg_tile_geom& g = a.g;
-  if (g.TW != 32 || g.TN != 1 || g.TD * g.TH * g.TW != 256) return SG_OK;
+  // 256-voxel tiles whose 16-voxel K steps are whole W rows (TW = 16) or half rows (TW = 32).  The kernel also
+  // runs 8-wide tiles, but measured on the 2x8x8 layers (256 cin/cout pairs, 8-16 tiles) it loses to the v1 kernel.
+  if (g.TW < 16 || g.TN * g.TD * g.TH * g.TW != 256) return SG_OK;
+  if (g.TN > 127 || g.HD > 127 || g.HH > 127 || g.HW > 127) return SG_OK;
   if ((s->cin % 8) || (s->cout % 8)) return SG_OK;
   if ((int64_t)s->n * s->d * s->h * s->w * (int64_t)(s->cin > s->cout ? s->cin : s->cout) >= (1ll << 31)) return SG_OK;
   const int64_t ntiles = (int64_t)g.nTn * g.nTd * g.nTh * g.nTw;

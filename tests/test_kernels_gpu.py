@@ -61,6 +61,8 @@ CONV_CASES = [
     (2, 32, 32, (6, 128, 256), (3, 3, 3)),   # 512 tile columns: sliding-halo wgrad and forward (ring of D planes)
     (2, 16, 32, (5, 126, 256), (3, 3, 3)),   # sliding-halo forward, one 32-byte chunk, ragged D and H
     (2, 32, 64, (4, 64, 256), (3, 3, 3)),    # sliding-halo forward, two cout slices
+    (32, 128, 128, (2, 8, 8), (1, 3, 3)),    # ping-pong wgrad on 8-wide tiles spanning two samples (TN = 2)
+    (16, 64, 128, (4, 16, 16), (3, 3, 3)),   # ping-pong wgrad on 16-wide tiles
 ]
 
 

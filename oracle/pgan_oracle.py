@@ -522,6 +522,36 @@ def step_simultaneous(p: Params, adam_g: TFAdam, adam_d: TFAdam, shadow: Optiona
                 gen_sample=gen_sample.detach(), g_grads=g_grads, d_grads=d_grads)
 
 
+def step_alternate(p: Params, adam_g: TFAdam, adam_d: TFAdam, shadow: Optional[Params], rnd: dict,
+                   real, alpha, cfg: dict, g_lr: float, d_lr: float, freeze: Optional[Sequence[str]] = None,
+                   ema_beta: float = 0.99):
+    """One `alternate` optimisation step (optimization.py:165-220): the discriminator is updated from
+    forward_discriminator's loss first; under tf.control_dependencies([train_disc]) the generator loss is then built
+    on the UPDATED discriminator and the generator is updated.  Both loss builders draw their own randomness in the
+    reference; with injected randomness they are fed the same z / noise tensors (as the product's InjectedRandom does)."""
+    gnames, dnames = split_vars(p)
+    if freeze is not None:
+        fz = set(freeze)
+        gnames = [k for k in gnames if k not in fz]
+        dnames = [k for k in dnames if k not in fz]
+    gcfg = {k: v for k, v in cfg.items() if k != 'gp_weight'}
+    work = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    disc_loss, gp_loss = forward_discriminator(work, real, rnd['z'], rnd['noise_real'], rnd['noise_fake'], rnd['gamma'],
+                                               alpha, **cfg)
+    d_grads = torch.autograd.grad(disc_loss, [work[k] for k in dnames])
+    d_grads = dict(zip(dnames, [g.detach() for g in d_grads]))
+    adam_d.apply(p, d_grads, d_lr)
+    work = {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+    gen_sample, gen_loss = forward_generator(work, real, rnd['z'], rnd['noise_real'], rnd['noise_fake'], alpha, **gcfg)
+    g_grads = torch.autograd.grad(gen_loss, [work[k] for k in gnames])
+    g_grads = dict(zip(gnames, [g.detach() for g in g_grads]))
+    adam_g.apply(p, g_grads, g_lr)
+    if shadow is not None:
+        ema_update(shadow, p, ema_beta)
+    return dict(gen_loss=gen_loss.detach(), disc_loss=disc_loss.detach(), gp_loss=gp_loss.detach(),
+                gen_sample=gen_sample.detach(), g_grads=g_grads, d_grads=d_grads)
+
+
 def draw_randomness(n, latent_dim, img_shape, seed, dtype=torch.float64):
     """The four random tensors of loss.py:116-133, drawn from a seeded torch generator."""
     gen = torch.Generator().manual_seed(seed)

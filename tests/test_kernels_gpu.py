@@ -63,6 +63,9 @@ CONV_CASES = [
     (2, 32, 64, (4, 64, 256), (3, 3, 3)),    # sliding-halo forward, two cout slices
     (32, 128, 128, (2, 8, 8), (1, 3, 3)),    # ping-pong wgrad on 8-wide tiles spanning two samples (TN = 2)
     (16, 64, 128, (4, 16, 16), (3, 3, 3)),   # ping-pong wgrad on 16-wide tiles
+    (2, 32, 32, (1, 128, 256), (1, 3, 3)),   # 2-D image shapes (SURFGAN_2D, D = 1): persistent kernels, (1,3,3) taps
+    (2, 3, 16, (1, 16, 16), (1, 1, 1)),      # 2-D from_rgb on RGB images
+    (2, 16, 3, (1, 16, 16), (1, 1, 1)),      # 2-D to_rgb
 ]
 
 

@@ -16,7 +16,7 @@ FIXTURES = ['oracle_step_p1_wgan_a000.npz', 'oracle_step_p2_wgan_a060.npz', 'ora
             'oracle_step_p3_wgan_a000.npz']
 
 
-def _build(fx, dtype):
+def _build(fx, dtype, strategy='simultaneous'):
     import saragan_amd.optimization as opt
     from saragan_amd.ExtendedEMA import ExtendedEMA
     from saragan_amd.networks import loss as L
@@ -36,7 +36,7 @@ def _build(fx, dtype):
     with use_store(store):
         tup = opt.optimize_step(og, od, generator, discriminator, ph, LATENT, alpha, fx['phase'], BASE_SHAPE,
                                 KERNEL_SPEC, FILTER_SPEC, 'leaky_relu', 0.2, fx['loss_fn'], cfg['gp_weight'],
-                                'simultaneous', False, False, 0.01, freeze if freeze is not None else None)
+                                strategy, False, False, 0.01, freeze if freeze is not None else None)
     store.load_state_dict({k: v for k, v in fx['p0'].items()}, strict=True)
     graph = tup[0].graph
     ema = ExtendedEMA(list(store.vars.keys()), 0.99, graph=graph)
@@ -102,6 +102,35 @@ def test_step_bf16_close_to_oracle(golden_dir, name):
     np.testing.assert_allclose(gs.double().cpu().numpy(), ref, rtol=3e-2, atol=3e-2 * np.abs(ref).max())
     from saragan_amd.varstore import set_compute_dtype
     set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('name', [FIXTURES[1], FIXTURES[2]])   # wgan while mixing (freeze ops), logistic
+def test_alternate_step_matches_oracle_fp32(golden_dir, name):
+    """optim_strategy 'alternate' (optimization.py:165-220): D step from forward_discriminator's loss (GP over all of
+    (c,d,h,w), loss.py:79), then the G loss on the UPDATED discriminator.  The oracle is replayed here in fp64 from
+    the fixture's initial weights and randomness."""
+    from oracle import pgan_oracle as O
+    fx = load_step_fixture(os.path.join(golden_dir, name), torch.float64)
+    store, tup, ph, ema, sess = _build(fx, torch.float32, strategy='alternate')
+    mixing = fx['freeze'] is not None
+    tg, td = (tup[12], tup[16]) if mixing else (tup[0], tup[1])
+    gg_h, dg_h = (tup[13], tup[17]) if mixing else (tup[6], tup[8])
+    gv, dv = (tup[14], tup[18]) if mixing else (tup[7], tup[9])
+    _, _, gl, dl, gs, gg, dg = sess.run([tg, td, tup[2], tup[3], tup[5], gg_h, dg_h], feed_dict={ph: fx['real'].float()})
+    p = {k: v.clone() for k, v in fx['p0'].items()}
+    ref = O.step_alternate(p, O.TFAdam(0.0, 0.9), O.TFAdam(0.0, 0.9), None, fx['rnd'], fx['real'], fx['alpha'],
+                           fx['cfg'], 1e-3, 1e-3, freeze=fx['freeze'])
+    np.testing.assert_allclose(float(dl), float(ref['disc_loss']), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(float(gl), float(ref['gen_loss']), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gs.double().cpu().numpy(), ref['gen_sample'].numpy(), rtol=1e-4, atol=1e-5)
+    for handle_vars, grads, refs in ((gv, gg, ref['g_grads']), (dv, dg, ref['d_grads'])):
+        assert [v.key for v in handle_vars] == list(refs.keys())
+        for v, g in zip(handle_vars, grads):
+            r = refs[v.key].numpy()
+            np.testing.assert_allclose(g.double().cpu().numpy(), r, rtol=1e-3, atol=1e-4 * np.abs(r).max() + 1e-9,
+                                       err_msg=v.key)
+    for k, v in store.vars.items():   # weights after the D-then-G updates
+        np.testing.assert_allclose(v.detach().double().cpu().numpy(), p[k].numpy(), rtol=1e-4, atol=2e-5, err_msg=k)
 
 
 def test_variable_names_created_by_networks_match_plan():

@@ -149,6 +149,9 @@ int sg_sumsq_ndhwc_keep_w(const void* g, float* out, int32_t n, int32_t d, int32
  * workspace: (n/group) floats. */
 int sg_minibatch_stddev_fwd(const void* x, void* y, float* workspace, int32_t n, int64_t vox_per_sample,
                             int32_t c, int32_t group_size, sg_dtype dt, sg_stream_t st);
+/* Its gradient: dx[n,d,h,w,c] from dy[n,d,h,w,c+1] and the forward input x (same workspace size). */
+int sg_minibatch_stddev_bwd(const void* dy, const void* x, void* dx, float* workspace, int32_t n,
+                            int64_t vox_per_sample, int32_t c, int32_t group_size, sg_dtype dt, sg_stream_t st);
 /* dtype conversion between f32 and bf16 buffers (dst dtype = dt_dst). */
 int sg_cast(const void* src, sg_dtype dt_src, void* dst, sg_dtype dt_dst, int64_t numel, sg_stream_t st);
 

@@ -55,6 +55,7 @@ SIGNATURES = {
     'sg_add_noise': (C.c_int, [_p, _p, _f, _u64, _u64, _i64, C.c_int, _p]),
     'sg_sumsq_ndhwc_keep_w': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, C.c_int, _p]),
     'sg_minibatch_stddev_fwd': (C.c_int, [_p, _p, _p, _i32, _i64, _i32, _i32, C.c_int, _p]),
+    'sg_minibatch_stddev_bwd': (C.c_int, [_p, _p, _p, _p, _i32, _i64, _i32, _i32, C.c_int, _p]),
     'sg_cast': (C.c_int, [_p, C.c_int, _p, C.c_int, _i64, _p]),
     'sg_adam_ema': (C.c_int, [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p]),
     'sg_segment_sumsq': (C.c_int, [_p, _p, _p, _i32, _p]),

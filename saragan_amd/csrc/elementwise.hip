@@ -579,6 +579,53 @@ __global__ void mbstd_concat_kernel(const T* __restrict__ x, const float* __rest
   }
 }
 
+// minibatch stddev backward, stage 1: S[m] = sum over the group's samples and voxels of dy[.., c] (the statistic's
+// channel); stage 2: dx = dy[.., :c] + S[m] / (P * G) * (x - mean_g x) / sqrt(var_g x + 1e-8), P = vox * c.
+template <typename T>
+__global__ __launch_bounds__(256) void mbstd_bwd_sum_kernel(const T* __restrict__ dy, float* __restrict__ sums, int n, int64_t vox,
+                                                            int c, int mgroups) {
+  __shared__ float red[256];
+  const int nn = blockIdx.y;
+  float s = 0.f;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < vox; v += (int64_t)gridDim.x * blockDim.x)
+    s += sg_traits<T>::to_f(dy[((int64_t)nn * vox + v) * (c + 1) + c]);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k >= 1; k >>= 1) {
+    if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(sums + nn % mgroups, red[0]);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mbstd_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                        const float* __restrict__ sums, T* __restrict__ dx, int group,
+                                                        int mgroups, int64_t vox, int c) {
+  const int m = blockIdx.y;
+  const int64_t per_sample = vox * c;
+  const float k = sums[m] / ((float)per_sample * (float)group);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += (int64_t)gridDim.x * blockDim.x) {
+    float mean = 0.f;
+    for (int gidx = 0; gidx < group; ++gidx) mean += sg_traits<T>::to_f(x[((int64_t)gidx * mgroups + m) * per_sample + i]);
+    mean /= (float)group;
+    float var = 0.f;
+    for (int gidx = 0; gidx < group; ++gidx) {
+      const float dlt = sg_traits<T>::to_f(x[((int64_t)gidx * mgroups + m) * per_sample + i]) - mean;
+      var += dlt * dlt;
+    }
+    const float rs = k * rsqrtf(var / (float)group + 1e-8f);
+    const int64_t v = i / c;
+    const int ch = (int)(i - v * c);
+    for (int gidx = 0; gidx < group; ++gidx) {
+      const int64_t nn = (int64_t)gidx * mgroups + m;
+      const float xv = sg_traits<T>::to_f(x[nn * per_sample + i]);
+      const float g0 = sg_traits<T>::to_f(dy[(nn * vox + v) * (c + 1) + ch]);
+      dx[nn * per_sample + i] = sg_traits<T>::from_f(g0 + rs * (xv - mean));
+    }
+  }
+}
+
 template <typename S, typename D>
 __global__ void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, int64_t numel) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < numel; i += (int64_t)gridDim.x * blockDim.x)
@@ -854,6 +901,28 @@ extern "C" int sg_minibatch_stddev_fwd(const void* x, void* y, float* workspace,
   SG_LAUNCH_CHECK();
   const int blocks = grid_for((int64_t)n * vox_per_sample * (c + 1));
 #define L(T) hipLaunchKernelGGL((mbstd_concat_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)x, workspace, (T*)y, n, vox_per_sample, c, mgroups)
+  SG_DISPATCH(dt, L(bf16_t), L(float));
+#undef L
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_minibatch_stddev_bwd(const void* dy, const void* x, void* dx, float* workspace, int32_t n,
+                                       int64_t vox_per_sample, int32_t c, int32_t group_size, sg_dtype dt, sg_stream_t st) {
+  if (!dy || !x || !dx || !workspace || n < 1 || vox_per_sample < 1 || c < 1 || group_size < 1) return SG_EINVAL;
+  const int group = group_size < n ? group_size : n;
+  if (n % group != 0) return SG_EINVAL;
+  const int mgroups = n / group;
+  hipStream_t hs = sg_st(st);
+  hipError_t e = hipMemsetAsync(workspace, 0, (size_t)mgroups * sizeof(float), hs);
+  if (e != hipSuccess) return (int)e;
+  const int bs = grid_for(vox_per_sample, 256, 64);
+#define L(T) hipLaunchKernelGGL((mbstd_bwd_sum_kernel<T>), dim3(bs, n), dim3(256), 0, hs, (const T*)dy, workspace, n, vox_per_sample, c, mgroups)
+  SG_DISPATCH(dt, L(bf16_t), L(float));
+#undef L
+  SG_LAUNCH_CHECK();
+  const int bx = grid_for(vox_per_sample * c, 256, 1024);
+#define L(T) hipLaunchKernelGGL((mbstd_bwd_kernel<T>), dim3(bx, mgroups), dim3(256), 0, hs, (const T*)dy, (const T*)x, workspace, (T*)dx, group, mgroups, vox_per_sample, c)
   SG_DISPATCH(dt, L(bf16_t), L(float));
 #undef L
   SG_LAUNCH_CHECK();

@@ -645,20 +645,45 @@ def sumsq_keep_w(g):
     return _SumsqKeepW.apply(g)
 
 
+class _MinibatchStddev(torch.autograd.Function):
+    """networks/ops.py:313-325: concat(x, per-group mean stddev).  Once-differentiable (the layer is disabled in
+    pgan, pgan/discriminator.py:50, so it never sits under the gradient penalty)."""
+
+    @staticmethod
+    def forward(ctx, x, group_size):
+        lib = _lib.load()
+        _req_cuda(x)
+        x = ndhwc(x)
+        n, c, d, h, w = _dims(x)
+        g = min(group_size, n)
+        if n % g != 0:
+            raise ValueError(f'minibatch_stddev_layer: batch {n} not divisible by group {g}')
+        y = _empty_like_shape(x, c + 1)
+        ws = torch.empty(n // g, device=x.device, dtype=torch.float32)
+        check(lib.sg_minibatch_stddev_fwd(_ptr(x), _ptr(y), _ptr(ws), n, d * h * w, c, group_size, _dt(x), _stream()),
+              'sg_minibatch_stddev_fwd')
+        ctx.save_for_backward(x)
+        ctx.group_size = group_size
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        gy = ndhwc(gy)
+        n, c, d, h, w = _dims(x)
+        g = min(ctx.group_size, n)
+        dx = torch.empty_like(x)
+        ws = torch.empty(n // g, device=x.device, dtype=torch.float32)
+        check(lib.sg_minibatch_stddev_bwd(_ptr(gy), _ptr(x), _ptr(dx), _ptr(ws), n, d * h * w, c, ctx.group_size, _dt(x),
+                                          _stream()), 'sg_minibatch_stddev_bwd')
+        return dx, None
+
+
 def minibatch_stddev(x, group_size=4):
-    """networks/ops.py:313-325 (forward only: the layer is disabled in pgan, pgan/discriminator.py:50)."""
-    lib = _lib.load()
-    _req_cuda(x)
-    x = ndhwc(x)
-    n, c, d, h, w = _dims(x)
-    g = min(group_size, n)
-    if n % g != 0:
-        raise ValueError(f'minibatch_stddev_layer: batch {n} not divisible by group {g}')
-    y = _empty_like_shape(x, c + 1)
-    ws = torch.empty(n // g, device=x.device, dtype=torch.float32)
-    check(lib.sg_minibatch_stddev_fwd(_ptr(x), _ptr(y), _ptr(ws), n, d * h * w, c, group_size, _dt(x), _stream()),
-          'sg_minibatch_stddev_fwd')
-    return y
+    """networks/ops.py:313-325 (the layer is disabled in pgan, pgan/discriminator.py:50)."""
+    return _MinibatchStddev.apply(x, group_size)
 
 
 def adam_ema_(p, g, m, v, ema, lr, beta1, beta2, step, eps=1e-8, gscale=1.0, ema_decay=0.99):

@@ -358,7 +358,15 @@ def test_sumsq_keep_w_and_mbstd(dtype):
     got = F.sumsq_keep_w(cl(g, dtype))
     np.testing.assert_allclose(got.double().cpu().numpy(), ref.numpy(), rtol=1e-4)
     x = rnd((8, 6, 1, 4, 4), 15, dtype)
-    close(F.minibatch_stddev(cl(x, dtype)), O.minibatch_stddev_layer(x), dtype, 'mbstd')
+    xr = x.clone().requires_grad_(True)
+    yr = O.minibatch_stddev_layer(xr)
+    gy = rnd(tuple(yr.shape), 16, dtype)
+    (gxr,) = torch.autograd.grad(yr, [xr], gy)
+    xg = cl(x, dtype).requires_grad_(True)
+    yg = F.minibatch_stddev(xg)
+    close(yg, yr, dtype, 'mbstd')
+    (gxg,) = torch.autograd.grad(yg, [xg], cl(gy, dtype))
+    close(gxg, gxr, dtype, 'mbstd backward')
 
 
 def test_add_noise_statistics():

@@ -5,8 +5,9 @@ CPU for tests).  Replaces the reference's Horovod usage on the hot path:
       HIP stream; the fused Adam waits on the bucket events), averaged by folding 1/world into the Adam kernel;
   hvd.broadcast_global_variables(0) (optuna_objective.py:328,375,413) -> broadcast_global_variables;
   MPI scatter of file lists (dataset.py:307-333) -> a shared-seed permutation each rank slices (dataset.py).
-xGMI is point-to-point (7 links per GPU): few large buckets beat many small ones, so the default bucket is 64 MiB
-and the whole gradient of a small network goes out as one message."""
+xGMI is point-to-point (7 links per GPU): large buckets amortise the ring's latency, but the bucket that becomes
+ready LAST is exposed (the generator's parameter-heavy low-resolution layers finish its backward), so the default
+is 32 MiB (SARAGAN_BUCKET_MIB overrides); the whole gradient of a small network still goes out as one message."""
 import os
 
 import torch
@@ -44,7 +45,9 @@ class GradientAllReducer:
     post-accumulate-grad hook decrements its bucket; a bucket whose parameters are all done is all-reduced
     asynchronously.  finish() launches whatever is left and waits."""
 
-    def __init__(self, group=None, bucket_bytes=64 << 20):
+    def __init__(self, group=None, bucket_bytes=None):
+        if bucket_bytes is None:
+            bucket_bytes = int(os.environ.get('SARAGAN_BUCKET_MIB', '32')) << 20
         self.group = group
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -112,7 +115,7 @@ class GradientAllReducer:
         self._handles = []
 
 
-def DistributedOptimizer(optimizer, group=None, bucket_bytes=64 << 20, op=None):
+def DistributedOptimizer(optimizer, group=None, bucket_bytes=None, op=None):
     """hvd.DistributedOptimizer(optimizer): gradients are averaged over ranks before they are applied.
     (`op` is accepted for the reference's Adasum call site, optuna_objective.py:182-183, and ignored.)"""
     optimizer.distributed = GradientAllReducer(group, bucket_bytes)

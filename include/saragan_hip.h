@@ -38,7 +38,9 @@ enum {
   SG_OK = 0,
   SG_EINVAL = -1,      /* bad shape / null pointer / unsupported combination */
   SG_EWORKSPACE = -2,  /* workspace too small */
-  SG_EALIGN = -3       /* pointer not 16-byte aligned */
+  SG_EALIGN = -3,      /* pointer not 16-byte aligned */
+  SG_EUNSUPPORTED = -4 /* valid request that no kernel of this build covers (sub-pixel epilogue on a small layer): the
+                          caller falls back to the plain formulation */
 };
 
 /* Geometry of one stride-1 'SAME' convolution (tf.nn.conv3d at networks/ops.py:150).
@@ -66,6 +68,15 @@ typedef struct {
                             dy*alpha)) into the convolution. */
   float mask_slope;
   void* sign_out;        /* optional: receives the sign words of y (after bias + act) for a later mask_bits */
+  /* Sub-pixel form of conv3d(upscale3d(x)) (networks/ops.py:276-289 + :147-150): the output voxels of one parity class
+   * (2i+a, 2j+b, 2k+c) are a 2x2x2-tap convolution of the LOW-resolution input with summed weights (27 -> 8 taps,
+   * 3.4x fewer FLOPs).  A launch with kd = kh = kw = 2 computes one class: out_scale = 2 makes y the full-resolution
+   * tensor [n,2d,2h,2w,cout] (pn_scale / sign words likewise) written at the voxels of class out_off; tap t of a
+   * dimension reads input offset t - 1 + tap_off (tap_off = parity: taps {-1,0} for even, {0,+1} for odd outputs).
+   * All zero: the ordinary convolution. */
+  int32_t out_scale;
+  int32_t out_off[3];
+  int32_t tap_off[3];
 } sg_conv_epilogue;
 
 /* Sign words of an NDHWC tensor t[nvox][c]: uint32 words[nvox][ceil(c/32)], bit j of word (v, k) = (t[v][32k+j] < 0),

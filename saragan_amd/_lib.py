@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsaragan_hip.so')
 
 SG_F32, SG_BF16 = 0, 1
+SG_EUNSUPPORTED = -4
 
 
 class ConvShape(C.Structure):
@@ -18,7 +19,8 @@ class ConvShape(C.Structure):
 class ConvEpilogue(C.Structure):
     _fields_ = [('bias', C.c_void_p), ('act', C.c_int32), ('slope', C.c_float), ('pixel_norm', C.c_int32),
                 ('eps', C.c_float), ('pn_scale', C.c_void_p), ('mask_bits', C.c_void_p), ('mask_slope', C.c_float),
-                ('sign_out', C.c_void_p)]
+                ('sign_out', C.c_void_p), ('out_scale', C.c_int32), ('out_off', C.c_int32 * 3),
+                ('tap_off', C.c_int32 * 3)]
 
 
 class ProfEntry(C.Structure):

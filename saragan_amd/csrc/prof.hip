@@ -41,6 +41,7 @@ extern "C" const char* sg_error_string(int code) {
     case SG_EINVAL: return "invalid argument (shape, null pointer or unsupported combination)";
     case SG_EWORKSPACE: return "workspace too small";
     case SG_EALIGN: return "pointer not 16-byte aligned";
+    case SG_EUNSUPPORTED: return "no kernel covers this request";
     default: break;
   }
   if (code > 0) return hipGetErrorString((hipError_t)code);

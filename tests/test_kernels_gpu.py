@@ -290,6 +290,39 @@ def test_fused_mask_chain_first_and_second_order(big, dtype):
 
 
 @pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('cout', [32, 64])
+def test_upconv_subpixel_matches_oracle(cout, dtype, monkeypatch):
+    """conv3d(upscale3d(x)) in sub-pixel form (eight 2x2x2-tap launches on the low-resolution input, stride-2
+    scatter epilogue with bias + LeakyReLU + pixel-norm + sign words) against the oracle's 27-tap formulation, and
+    against the library's own fused-gather path."""
+    from saragan_amd import functional as F
+    monkeypatch.setenv('SG_FWD4_GX', '8')       # reach the ping-pong kernel with a small tensor (>= 16 tiles)
+    n, cin, sp = 2, 16, (4, 16, 32)
+    x = rnd((n, cin, *sp), 41, dtype)
+    w = rnd((3, 3, 3, cin, cout), 42, dtype)
+    b = rnd((cout,), 43, torch.float32) * 0.5
+    coef = O.runtime_coef(w.shape, 'leaky_relu', 0.2)
+    ref = O.pixel_norm(O.act(O.apply_bias(O.conv3d(O.upscale3d(x), w, 'leaky_relu', 0.2), b.double()), 'leaky_relu', 0.2))
+    xg, wg, bg = cl(x, dtype), w.float().to(dev()), b.float().to(dev())
+    F.clear_pack_cache()
+    res = F._raw_upconv_subpixel(xg, wg, coef, bg, True, 0.2, True, 1e-8, True, None, 0.0, True)
+    assert res is not None, 'the sub-pixel path was not taken'
+    y, scale, signs = res
+    # the summed 2x2x2 weights are rounded to bf16 once instead of per tap: same tolerance class as the other kernels
+    close(y, ref, dtype, 'sub-pixel vs oracle')
+    monkeypatch.setattr(F, '_NO_SUBPIXEL', True)     # (the default)
+    y2, scale2, signs2 = F.raw_conv(xg, wg, coef, False, True, bias=bg, act=True, slope=0.2, pixel_norm=True,
+                                    want_scale=True, want_signs=True)
+    close(y, y2.double(), dtype, 'sub-pixel vs fused gather')
+    np.testing.assert_allclose(scale.cpu().numpy(), scale2.cpu().numpy(), rtol=2e-2 if dtype == torch.bfloat16 else 1e-4)
+    diff = (signs ^ signs2).to(torch.int64) & 0xFFFFFFFF
+    flipped = sum(int(((diff >> b) & 1).sum()) for b in range(32))
+    # sign bits can only differ where an activation is within rounding of zero (bf16: the two formulations round
+    # their weights differently)
+    assert flipped <= (2e-3 if dtype == torch.bfloat16 else 1e-5) * signs.numel() * 32, flipped
+
+
+@pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('shape', [(5, 48, 20), (16, 2048, 96)])   # the second: streamed-weight small-batch kernel
 def test_dense(shape, dtype):
     from saragan_amd import functional as F

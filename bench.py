@@ -28,7 +28,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch')
+    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch')
     ap.add_argument('--size', default='s')
     ap.add_argument('--phase', type=int, default=6)
     ap.add_argument('--latent', type=int, default=512)

@@ -1556,8 +1556,7 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
     it_crd[k] = row < hv ? (hw | (hh_ << 8) | (hd << 16) | ((int)q3 << 24) | (sl << 31)) : 0x7F7F7F7F;
   }
   constexpr uint32_t DEAD = 0x80000000u;        // byte offset beyond the buffer: the load returns zeros
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(a.x), 0, a.lean ? (int)((int64_t)g.N * g.D * g.H * g.W * a.cin * (int)sizeof(T)) : 0, 0x00020000);
+  const int64_t sample_bytes = (int64_t)g.D * g.H * g.W * a.cin * (int)sizeof(T);
 
   auto tile_of_item = [&](int q) { return first + (2 * (q / ncg) + grp) * per_x; };
 
@@ -1587,7 +1586,12 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
       const int hi_n = min(g.TN, g.N - o.n0) - 1;
       const uint32_t lo = (uint32_t)(lo_w | (lo_h << 8) | (lo_d << 16));
       const uint32_t hi = (uint32_t)(hi_w | (hi_h << 8) | (hi_d << 16) | (hi_n << 24)) | 0x80808080u;
-      const int tile_off = (int)((((((int64_t)o.n0 * g.D + (o.d0 - g.PD)) * g.H + (o.h0 - g.PH)) * g.W + (o.w0 - g.PW)) *
+      // the resource starts at the tile's first sample (a 64-bit scalar add): offsets stay below 2 GiB for any batch
+      const int64_t left = (int64_t)(g.N - o.n0) * sample_bytes;
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(a.x)) + (int64_t)o.n0 * sample_bytes, 0,
+          (int)(left < 0x7FFFFFFFll ? left : 0x7FFFFFFFll), 0x00020000);
+      const int tile_off = (int)((((((int64_t)(o.d0 - g.PD)) * g.H + (o.h0 - g.PH)) * g.W + (o.w0 - g.PW)) *
                                       (int64_t)a.cin + c0) * (int)sizeof(T));
       const bool tail = c0 + CH > a.cin;                 // the second slot's channels may not exist
 #pragma unroll
@@ -1791,13 +1795,13 @@ static int launch_fwd4(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, b
   gx = sg_env_int("SG_FWD4_GX", gx);   // tests shrink the grid to reach this kernel with small tensors
   if (gx < 8 || (gx & 7)) return SG_EINVAL;
   if (ntiles >= (1 << 24) || ntiles < 2 * gx) return SG_OK;
-  if ((int64_t)s->n * s->d * s->h * s->w * (int64_t)s->cin >= (1ll << 31)) return SG_OK;
+  // per-lane halo offsets are relative to the tile's first sample: only TN samples have to fit 31 bits
+  if ((int64_t)g.TN * s->d * s->h * s->w * (int64_t)s->cin * (int64_t)sizeof(T) >= (1ll << 31)) return SG_OK;
   const int hv = g.TN * g.HD * g.HH * g.HW;
   a.G = 1;
   a.rs = 32;
   a.xbytes = hv * 32;   // exact: lanes beyond the last row are masked off in the LDS-DMA
-  a.lean = (!s->upsample_in && (int64_t)s->n * s->d * s->h * s->w * (int64_t)s->cin * (int64_t)sizeof(T) < (1ll << 31) &&
-            !sg_env_int("SG_FWD4_NO_LEAN", 0)) ? 1 : 0;
+  a.lean = (!s->upsample_in && !sg_env_int("SG_FWD4_NO_LEAN", 0)) ? 1 : 0;   // buffer resource rebased per tile sample
   a.wbytes = a.taps * NTB * 1024;
   if (sg_cdiv(hv * 2, 64) > 32) return SG_OK;
   size_t lds = 2ull * a.xbytes + (size_t)a.nchunk * a.wbytes + NTB * 128;

@@ -545,7 +545,8 @@ static int launch_wgrad2(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   if (g.TW < 16 || g.TN * g.TD * g.TH * g.TW != 256) return SG_OK;
   if (g.TN > 127 || g.HD > 127 || g.HH > 127 || g.HW > 127) return SG_OK;
   if ((s->cin % 8) || (s->cout % 8)) return SG_OK;
-  if ((int64_t)s->n * s->d * s->h * s->w * (int64_t)(s->cin > s->cout ? s->cin : s->cout) >= (1ll << 31)) return SG_OK;
+  // staging offsets are relative to the tile's first sample (64-bit tile bases): TN samples must fit 31 bits
+  if ((int64_t)g.TN * s->d * s->h * s->w * (int64_t)(s->cin > s->cout ? s->cin : s->cout) >= (1ll << 31)) return SG_OK;
   const int64_t ntiles = (int64_t)g.nTn * g.nTd * g.nTh * g.nTw;
   const int pairs = a.ciT * a.coT;
   int gx = (256 / pairs) / 8 * 8;
@@ -883,7 +884,8 @@ static int launch_wgrad3(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   if (g.TD != 2 || g.TH != 4) return SG_OK;           // the unrolled K loop is written for 2 x 4 x 32 tiles
   if (g.HH > 127 || g.HW > 127) return SG_OK;
   if ((s->cin % 8) || (s->cout % 8)) return SG_OK;
-  if ((int64_t)s->n * s->d * s->h * s->w * (int64_t)(s->cin > s->cout ? s->cin : s->cout) >= (1ll << 31)) return SG_OK;
+  // staging offsets are relative to the tile's first sample (64-bit tile bases): TN samples must fit 31 bits
+  if ((int64_t)g.TN * s->d * s->h * s->w * (int64_t)(s->cin > s->cout ? s->cin : s->cout) >= (1ll << 31)) return SG_OK;
   const int ncol = g.nTn * g.nTh * g.nTw;
   const int pairs = a.ciT * a.coT;
   int gx = (256 / pairs) / 8 * 8;

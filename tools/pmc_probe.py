@@ -15,18 +15,19 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from saragan_amd import _lib  # noqa: E402
 from saragan_amd._lib import ConvEpilogue, ConvShape  # noqa: E402
 
-SHAPES = [  # n, (d,h,w), cin, cout  (all 3x3x3): the >= 1 ms/step entries of `bench.py --dump-prof`; n = 32 is the
-    # concatenated real+fake batch of the discriminator, n = 16 the generator / gradient-penalty passes
-    (32, (32, 128, 128), 64, 32),
+SHAPES = [  # n, (d,h,w), cin, cout  (all 3x3x3): the >= 1 ms/step entries of `bench.py --dump-prof` at the default
+    # per-GPU batch 32; n = 64 is the concatenated real+fake batch of the discriminator, n = 32 the generator /
+    # gradient-penalty passes
+    (64, (32, 128, 128), 64, 32),
+    (64, (32, 128, 128), 32, 32),
+    (64, (32, 128, 128), 32, 64),
     (32, (32, 128, 128), 32, 32),
     (32, (32, 128, 128), 32, 64),
-    (16, (32, 128, 128), 32, 32),
-    (16, (32, 128, 128), 32, 64),
-    (16, (32, 128, 128), 64, 32),
-    (32, (16, 64, 64), 64, 64),
-    (32, (16, 64, 64), 64, 128),
-    (32, (16, 64, 64), 128, 64),
-    (32, (8, 32, 32), 128, 128),
+    (32, (32, 128, 128), 64, 32),
+    (64, (16, 64, 64), 64, 64),
+    (64, (16, 64, 64), 64, 128),
+    (64, (16, 64, 64), 128, 64),
+    (64, (8, 32, 32), 128, 128),
 ]
 
 

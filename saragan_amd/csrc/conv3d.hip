@@ -1552,11 +1552,14 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
     uint32_t q3 = sg_div(q2, g.fHD);
     int hd = (int)(q2 - q3 * g.HD);
     it_rel[k] = row < hv ? ((((int)q3 * g.D + hd) * g.H + hh_) * g.W + hw) * a.cin + sl * EPP : -2;   // -2: beyond the image, lane idle
+    if (g.ups && a.lean && row < hv)   // fused nearest x2 gather: tile origins are even (host-checked), so the halved
+      // coordinate of halo voxel hd is d0/2 + ((hd - PD) >> 1): an offset relative to the tile's low-resolution origin
+      it_rel[k] = ((((int)q3 * Di + ((hd - g.PD) >> 1)) * Hi + ((hh_ - g.PH) >> 1)) * Wi + ((hw - g.PW) >> 1)) * a.cin + sl * EPP;
     // packed halo coordinate for the boundary test (bytes w,h,d,n, all < 128); bit 31 = second 16-byte slot
     it_crd[k] = row < hv ? (hw | (hh_ << 8) | (hd << 16) | ((int)q3 << 24) | (sl << 31)) : 0x7F7F7F7F;
   }
   constexpr uint32_t DEAD = 0x80000000u;        // byte offset beyond the buffer: the load returns zeros
-  const int64_t sample_bytes = (int64_t)g.D * g.H * g.W * a.cin * (int)sizeof(T);
+  const int64_t sample_bytes = (int64_t)Di * Hi * Wi * a.cin * (int)sizeof(T);   // of the (possibly half-resolution) input
 
   auto tile_of_item = [&](int q) { return first + (2 * (q / ncg) + grp) * per_x; };
 
@@ -1591,12 +1594,14 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
       const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<char*>(reinterpret_cast<const char*>(a.x)) + (int64_t)o.n0 * sample_bytes, 0,
           (int)(left < 0x7FFFFFFFll ? left : 0x7FFFFFFFll), 0x00020000);
-      const int tile_off = (int)((((((int64_t)(o.d0 - g.PD)) * g.H + (o.h0 - g.PH)) * g.W + (o.w0 - g.PW)) *
-                                      (int64_t)a.cin + c0) * (int)sizeof(T));
+      const int tile_off = g.ups ? (int)(((((int64_t)(o.d0 >> 1) * Hi + (o.h0 >> 1)) * Wi + (o.w0 >> 1)) * (int64_t)a.cin + c0) *
+                                         (int)sizeof(T))
+                                 : (int)((((((int64_t)(o.d0 - g.PD)) * g.H + (o.h0 - g.PH)) * g.W + (o.w0 - g.PW)) *
+                                          (int64_t)a.cin + c0) * (int)sizeof(T));
       const bool tail = c0 + CH > a.cin;                 // the second slot's channels may not exist
 #pragma unroll
       for (int k = 0; k < MAXIT; ++k) {
-        if ((wave + 4 * k) * 64 < items && it_rel[k] != -2) {
+        if ((wave + 4 * k) * 64 < items && it_crd[k] != 0x7F7F7F7F) {   // idle lanes: beyond the halo image
           const uint32_t c_ = (uint32_t)it_crd[k] & 0x7FFFFFFFu;
           const uint32_t t1 = (c_ | 0x80808080u) - lo, t2 = hi - c_;
           bool ok = (t1 & t2 & 0x80808080u) == 0x80808080u;
@@ -1801,7 +1806,9 @@ static int launch_fwd4(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, b
   a.G = 1;
   a.rs = 32;
   a.xbytes = hv * 32;   // exact: lanes beyond the last row are masked off in the LDS-DMA
-  a.lean = (!s->upsample_in && !sg_env_int("SG_FWD4_NO_LEAN", 0)) ? 1 : 0;   // buffer resource rebased per tile sample
+  // buffer resource rebased per tile sample; with the fused x2 gather the tile origins must be even
+  a.lean = ((!s->upsample_in || (g.TD % 2 == 0 && g.TH % 2 == 0 && g.TW % 2 == 0 && g.TN == 1)) &&
+            !sg_env_int("SG_FWD4_NO_LEAN", 0)) ? 1 : 0;
   a.wbytes = a.taps * NTB * 1024;
   if (sg_cdiv(hv * 2, 64) > 32) return SG_OK;
   size_t lds = 2ull * a.xbytes + (size_t)a.nchunk * a.wbytes + NTB * 128;

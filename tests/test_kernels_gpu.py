@@ -291,6 +291,26 @@ def test_fused_mask_chain_first_and_second_order(big, dtype):
 
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('cout', [32, 64])
+def test_upconv_fused_gather_pingpong_kernel(cout, dtype, monkeypatch):
+    """conv3d(upscale3d(x)) with Cin = 64 through the streamed ping-pong kernel's buffer-addressed x2 gather
+    (boundary and interior tiles) against the oracle."""
+    from saragan_amd import functional as F
+    monkeypatch.setenv('SG_FWD4_GX', '8')       # reach the ping-pong kernel with a small tensor (>= 16 tiles)
+    n, cin, sp = 2, 64, (4, 8, 32)
+    x = rnd((n, cin, *sp), 51, dtype)
+    w = rnd((3, 3, 3, cin, cout), 52, dtype)
+    b = rnd((cout,), 53, torch.float32) * 0.5
+    coef = O.runtime_coef(w.shape, 'leaky_relu', 0.2)
+    wq = (w * coef).to(dtype).double() / coef
+    ref = O.act(O.apply_bias(O.conv3d(O.upscale3d(x), wq, 'leaky_relu', 0.2), b.double()), 'leaky_relu', 0.2)
+    F.clear_pack_cache()
+    y, _, _ = F.raw_conv(cl(x, dtype), w.float().to(dev()), coef, False, True, bias=b.float().to(dev()), act=True,
+                         slope=0.2)
+    close(y, ref, dtype, 'fused x2 gather')
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('cout', [32, 64])
 def test_upconv_subpixel_matches_oracle(cout, dtype, monkeypatch):
     """conv3d(upscale3d(x)) in sub-pixel form (eight 2x2x2-tap launches on the low-resolution input, stride-2
     scatter epilogue with bias + LeakyReLU + pixel-norm + sign words) against the oracle's 27-tap formulation, and

@@ -1671,6 +1671,7 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
   const char* wl = wmine + lane * 16;
   T* y = reinterpret_cast<T*>(a.y);
   const float inv_c = 1.f / (float)a.cout;
+  const bool wide_store = (a.cout % 32 == 0) && !(a.dbg_flags & 16);   // whole 32-channel tiles, 16-byte aligned rows
   // output voxel index: the conv's own grid, or (sub-pixel class) voxel (2d+oa, 2h+ob, 2w+oc) of the x2 tensor
   auto ovox = [&](int n, int d, int h, int w) -> int64_t {
     if (a.os == 2) return ((((int64_t)n * (2 * g.D) + 2 * d + a.oa) * (2 * g.H) + 2 * h + a.ob) * (2 * g.W) + 2 * w + a.oc);
@@ -1678,9 +1679,20 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
   };
   f32x16 acc[MTW][NTB];
 
+  // diagnostic time stamps (tools/ts_conv.py): per phase [top, after staging, end].  Measured on 64->32 at 128^2:
+  // MFMA phase 2.4k cycles, staging of one 26-KiB halo chunk 3.3k (the CU's ~20 B/clk share of the memory system),
+  // epilogue 6k every fourth item: this layer is bound by the bytes staged per tile (4 chunk passes, no sliding
+  // halo -- a ring of 64-channel planes does not fit next to 108 KiB of resident weights).
+  int dbgi = 0;
+  auto stamp = [&]() {
+    if (a.dbg != nullptr && blockIdx.x == 8 && blockIdx.y == 0 && lane == 0 && wave == 0 && dbgi < 120)
+      a.dbg[grp * 128 + dbgi] = __builtin_amdgcn_s_memtime();
+    ++dbgi;
+  };
   const int nphase = 2 * items_max + 1;
   for (int p = 0; p < nphase; ++p) {
     const int q = p >> 1;                      // item index within the running group
+    stamp();
     if ((p & 1) == grp) {
       if (q < items_mine) {
         if (q % ncg == 0) {
@@ -1714,6 +1726,7 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
         }
       }
       if (qn < items_mine) stage_item(qn);
+      stamp();
       if (!a.wres && (p >> 1) + 1 < items_max) {   // my half of the next item's slab (phase parity picks the half)
         constexpr int nfrag = TAPS * NTB, hf = (nfrag + 1) / 2;
         stage_slab((p >> 1) + 1, (p & 1) ? hf : 0, (p & 1) ? nfrag : hf, wave, 4);
@@ -1759,7 +1772,11 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NTB; ++nt) sg_apply_sign_word(acc[mt][nt], mb[mt][nt], hh, a.mask_slope);
           }
-          if (ok) {
+          if (sizeof(T) == 2 && wide_store) {   // uniform: 16 contiguous bytes per lane after a half-wave exchange
+            bf16_t* yrow = reinterpret_cast<bf16_t*>(y) + ovox(n, d, h, w) * (int64_t)a.cout + nt0 * 32;
+#pragma unroll
+            for (int nt = 0; nt < NTB; ++nt) sg_store_tile_row_bf16(yrow + nt * 32, acc[mt][nt], hh, ok && nt < ntb);
+          } else if (ok) {
             T* yrow = y + ovox(n, d, h, w) * (int64_t)a.cout;
 #pragma unroll
             for (int nt = 0; nt < NTB; ++nt)
@@ -1782,6 +1799,7 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
         }
       }
     }
+    stamp();
     __syncthreads();
   }
 }

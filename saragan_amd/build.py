@@ -1,5 +1,7 @@
 """Builds libsaragan_hip.so for gfx950 with hipcc (in-tree: saragan_amd/libsaragan_hip.so)."""
+import json
 import os
+import re
 import subprocess
 import sys
 
@@ -26,8 +28,28 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+RESOURCES = os.path.join(HERE, 'build', 'resource_usage.json')
+_REMARK = re.compile(r'remark:\s+(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|'
+                     r'SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]):\s+(\S+)')
+_KEYS = {'TotalSGPRs': 'sgprs', 'VGPRs': 'vgprs', 'AGPRs': 'agprs', 'ScratchSize [bytes/lane]': 'scratch_bytes',
+         'Occupancy [waves/SIMD]': 'occupancy', 'SGPRs Spill': 'sgpr_spill', 'VGPRs Spill': 'vgpr_spill',
+         'LDS Size [bytes/block]': 'static_lds'}
+
+
+def parse_resource_remarks(text):
+    """hipcc -Rpass-analysis=kernel-resource-usage remarks -> {mangled kernel name: {vgprs, vgpr_spill, ...}}."""
+    out, cur = {}, None
+    for m in _REMARK.finditer(text):
+        k, v = m.group(1), m.group(2)
+        if k == 'Function Name':
+            cur = out.setdefault(v, {})
+        elif cur is not None:
+            cur[_KEYS[k]] = int(v)
+    return out
+
+
 def build(force=False, verbose=True):
-    if not force and not needs_build():
+    if not force and not needs_build() and os.path.exists(RESOURCES):
         return LIB
     objs = []
     os.makedirs(os.path.join(HERE, 'build'), exist_ok=True)
@@ -35,18 +57,46 @@ def build(force=False, verbose=True):
     for s in SOURCES:
         o = os.path.join(HERE, 'build', s.replace('.hip', '.o'))
         objs.append(o)
-        cmd = [_hipcc()] + FLAGS + ['-c', os.path.join(CSRC, s), '-o', o]
+        cmd = [_hipcc()] + FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-c', os.path.join(CSRC, s), '-o', o]
         if verbose:
             print(' '.join(cmd), flush=True)
-        procs.append((s, subprocess.Popen(cmd)))
-    for s, p in procs:
-        if p.wait() != 0:
+        log = open(o + '.log', 'w+')
+        procs.append((s, subprocess.Popen(cmd, stderr=log), log))
+    usage = {}
+    for s, p, log in procs:
+        rc = p.wait()
+        log.seek(0)
+        text = log.read()
+        log.close()
+        if rc != 0:
+            sys.stderr.write(text)
             raise RuntimeError(f'hipcc failed on {s}')
+        # the remarks go to the per-kernel table; anything else the compiler said (warnings) is shown
+        rest = [ln for ln in text.splitlines() if 'kernel-resource-usage' not in ln]
+        rest = [ln for i, ln in enumerate(rest) if not _is_remark_context(rest, i)]
+        if verbose and any('warning' in ln or 'error' in ln for ln in rest):
+            sys.stderr.write('\n'.join(rest) + '\n')
+        usage[s] = parse_resource_remarks(text)
+    with open(RESOURCES, 'w') as f:
+        json.dump(usage, f, indent=1, sort_keys=True)
     cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.check_call(cmd)
     return LIB
+
+
+def _is_remark_context(lines, i):
+    """clang prints the source line and a caret under every remark: drop those too."""
+    s = lines[i].lstrip()
+    return bool(re.match(r'^\d+ \|', s)) or s.startswith('| ^') or s == '|' or s.startswith('^')
+
+
+def resource_usage():
+    """Per-kernel register / scratch / spill table of the current build (built on demand)."""
+    build(force=not os.path.exists(RESOURCES), verbose=False)
+    with open(RESOURCES) as f:
+        return json.load(f)
 
 
 if __name__ == '__main__':

@@ -621,23 +621,37 @@ static int launch_fwd2(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st) {
 
 // Fully unrolled, software-pipelined K loop of the weight-stationary kernel (see the call site).  Template
 // recursion keeps every LDS offset and wait count an immediate.
-template <typename T, int MTW, int GC, int TAPS, int RING>
+// Address-table index of operand fragment (tap, M tile).  With HS ("H shift") the wave's two M tiles are consecutive
+// H rows of the tile, so the fragment of (kd, kh, kw) for M tile 1 IS the fragment of (kd, kh + 1, kw) for M tile 0:
+// the table holds KD x (KH + 1) x KW addresses instead of KD x KH x KW x 2 (36 instead of 54 registers at 3x3x3,
+// which is what kept <2,2,3,3,3> from fitting 256 VGPRs next to its 64 accumulators).
+template <int MTW, int KH, int KW, bool HS>
+__host__ __device__ constexpr int sg_xa_index(int tap, int mt) {
+  return HS ? ((tap / (KH * KW)) * (KH + 1) + (tap / KW) % KH + mt) * KW + tap % KW : tap * MTW + mt;
+}
+template <int MTW, int KD, int KH, int KW, bool HS>
+struct sg_xa_size { static constexpr int value = HS ? KD * (KH + 1) * KW : KD * KH * KW * MTW; };
+
+template <typename T, int MTW, int GC, int TAPS, int RING, int KH, int KW, bool HS, int NA>
 struct sg_unrolled_k {
   static constexpr int NS = TAPS * GC, PF = RING - 1, RPS = 1 + MTW;
   template <int ST>
-  static __device__ __forceinline__ void load(u32x4 (&wfr)[RING], u32x4 (&xfr)[RING][MTW], const int (&xaddr)[TAPS][MTW],
+  static __device__ __forceinline__ void load(u32x4 (&wfr)[RING], u32x4 (&xfr)[RING][MTW], const int (&xaddr)[NA],
                                               int wl_off) {
     constexpr int SL = ST % RING, tap = ST / GC, gi = ST % GC;
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wfr[SL]) : "v"(wl_off), "n"(ST << 10));
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt) {
-      const int xa = xaddr[tap][mt] ^ (gi << 5);
+      int xa = xaddr[sg_xa_index<MTW, KH, KW, HS>(tap, mt)];
+      // chunk gi sits in slot 2*gi + hh (XOR-swizzled): toggled here, opaque to the compiler, which would otherwise
+      // keep a second copy of the whole address table in registers
+      if constexpr (gi != 0) asm volatile("v_xor_b32_e32 %0, %1, %2" : "=v"(xa) : "n"(gi << 5), "v"(xaddr[sg_xa_index<MTW, KH, KW, HS>(tap, mt)]));
       asm volatile("ds_read_b128 %0, %1" : "=v"(xfr[SL][mt]) : "v"(xa));
     }
   }
   template <int ST>
   static __device__ __forceinline__ void step(f32x16 (&acc)[MTW], u32x4 (&wfr)[RING], u32x4 (&xfr)[RING][MTW],
-                                              const int (&xaddr)[TAPS][MTW], int wl_off) {
+                                              const int (&xaddr)[NA], int wl_off) {
     if constexpr (ST < NS) {
       if constexpr (ST + PF < NS) load<ST + PF>(wfr, xfr, xaddr, wl_off);
       constexpr int younger = (NS - 1 - ST < PF ? NS - 1 - ST : PF) * RPS;   // reads issued after step ST's
@@ -651,14 +665,14 @@ struct sg_unrolled_k {
   }
   template <int ST>
   static __device__ __forceinline__ void prologue(u32x4 (&wfr)[RING], u32x4 (&xfr)[RING][MTW],
-                                                  const int (&xaddr)[TAPS][MTW], int wl_off) {
+                                                  const int (&xaddr)[NA], int wl_off) {
     if constexpr (ST < PF && ST < NS) {
       load<ST>(wfr, xfr, xaddr, wl_off);
       prologue<ST + 1>(wfr, xfr, xaddr, wl_off);
     }
   }
   static __device__ __forceinline__ void run(f32x16 (&acc)[MTW], u32x4 (&wfr)[RING], u32x4 (&xfr)[RING][MTW],
-                                             const int (&xaddr)[TAPS][MTW], int wl_off) {
+                                             const int (&xaddr)[NA], int wl_off) {
     prologue<0>(wfr, xfr, xaddr, wl_off);
     step<0>(acc, wfr, xfr, xaddr, wl_off);
   }
@@ -667,22 +681,23 @@ struct sg_unrolled_k {
 
 // Same for the streamed-weight kernel (v4): one step = one tap of the current 32-byte channel chunk:
 // NTB weight fragments + MTW activation fragments, MTW*NTB MFMAs.
-template <typename T, int MTW, int NTB, int TAPS, int RING>
+template <typename T, int MTW, int NTB, int TAPS, int RING, int KH, int KW, bool HS, int NA>
 struct sg_unrolled_k4 {
   static constexpr int PF = RING - 1, RPS = NTB + MTW;
   template <int ST>
   static __device__ __forceinline__ void load(u32x4 (&wfr)[RING][NTB], u32x4 (&xfr)[RING][MTW],
-                                              const int (&xaddr)[TAPS][MTW], int wl_off) {
+                                              const int (&xaddr)[NA], int wl_off) {
     constexpr int SL = ST % RING;
 #pragma unroll
     for (int nt = 0; nt < NTB; ++nt)
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wfr[SL][nt]) : "v"(wl_off), "n"((ST * NTB + nt) << 10));
 #pragma unroll
-    for (int mt = 0; mt < MTW; ++mt) asm volatile("ds_read_b128 %0, %1" : "=v"(xfr[SL][mt]) : "v"(xaddr[ST][mt]));
+    for (int mt = 0; mt < MTW; ++mt)
+      asm volatile("ds_read_b128 %0, %1" : "=v"(xfr[SL][mt]) : "v"(xaddr[sg_xa_index<MTW, KH, KW, HS>(ST, mt)]));
   }
   template <int ST>
   static __device__ __forceinline__ void step(f32x16 (&acc)[MTW][NTB], u32x4 (&wfr)[RING][NTB], u32x4 (&xfr)[RING][MTW],
-                                              const int (&xaddr)[TAPS][MTW], int wl_off) {
+                                              const int (&xaddr)[NA], int wl_off) {
     if constexpr (ST < TAPS) {
       if constexpr (ST + PF < TAPS) load<ST + PF>(wfr, xfr, xaddr, wl_off);
       constexpr int younger = (TAPS - 1 - ST < PF ? TAPS - 1 - ST : PF) * RPS;
@@ -699,13 +714,13 @@ struct sg_unrolled_k4 {
   }
   template <int ST>
   static __device__ __forceinline__ void prologue(u32x4 (&wfr)[RING][NTB], u32x4 (&xfr)[RING][MTW],
-                                                  const int (&xaddr)[TAPS][MTW], int wl_off) {
+                                                  const int (&xaddr)[NA], int wl_off) {
     if constexpr (ST < PF && ST < TAPS) {
       load<ST>(wfr, xfr, xaddr, wl_off);
       prologue<ST + 1>(wfr, xfr, xaddr, wl_off);
     }
   }
-  static __device__ __forceinline__ void run(f32x16 (&acc)[MTW][NTB], const int (&xaddr)[TAPS][MTW], int wl_off) {
+  static __device__ __forceinline__ void run(f32x16 (&acc)[MTW][NTB], const int (&xaddr)[NA], int wl_off) {
     u32x4 wfr[RING][NTB], xfr[RING][MTW];
     prologue<0>(wfr, xfr, xaddr, wl_off);
     step<0>(acc, wfr, xfr, xaddr, wl_off);
@@ -757,7 +772,11 @@ __global__ __launch_bounds__(512) void conv_fwd3r_kernel(ConvFwdArgs a) {
   const int K = first < t_end ? (t_end - first + per_x - 1) / per_x : 0;   // tiles of this block
 
   // ---- tile-invariant per-lane state ----------------------------------------------------------------
-  int xaddr[TAPS][MTW];   // LDS byte address of every (tap, M tile) operand fragment, chunk 0, own buffer
+  // LDS byte address of every (tap, M tile) operand fragment, chunk 0, own buffer (HS: see sg_xa_index; the host
+  // only launches an HS instantiation on tiles where M tile 1 is M tile 0 moved by one H row)
+  constexpr bool HS = (MTW == 2 && GC == 2);
+  constexpr int NA = sg_xa_size<MTW, KD, KH, KW, HS>::value;
+  int xaddr[NA];
   int tcoord[MTW];
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt) {
@@ -771,15 +790,16 @@ __global__ __launch_bounds__(512) void conv_fwd3r_kernel(ConvFwdArgs a) {
     int tn = (int)q3;
     const int lrow = (m < tvox) ? (((tn * g.HD + td) * g.HH + th) * g.HW + tw) : 0;
     tcoord[mt] = (m < tvox) ? (tw | (th << 8) | (td << 16) | (tn << 24)) : -1;
+    if (HS && mt > 0) continue;
 #pragma unroll
     for (int kd = 0; kd < KD; ++kd)
 #pragma unroll
-      for (int kh = 0; kh < KH; ++kh)
+      for (int kh = 0; kh < KH + (HS ? 1 : 0); ++kh)
 #pragma unroll
         for (int kw = 0; kw < KW; ++kw) {
           const int row = lrow + (kd * g.HH + kh) * g.HW + kw;
-          xaddr[(kd * KH + kh) * KW + kw][mt] =
-              grp * a.xbytes + row * rb + (((hh) ^ ((row >> rshift) & (S - 1))) << 4);
+          const int idx = HS ? (kd * (KH + 1) + kh) * KW + kw : ((kd * KH + kh) * KW + kw) * MTW + mt;
+          xaddr[idx] = grp * a.xbytes + row * rb + (((hh) ^ ((row >> rshift) & (S - 1))) << 4);
         }
   }
   // halo staging items of this lane: element offset relative to the tile's first halo voxel + packed coords
@@ -809,20 +829,15 @@ __global__ __launch_bounds__(512) void conv_fwd3r_kernel(ConvFwdArgs a) {
 
   // Halo staging by LDS-DMA: asynchronous (lands while this group runs its epilogue), no VGPRs held.  A piece
   // costs 100-200 issue cycles on THIS wave only; the MFMA group on the same SIMDs keeps running.
+  // a.lean: buffer addressing -- a scalar resource rebased to the tile's first sample, a scalar tile offset and the
+  // per-lane 32-bit offset computed once; pieces outside the volume carry an out-of-range offset and read zeros
+  // (64-bit per-piece pointers and zero-page selects had the compiler keep 28 more registers live: spills).
+  constexpr uint32_t DEAD = 0x80000000u;
+  const int64_t sample_bytes = (int64_t)Di * Hi * Wi * a.cin * (int)sizeof(T);
   auto stage_tile = [&](const sg_tile_origin& o) {
-    const bool interior = !g.ups && o.d0 >= g.PD && o.h0 >= g.PH && o.w0 >= g.PW && o.d0 + g.TD + g.PD <= g.D &&
-                          o.h0 + g.TH + g.PH <= g.H && o.w0 + g.TW + g.PW <= g.W && o.n0 + g.TN <= g.N;
-    const T* base = x + ((((int64_t)o.n0 * g.D + (o.d0 - g.PD)) * g.H + (o.h0 - g.PH)) * g.W + (o.w0 - g.PW)) *
-                            (int64_t)a.cin;
-    if (interior) {   // every halo voxel is inside the volume: one 64-bit add per piece
-#pragma unroll
-      for (int k = 0; k < MAXIT; ++k) {
-        if ((wave + 4 * k) * 64 < items) {
-          const void* src = it_rel[k] >= 0 ? (const void*)(base + it_rel[k]) : (const void*)sg_zero_page;
-          sg_glds16(src, xmine + (size_t)(wave + 4 * k) * 1024);
-        }
-      }
-    } else if (!g.ups) {
+    if (a.lean) {
+      const bool interior = o.d0 >= g.PD && o.h0 >= g.PH && o.w0 >= g.PW && o.d0 + g.TD + g.PD <= g.D &&
+                            o.h0 + g.TH + g.PH <= g.H && o.w0 + g.TW + g.PW <= g.W && o.n0 + g.TN <= g.N;
       // boundary tile: a piece is valid iff its packed halo coordinate (w,h,d,n bytes, all < 128) lies inside the
       // per-tile range [lo, hi] in every byte; two byte-parallel subtractions with the borrow guard bit 7 test it
       const int lo_w = max(0, g.PW - o.w0), hi_w = min(g.HW, g.W + g.PW - o.w0) - 1;
@@ -831,17 +846,26 @@ __global__ __launch_bounds__(512) void conv_fwd3r_kernel(ConvFwdArgs a) {
       const int hi_n = min(g.TN, g.N - o.n0) - 1;
       const uint32_t lo = (uint32_t)(lo_w | (lo_h << 8) | (lo_d << 16));
       const uint32_t hi = (uint32_t)(hi_w | (hi_h << 8) | (hi_d << 16) | (hi_n << 24)) | 0x80808080u;
+      const int64_t left = (int64_t)(g.N - o.n0) * sample_bytes;
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(reinterpret_cast<const char*>(a.x)) + (int64_t)o.n0 * sample_bytes, 0,
+          (int)(left < 0x7FFFFFFFll ? left : 0x7FFFFFFFll), 0x00020000);
+      const int tile_off = (int)((((((int64_t)(o.d0 - g.PD)) * g.H + (o.h0 - g.PH)) * g.W + (o.w0 - g.PW)) *
+                                  (int64_t)a.cin) * (int)sizeof(T));
 #pragma unroll
       for (int k = 0; k < MAXIT; ++k) {
         if ((wave + 4 * k) * 64 < items) {
-          const uint32_t c_ = (uint32_t)it_crd[k];
-          const uint32_t t1 = (c_ | 0x80808080u) - lo, t2 = hi - c_;
-          const bool ok = ((t1 & t2 & 0x80808080u) == 0x80808080u);
-          const void* src = ok ? (const void*)(base + it_rel[k]) : (const void*)sg_zero_page;
-          sg_glds16(src, xmine + (size_t)(wave + 4 * k) * 1024);
+          bool ok = it_rel[k] >= 0;
+          if (!interior) {
+            const uint32_t c_ = (uint32_t)it_crd[k];
+            const uint32_t t1 = (c_ | 0x80808080u) - lo, t2 = hi - c_;
+            ok = ok && ((t1 & t2 & 0x80808080u) == 0x80808080u);
+          }
+          const uint32_t vo = ok ? (uint32_t)(it_rel[k] * (int)sizeof(T) + tile_off) : DEAD;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xmine + (size_t)(wave + 4 * k) * 1024), 16, vo, 0, 0, 0);
         }
       }
-    } else {   // fused nearest-x2 gather: coordinates are halved, no shortcut
+    } else {   // fused nearest-x2 gather / tensors beyond the 31-bit offset range: per-piece coordinates
 #pragma unroll 1
       for (int k = 0; k < MAXIT; ++k) {
         if ((wave + 4 * k) * 64 < items) {
@@ -852,7 +876,7 @@ __global__ __launch_bounds__(512) void conv_fwd3r_kernel(ConvFwdArgs a) {
           const void* src = sg_zero_page;
           if (it_rel[k] >= 0 && n < g.N && (unsigned)d < (unsigned)g.D && (unsigned)h < (unsigned)g.H &&
               (unsigned)w < (unsigned)g.W) {
-            d >>= 1; h >>= 1; w >>= 1;
+            if (g.ups) { d >>= 1; h >>= 1; w >>= 1; }
             const int row = ((wave + 4 * k) * 64 + lane) >> sshift;
             const int sl_c = ((lane & (S - 1)) ^ ((row >> rshift) & (S - 1))) * EPP;
             src = x + ((((int64_t)n * Di + d) * Hi + h) * Wi + w) * (int64_t)a.cin + sl_c;
@@ -910,7 +934,7 @@ __global__ __launch_bounds__(512) void conv_fwd3r_kernel(ConvFwdArgs a) {
         u32x4 wfr[RING], xfr[RING][MTW];
         const int wl_off = (int)(wl - smem);            // LDS byte address of this lane's weight column
         (void)RPS; (void)NS; (void)PF;
-        sg_unrolled_k<T, MTW, GC, TAPS, RING>::run(acc, wfr, xfr, xaddr, wl_off);
+        sg_unrolled_k<T, MTW, GC, TAPS, RING, KH, KW, HS, NA>::run(acc, wfr, xfr, xaddr, wl_off);
       }
     } else {
       if (a.dbg_flags & 4) __builtin_amdgcn_s_setprio(3);
@@ -1008,6 +1032,10 @@ static int launch_fwd3r(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
   a.vec_in = 1;
   a.vec_out = (s->cout % 4 == 0) ? 1 : 0;
   if (sg_cdiv(hv * GC * 2, 64) > 56) return SG_OK;   // more halo DMA pieces than the kernel's per-lane table holds
+  if (MTW == 2 && GC == 2 && !(g.TW == 32 && (g.TH & 1) == 0)) return SG_OK;   // shared address table (sg_xa_index)
+  // buffer addressing of the halo: per-lane offsets are relative to the tile's first sample
+  a.lean = (!s->upsample_in && (int64_t)g.TN * s->d * s->h * s->w * (int64_t)s->cin * (int64_t)sizeof(T) < (1ll << 31) &&
+            !sg_env_int("SG_FWD3_NO_LEAN", 0)) ? 1 : 0;
   auto kern = conv_fwd3r_kernel<T, MTW, GC, KD, KH, KW>;
   static bool attr_set = false;
   if (!attr_set) {
@@ -1510,7 +1538,11 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
   const int items_mine = kmine * ncg;
   const int items_max = ((K + 1) >> 1) * ncg;                               // group 0 has the most
 
-  int xaddr[TAPS][MTW];
+  // HS (two output-channel tiles per wave: 64 accumulators): the address table is shared between the wave's two
+  // M tiles (sg_xa_index); the host launches it only where M tile 1 is M tile 0 moved by one H row
+  constexpr bool HS = (MTW == 2 && NTB == 2);
+  constexpr int NA = sg_xa_size<MTW, KD, KH, KW, HS>::value;
+  int xaddr[NA];
   int tcoord[MTW];
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt) {
@@ -1524,14 +1556,16 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
     int tn = (int)q3;
     const int lrow = (m < tvox) ? (((tn * g.HD + td) * g.HH + th) * g.HW + tw) : 0;
     tcoord[mt] = (m < tvox) ? (tw | (th << 8) | (td << 16) | (tn << 24)) : -1;
+    if (HS && mt > 0) continue;
 #pragma unroll
     for (int kd = 0; kd < KD; ++kd)
 #pragma unroll
-      for (int kh = 0; kh < KH; ++kh)
+      for (int kh = 0; kh < KH + (HS ? 1 : 0); ++kh)
 #pragma unroll
         for (int kw = 0; kw < KW; ++kw) {
           const int row = lrow + ((kd + a.tap_d) * g.HH + (kh + a.tap_h)) * g.HW + (kw + a.tap_w);
-          xaddr[(kd * KH + kh) * KW + kw][mt] = grp * a.xbytes + row * rb + ((hh ^ ((row >> 3) & 1)) << 4);
+          const int idx = HS ? (kd * (KH + 1) + kh) * KW + kw : ((kd * KH + kh) * KW + kw) * MTW + mt;
+          xaddr[idx] = grp * a.xbytes + row * rb + ((hh ^ ((row >> 3) & 1)) << 4);
         }
   }
   const int hv = g.TN * g.HD * g.HH * g.HW;
@@ -1703,7 +1737,7 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
 #pragma unroll
               for (int i = 0; i < 16; ++i) acc[mt][nt][i] = bias_lds[nt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];
         }
-        sg_unrolled_k4<T, MTW, NTB, TAPS, 3>::run(acc, xaddr, (int)(wl - smem) + (a.wres ? (q % ncg) : (q & 1)) * a.wbytes);
+        sg_unrolled_k4<T, MTW, NTB, TAPS, 3, KH, KW, HS, NA>::run(acc, xaddr, (int)(wl - smem) + (a.wres ? (q % ncg) : (q & 1)) * a.wbytes);
       }
     } else {
       // my next item is q' = (p + 1) >> 1; my previous one q' - 1 (ran in phase p - 1)
@@ -1829,6 +1863,7 @@ static int launch_fwd4(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, b
             !sg_env_int("SG_FWD4_NO_LEAN", 0)) ? 1 : 0;
   a.wbytes = a.taps * NTB * 1024;
   if (sg_cdiv(hv * 2, 64) > 32) return SG_OK;
+  if (MTW == 2 && NTB == 2 && !(g.TW == 32 && (g.TH & 1) == 0)) return SG_OK;   // shared address table (sg_xa_index)
   size_t lds = 2ull * a.xbytes + (size_t)a.nchunk * a.wbytes + NTB * 128;
   a.wres = (lds <= 160 * 1024 && !sg_env_int("SG_FWD4_NO_WRES", 0)) ? 1 : 0;
   if (!a.wres) lds = 2ull * a.xbytes + 2ull * a.wbytes + NTB * 128;
@@ -2141,7 +2176,10 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     bool used = false;
     rc = SG_OK;
     const bool k333 = s->kd == 3 && s->kh == 3 && s->kw == 3, k133 = s->kd == 1 && s->kh == 3 && s->kw == 3;
-    const bool n1 = a.ntile == 1;
+    // two output-channel tiles per wave need the shared address table (TW = 32, even TH); other tiles run one
+    // 32-channel slice per block (pixel-norm over 64 channels then falls through to the v2 kernels)
+    const sg_tile_geom g4 = sg_make_geom(s, 256, /*prefer_w32=*/true);
+    const bool n1 = a.ntile == 1 || (!(g4.TW == 32 && (g4.TH & 1) == 0) && !a.pixel_norm);
     if (dt == SG_BF16) {
       if (k333) rc = n1 ? launch_fwd4<bf16_t, 2, 1, 3, 3, 3>(a, s, hs, &used) : launch_fwd4<bf16_t, 2, 2, 3, 3, 3>(a, s, hs, &used);
       else if (k133) rc = n1 ? launch_fwd4<bf16_t, 2, 1, 1, 3, 3>(a, s, hs, &used) : launch_fwd4<bf16_t, 2, 2, 1, 3, 3>(a, s, hs, &used);
@@ -2169,10 +2207,11 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     }
     if (best < 0) best = 0;
     const int mtw = cand[best][0], ntb = cand[best][1];
-    const int gc = !v2 ? 0 : (a.nchunk >= 4 && a.taps <= 9 ? 4 : (a.nchunk >= 2 ? 2 : 1));
+    // (2 x 4 register tile with 4 chunks per step would need 320 VGPRs: it stays at 2 chunks per step)
+    const int gc = !v2 ? 0 : (a.nchunk >= 4 && a.taps <= 9 && !(mtw == 2 && ntb == 4) ? 4 : (a.nchunk >= 2 ? 2 : 1));
 #define SG_FWD2(T, M, N)                                                                                   \
-  (gc == 4 ? launch_fwd2<T, M, N, 4>(a, s, hs) : gc == 2 ? launch_fwd2<T, M, N, 2>(a, s, hs)                \
-                                                       : launch_fwd2<T, M, N, 1>(a, s, hs))
+  (gc == 4 ? launch_fwd2<T, M, (M == 2 && N == 4 ? 2 : N), 4>(a, s, hs)                                     \
+           : gc == 2 ? launch_fwd2<T, M, N, 2>(a, s, hs) : launch_fwd2<T, M, N, 1>(a, s, hs))
 #define SG_FWD_PICK(T)                                                                                     \
   do {                                                                                                     \
     if (!v2) {                                                                                             \

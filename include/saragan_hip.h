@@ -10,8 +10,9 @@
  *  - plain C: pointers, sizes and small POD structs only; no torch / HIP types in signatures
  *    (`sg_stream_t` is a hipStream_t passed as void*; NULL = the default stream);
  *  - every buffer is caller-owned DEVICE memory; no entry point allocates, frees or synchronises;
- *    kernels are enqueued on the stream given; entry points are re-entrant (no global mutable state
- *    except the opt-in profiler, sg_prof_*);
+ *    kernels are enqueued on the stream given; entry points are re-entrant.  Process-wide state is limited to the
+ *    opt-in profiler (sg_prof_*), an immutable snapshot of the SG_* diagnostic environment switches taken at
+ *    the first launch (sg_config_reload) and the one-time registration of each kernel's LDS size;
  *  - activations are NDHWC (channels-last 3-D): element (n,d,h,w,c) at (((n*D+d)*H+h)*W+w)*C+c.
  *    A 2-D image batch is D == 1.  dtype SG_F32 or SG_BF16 (storage AND MFMA input type; accumulation
  *    is always f32);
@@ -54,8 +55,11 @@ typedef struct {
   int32_t upsample_in;
 } sg_conv_shape;
 
-/* Epilogue fused into sg_conv3d_fwd (apply_bias + act + pixel_norm: networks/ops.py:130-136,167-192,308-310). */
+/* Epilogue fused into sg_conv3d_fwd (apply_bias + act + pixel_norm: networks/ops.py:130-136,167-192,308-310).
+ * struct_size MUST be sizeof(sg_conv_epilogue) of the header the caller was built against: the library rejects any
+ * other value with SG_EINVAL instead of reading past a shorter (older) struct. */
 typedef struct {
+  uint32_t struct_size;
   const float* bias;   /* [cout] or NULL */
   int32_t act;         /* 0 = linear, 1 = leaky_relu */
   float slope;         /* leaky_relu negative slope */
@@ -173,6 +177,16 @@ int sg_cast(const void* src, sg_dtype dt_src, void* dst, sg_dtype dt_dst, int64_
  * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller.  g NULL => EMA only. */
 int sg_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t numel, float lr_t,
                 float b1, float b2, float eps, float gscale, float ema_decay, sg_stream_t st);
+/* The other optimisers optimization.py:17-22,29-35 can create, fused with the EMA update in the same way
+ * (TF training_ops rules; g is scaled by gscale first; ema may be NULL):
+ *   SG_OPT_SGD       tf.train.GradientDescentOptimizer      p -= lr*g
+ *   SG_OPT_MOMENTUM  tf.train.MomentumOptimizer(momentum=h) s1 = h*s1 + g; p -= nesterov ? lr*g + lr*h*s1 : lr*s1
+ *   SG_OPT_ADADELTA  tf.train.AdadeltaOptimizer(rho=h, eps) s1 = h*s1 + (1-h)*g^2; u = sqrt(s2+eps)*rsqrt(s1+eps)*g;
+ *                                                          p -= lr*u; s2 = h*s2 + (1-h)*u^2
+ * s1 / s2: f32 state ranges like p (unused ones may be NULL). */
+enum { SG_OPT_SGD = 0, SG_OPT_MOMENTUM = 1, SG_OPT_ADADELTA = 2 };
+int sg_optim_step(int kind, float* p, const float* g, float* s1, float* s2, float* ema, int64_t numel, float lr,
+                  float h, float eps, int nesterov, float gscale, float ema_decay, sg_stream_t st);
 /* out[i] = sum of squares of segment i (offsets[i]..offsets[i+1]) of a flat f32 buffer
  * (tf.norm per gradient + tf.clip_by_global_norm, optimization.py:66-71).  offsets: DEVICE int64[nseg+1]. */
 int sg_segment_sumsq(const float* flat, const int64_t* offsets, float* out, int32_t nseg, sg_stream_t st);
@@ -188,9 +202,14 @@ typedef struct {
   int64_t launches;
   double total_ms;
   double flops_per_launch;
+  char kernel[64];     /* kernel family + template arguments the dispatcher chose for this shape, e.g. "conv_fwd4<bf16,2,1,3,3,3>" */
 } sg_prof_entry;
 int sg_prof_enable(int on);
 int sg_prof_collect(sg_prof_entry* out, int32_t max_entries, int32_t* n_entries);
+
+/* The SG_* environment switches (kernel-selection overrides for diagnosis, e.g. SG_FWD_NO_V4=1) are read once, at the
+ * first launch.  Tools that change one between launches call this to take a new snapshot. */
+int sg_config_reload(void);
 
 #ifdef __cplusplus
 }

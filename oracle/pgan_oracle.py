@@ -446,6 +446,63 @@ class TFAdam:
             params[name] = params[name] - lr_t * self.m[name] / (torch.sqrt(self.v[name]) + self.eps)
 
 
+class TFSGD:
+    """tf.train.GradientDescentOptimizer (optimization.py:17-18): theta -= lr * g."""
+
+    def __init__(self):
+        self.t = 0
+
+    def apply(self, params: Params, grads: Dict[str, torch.Tensor], lr: float):
+        self.t += 1
+        for name, g in grads.items():
+            params[name] = params[name] - lr * g
+
+
+class TFMomentum:
+    """tf.train.MomentumOptimizer(lr, momentum, use_nesterov) (optimization.py:21-22 passes use_nesterov=True);
+    TF training_ops ApplyMomentum: accum = accum * momentum + g;
+    var -= g * lr + accum * momentum * lr (Nesterov)  |  var -= accum * lr."""
+
+    def __init__(self, momentum=0.9, use_nesterov=True):
+        self.mom, self.nesterov = momentum, use_nesterov
+        self.t = 0
+        self.accum: Params = {}
+
+    def apply(self, params: Params, grads: Dict[str, torch.Tensor], lr: float):
+        self.t += 1
+        for name, g in grads.items():
+            if name not in self.accum:
+                self.accum[name] = torch.zeros_like(params[name])
+            self.accum[name] = self.accum[name] * self.mom + g
+            if self.nesterov:
+                params[name] = params[name] - (g * lr + self.accum[name] * self.mom * lr)
+            else:
+                params[name] = params[name] - self.accum[name] * lr
+
+
+class TFAdadelta:
+    """tf.train.AdadeltaOptimizer(lr, rho, epsilon=1e-07) (optimization.py:19-20); TF training_ops ApplyAdadelta:
+    accum = accum * rho + g^2 * (1 - rho); update = sqrt(accum_update + eps) * rsqrt(accum + eps) * g;
+    var -= update * lr; accum_update = accum_update * rho + update^2 * (1 - rho)."""
+
+    def __init__(self, rho=0.95, epsilon=1e-7):
+        self.rho, self.eps = rho, epsilon
+        self.t = 0
+        self.accum: Params = {}
+        self.accum_update: Params = {}
+
+    def apply(self, params: Params, grads: Dict[str, torch.Tensor], lr: float):
+        self.t += 1
+        for name, g in grads.items():
+            if name not in self.accum:
+                self.accum[name] = torch.zeros_like(params[name])
+                self.accum_update[name] = torch.zeros_like(params[name])
+            self.accum[name] = self.accum[name] * self.rho + g * g * (1 - self.rho)
+            update = torch.sqrt(self.accum_update[name] + self.eps) * torch.rsqrt(self.accum[name] + self.eps) * g
+            params[name] = params[name] - update * lr
+            self.accum_update[name] = self.accum_update[name] * self.rho + update * update * (1 - self.rho)
+
+
 def clip_by_global_norm(grads: Dict[str, torch.Tensor], clip_norm: float = 1.0):
     """tf.clip_by_global_norm (optimization.py:66-67): g * clip / max(global_norm, clip)."""
     gn = torch.sqrt(sum((g * g).sum() for g in grads.values()))

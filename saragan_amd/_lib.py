@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsaragan_hip.so')
 
 SG_F32, SG_BF16 = 0, 1
+SG_OPT_SGD, SG_OPT_MOMENTUM, SG_OPT_ADADELTA = 0, 1, 2
 SG_EUNSUPPORTED = -4
 
 
@@ -17,15 +18,20 @@ class ConvShape(C.Structure):
 
 
 class ConvEpilogue(C.Structure):
-    _fields_ = [('bias', C.c_void_p), ('act', C.c_int32), ('slope', C.c_float), ('pixel_norm', C.c_int32),
+    """sg_conv_epilogue.  struct_size is filled in here: positional arguments start at `bias`."""
+    _fields_ = [('struct_size', C.c_uint32),
+                ('bias', C.c_void_p), ('act', C.c_int32), ('slope', C.c_float), ('pixel_norm', C.c_int32),
                 ('eps', C.c_float), ('pn_scale', C.c_void_p), ('mask_bits', C.c_void_p), ('mask_slope', C.c_float),
                 ('sign_out', C.c_void_p), ('out_scale', C.c_int32), ('out_off', C.c_int32 * 3),
                 ('tap_off', C.c_int32 * 3)]
 
+    def __init__(self, *args, **kw):
+        super().__init__(C.sizeof(type(self)), *args, **kw)
+
 
 class ProfEntry(C.Structure):
     _fields_ = [('kind', C.c_int32), ('shape', ConvShape), ('dtype', C.c_int32), ('launches', C.c_int64),
-                ('total_ms', C.c_double), ('flops_per_launch', C.c_double)]
+                ('total_ms', C.c_double), ('flops_per_launch', C.c_double), ('kernel', C.c_char * 64)]
 
 
 _p, _i32, _i64, _f, _u64, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_uint64, C.c_size_t
@@ -60,9 +66,11 @@ SIGNATURES = {
     'sg_minibatch_stddev_bwd': (C.c_int, [_p, _p, _p, _p, _i32, _i64, _i32, _i32, C.c_int, _p]),
     'sg_cast': (C.c_int, [_p, C.c_int, _p, C.c_int, _i64, _p]),
     'sg_adam_ema': (C.c_int, [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p]),
+    'sg_optim_step': (C.c_int, [C.c_int, _p, _p, _p, _p, _p, _i64, _f, _f, _f, C.c_int, _f, _f, _p]),
     'sg_segment_sumsq': (C.c_int, [_p, _p, _p, _i32, _p]),
     'sg_prof_enable': (C.c_int, [C.c_int]),
     'sg_prof_collect': (C.c_int, [C.POINTER(ProfEntry), _i32, C.POINTER(_i32)]),
+    'sg_config_reload': (C.c_int, []),
 }
 
 _lib = None

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include "../../include/saragan_hip.h"
 
 typedef __bf16 bf16_t;
@@ -20,6 +21,31 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
   } while (0)
 
 static inline hipStream_t sg_st(sg_stream_t s) { return (hipStream_t)s; }
+
+// Diagnostic switches (environment variables SG_*).  They are read ONCE, at the first launch that asks, into an
+// immutable snapshot; sg_config_reload() (include/saragan_hip.h) builds a new snapshot for tools that flip a switch
+// between launches.  Launch paths never call getenv.
+struct sg_config {
+  int fwd_lds, fwd_tg;                       // SG_FWD_LDS, SG_FWD_TG (0 = automatic)
+  int fwd_v1, fwd_no_pw, fwd_no_dense;       // SG_FWD_V1, SG_FWD_NO_PW, SG_FWD_NO_DENSE
+  int fwd_no_v3, fwd_no_v3s, fwd_no_v4, fwd_no_v5;   // SG_FWD_NO_V3, SG_FWD_NO_V3S, SG_FWD_NO_V4, SG_FWD_NO_V5
+  int fwd3_gx, fwd3_no_lean;                 // SG_FWD3_GX (0 = automatic), SG_FWD3_NO_LEAN
+  int fwd4_gx, fwd4_no_lean, fwd4_no_wres;   // SG_FWD4_GX (0 = automatic), SG_FWD4_NO_LEAN, SG_FWD4_NO_WRES
+  int wgrad_v1, wgrad_no_v3;                 // SG_WGRAD_V1, SG_WGRAD_NO_V3
+  int dbg_flags;                             // SG_DBG_FLAGS
+};
+const sg_config& sg_cfg();
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel symbol (idempotent; thread-safe).
+#define SG_ALLOW_160K_LDS(kern)                                                                                  \
+  do {                                                                                                           \
+    static std::once_flag once__;                                                                                \
+    static hipError_t err__ = hipSuccess;                                                                        \
+    std::call_once(once__, [&] {                                                                                 \
+      err__ = hipFuncSetAttribute((const void*)(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+    });                                                                                                          \
+    if (err__ != hipSuccess) return (int)err__;                                                                  \
+  } while (0)
 static inline size_t sg_esize(sg_dtype dt) { return dt == SG_BF16 ? 2 : 4; }
 static inline bool sg_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 

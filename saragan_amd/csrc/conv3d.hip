@@ -13,7 +13,6 @@
 // so a wave fetches a fragment with one lane-linear 1-KiB access (LDS-DMA friendly, conflict-free ds_read_b128).
 #include "common.h"
 #include "prof.h"
-#include <stdlib.h>
 
 // ------------------------------------------------------------------------------------------------------
 // weight packing
@@ -373,13 +372,9 @@ static int launch_fwd(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st) {
   const size_t lds = (size_t)a.xbytes + (size_t)TG * G * NTB * 1024;
   if (lds > 160 * 1024) return SG_EINVAL;
   auto kern = conv_fwd_kernel<T, MTW, NTB>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  SG_ALLOW_160K_LDS(kern);
   dim3 grid((unsigned)ntiles, (unsigned)sg_cdiv(a.ntile, NTB));
+  SG_KNAME("conv_fwd<%s,%d,%d>", sg_tname<T>(), MTW, NTB);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
   SG_LAUNCH_CHECK();
   return SG_OK;
@@ -570,11 +565,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd2_kernel(ConvFwdArgs a) {
   conv_epilogue<T, MTW, NTB>(acc, ooff, a, nt0, hh);
 }
 
-static int sg_env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v && *v ? atoi(v) : dflt;
-}
-
 template <typename T, int MTW, int NTB, int GC>
 static int launch_fwd2(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st) {
   constexpr int BM = MTW * 128;
@@ -583,7 +573,7 @@ static int launch_fwd2(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st) {
   const int64_t ntiles = (int64_t)g.nTn * g.nTd * g.nTh * g.nTw;
   if (ntiles >= (1 << 24)) return SG_EINVAL;
   const int hv = g.TN * g.HD * g.HH * g.HW;
-  const int lds_cap = sg_env_int("SG_FWD_LDS", 80 * 1024);   // per block; 80 KiB = two blocks per CU
+  const int lds_cap = sg_cfg().fwd_lds;   // per block; 80 KiB = two blocks per CU
   const int G = GC;
   a.G = G;
   a.rs = G * 32;
@@ -598,19 +588,15 @@ static int launch_fwd2(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st) {
   // even out the phases (e.g. 27 taps with room for 10 -> 3 phases of 9)
   const int nph = sg_cdiv(a.taps, TG);
   TG = sg_cdiv(a.taps, nph);
-  TG = sg_env_int("SG_FWD_TG", TG);
+  if (sg_cfg().fwd_tg > 0) TG = sg_cfg().fwd_tg;
   a.TG = TG;
   a.vec_in = 1;
   a.vec_out = (s->cout % 4 == 0) ? 1 : 0;
   const size_t lds = (size_t)a.xbytes + 2ull * TG * G * NTB * 1024;
   if (lds > 160 * 1024) return SG_EINVAL;
   auto kern = conv_fwd2_kernel<T, MTW, NTB, GC>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  SG_ALLOW_160K_LDS(kern);
+  SG_KNAME("conv_fwd2<%s,%d,%d,%d>", sg_tname<T>(), MTW, NTB, GC);
   dim3 grid((unsigned)ntiles, (unsigned)sg_cdiv(a.ntile, NTB));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, a);
   SG_LAUNCH_CHECK();
@@ -1035,18 +1021,14 @@ static int launch_fwd3r(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
   if (MTW == 2 && GC == 2 && !(g.TW == 32 && (g.TH & 1) == 0)) return SG_OK;   // shared address table (sg_xa_index)
   // buffer addressing of the halo: per-lane offsets are relative to the tile's first sample
   a.lean = (!s->upsample_in && (int64_t)g.TN * s->d * s->h * s->w * (int64_t)s->cin * (int64_t)sizeof(T) < (1ll << 31) &&
-            !sg_env_int("SG_FWD3_NO_LEAN", 0)) ? 1 : 0;
+            !sg_cfg().fwd3_no_lean) ? 1 : 0;
   auto kern = conv_fwd3r_kernel<T, MTW, GC, KD, KH, KW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  SG_ALLOW_160K_LDS(kern);
   int gx = 256 / a.ntile;            // one block per CU in total
   gx = (gx / 8) * 8;
   if (gx < 8) gx = 8;
-  gx = sg_env_int("SG_FWD3_GX", gx);
+  if (sg_cfg().fwd3_gx > 0) gx = sg_cfg().fwd3_gx;
+  SG_KNAME("conv_fwd3r<%s,%d,%d,%d,%d,%d>", sg_tname<T>(), MTW, GC, KD, KH, KW);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.ntile), dim3(512), lds, st, a);
   SG_LAUNCH_CHECK();
   *used = true;
@@ -1480,12 +1462,8 @@ static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
   a.vec_in = 1;
   a.vec_out = (s->cout % 4 == 0) ? 1 : 0;
   auto kern = conv_fwd3s_kernel<T, GC>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  SG_ALLOW_160K_LDS(kern);
+  SG_KNAME("conv_fwd3s<%s,%d>", sg_tname<T>(), GC);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.ntile), dim3(512), lds, st, a);
   SG_LAUNCH_CHECK();
   *used = true;
@@ -1849,7 +1827,7 @@ static int launch_fwd4(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, b
   const int ny = sg_cdiv(a.ntile, NTB);
   int gx = (256 / ny) / 8 * 8;
   if (gx < 8) gx = 8;
-  gx = sg_env_int("SG_FWD4_GX", gx);   // tests shrink the grid to reach this kernel with small tensors
+  if (sg_cfg().fwd4_gx > 0) gx = sg_cfg().fwd4_gx;   // tools shrink the grid to reach this kernel with small tensors
   if (gx < 8 || (gx & 7)) return SG_EINVAL;
   if (ntiles >= (1 << 24) || ntiles < 2 * gx) return SG_OK;
   // per-lane halo offsets are relative to the tile's first sample: only TN samples have to fit 31 bits
@@ -1860,24 +1838,20 @@ static int launch_fwd4(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, b
   a.xbytes = hv * 32;   // exact: lanes beyond the last row are masked off in the LDS-DMA
   // buffer resource rebased per tile sample; with the fused x2 gather the tile origins must be even
   a.lean = ((!s->upsample_in || (g.TD % 2 == 0 && g.TH % 2 == 0 && g.TW % 2 == 0 && g.TN == 1)) &&
-            !sg_env_int("SG_FWD4_NO_LEAN", 0)) ? 1 : 0;
+            !sg_cfg().fwd4_no_lean) ? 1 : 0;
   a.wbytes = a.taps * NTB * 1024;
   if (sg_cdiv(hv * 2, 64) > 32) return SG_OK;
   if (MTW == 2 && NTB == 2 && !(g.TW == 32 && (g.TH & 1) == 0)) return SG_OK;   // shared address table (sg_xa_index)
   size_t lds = 2ull * a.xbytes + (size_t)a.nchunk * a.wbytes + NTB * 128;
-  a.wres = (lds <= 160 * 1024 && !sg_env_int("SG_FWD4_NO_WRES", 0)) ? 1 : 0;
+  a.wres = (lds <= 160 * 1024 && !sg_cfg().fwd4_no_wres) ? 1 : 0;
   if (!a.wres) lds = 2ull * a.xbytes + 2ull * a.wbytes + NTB * 128;
   if (lds > 160 * 1024) return SG_OK;
   a.ntiles = (int)ntiles;
   a.vec_in = 1;
   a.vec_out = (s->cout % 4 == 0) ? 1 : 0;
   auto kern = conv_fwd4_kernel<T, MTW, NTB, KD, KH, KW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  SG_ALLOW_160K_LDS(kern);
+  SG_KNAME("conv_fwd4<%s,%d,%d,%d,%d,%d>", sg_tname<T>(), MTW, NTB, KD, KH, KW);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ny), dim3(512), lds, st, a);
   SG_LAUNCH_CHECK();
   *used = true;
@@ -2072,7 +2046,8 @@ static int launch_pw_fwd(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st,
   constexpr int E = 16 / (int)sizeof(T);
   if (a.taps != 1 || s->upsample_in || a.pixel_norm) return SG_OK;
   const int64_t nvox = (int64_t)s->n * s->d * s->h * s->w;
-  if (nvox <= 32 && s->cin % sg_traits<T>::CH == 0 && a.nchunk >= 64 && !sg_env_int("SG_FWD_NO_DENSE", 0)) {
+  if (nvox <= 32 && s->cin % sg_traits<T>::CH == 0 && a.nchunk >= 64 && !sg_cfg().fwd_no_dense) {
+    SG_KNAME("dense_small_m<%s>", sg_tname<T>());
     hipLaunchKernelGGL(dense_small_m_kernel<T>, dim3((unsigned)a.ntile), dim3(1024), 0, st, a, (int)nvox);
     SG_LAUNCH_CHECK();
     *used = true;
@@ -2083,6 +2058,7 @@ static int launch_pw_fwd(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st,
     const int rows = 256 / (s->cout / E);
     int64_t nb = (nvox + rows - 1) / rows;
     if (nb > 8192) nb = 8192;
+    SG_KNAME("pw_fwd_small_cin<%s>", sg_tname<T>());
     hipLaunchKernelGGL(pw_fwd_small_cin_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, a, nvox);
     SG_LAUNCH_CHECK();
     *used = true;
@@ -2090,6 +2066,7 @@ static int launch_pw_fwd(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st,
     const int rows = 256 / (s->cin / E);
     int64_t nb = (nvox + rows - 1) / rows;
     if (nb > 8192) nb = 8192;
+    SG_KNAME("pw_fwd_small_cout<%s>", sg_tname<T>());
     hipLaunchKernelGGL(pw_fwd_small_cout_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, a, nvox);
     SG_LAUNCH_CHECK();
     *used = true;
@@ -2103,6 +2080,7 @@ extern "C" __attribute__((visibility("default"))) void sg_debug_set_ts_buffer(vo
 extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_conv_shape* s,
                              const sg_conv_epilogue* ep, sg_dtype dt, sg_stream_t st) {
   if (!conv_shape_ok(s) || !x || !wp || !y) return SG_EINVAL;
+  if (ep && ep->struct_size != (uint32_t)sizeof(sg_conv_epilogue)) return SG_EINVAL;   // caller built against another header
   if (!sg_aligned16(x) || !sg_aligned16(wp) || !sg_aligned16(y)) return SG_EALIGN;
   ConvFwdArgs a;
   a.x = x; a.wp = wp; a.y = y;
@@ -2121,7 +2099,7 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
   const bool subpixel = a.os == 2 || a.tap_d || a.tap_h || a.tap_w || s->kd == 2;
   if (subpixel && ((a.tap_d | a.tap_h | a.tap_w | a.oa | a.ob | a.oc) & ~1)) return SG_EINVAL;
   a.dbg = g_dbg_ts;
-  a.dbg_flags = sg_env_int("SG_DBG_FLAGS", 0);
+  a.dbg_flags = sg_cfg().dbg_flags;
   a.cin = s->cin; a.cout = s->cout;
   a.taps = s->kd * s->kh * s->kw; a.kh = s->kh; a.kw = s->kw;
   a.nchunk = conv_nchunk(s, dt);
@@ -2144,17 +2122,17 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     prof.done(rc);
     return rc;
   }
-  if (!sg_env_int("SG_FWD_NO_PW", 0)) {   // streaming kernels for the 1x1x1 layers with <= 4 channels on one side
+  if (!sg_cfg().fwd_no_pw) {   // streaming kernels for the 1x1x1 layers with <= 4 channels on one side
     bool used = false;
     rc = dt == SG_BF16 ? launch_pw_fwd<bf16_t>(a, s, hs, &used) : launch_pw_fwd<float>(a, s, hs, &used);
     if (rc != SG_OK || used) { prof.done(rc); return rc; }
   }
-  const bool v2 = ((s->cin * es) % 16 == 0) && !sg_env_int("SG_FWD_V1", 0);
-  if (v2 && !sg_env_int("SG_FWD_NO_V3", 0) && (!a.pixel_norm || a.ntile == 1)) {
+  const bool v2 = ((s->cin * es) % 16 == 0) && !sg_cfg().fwd_v1;
+  if (v2 && !sg_cfg().fwd_no_v3 && (!a.pixel_norm || a.ntile == 1)) {
     bool used = false;
     rc = SG_OK;
     const bool k333 = s->kd == 3 && s->kh == 3 && s->kw == 3, k133 = s->kd == 1 && s->kh == 3 && s->kw == 3;
-    if (dt == SG_BF16 && k333 && !sg_env_int("SG_FWD_NO_V3S", 0)) {   // sliding-halo variant where its tile fits
+    if (dt == SG_BF16 && k333 && !sg_cfg().fwd_no_v3s) {   // sliding-halo variant where its tile fits
       if (a.nchunk == 2) rc = launch_fwd3s<bf16_t, 2>(a, s, hs, &used);
       else if (a.nchunk == 1) rc = launch_fwd3s<bf16_t, 1>(a, s, hs, &used);
       if (rc != SG_OK || used) { prof.done(rc); return rc; }
@@ -2172,7 +2150,7 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     }
     if (rc != SG_OK || used) { prof.done(rc); return rc; }
   }
-  if (v2 && !sg_env_int("SG_FWD_NO_V4", 0) && (!a.pixel_norm || a.ntile <= 2)) {
+  if (v2 && !sg_cfg().fwd_no_v4 && (!a.pixel_norm || a.ntile <= 2)) {
     bool used = false;
     rc = SG_OK;
     const bool k333 = s->kd == 3 && s->kh == 3 && s->kw == 3, k133 = s->kd == 1 && s->kh == 3 && s->kw == 3;

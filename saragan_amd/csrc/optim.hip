@@ -44,6 +44,66 @@ __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__
   }
 }
 
+// tf.train.GradientDescentOptimizer / MomentumOptimizer(use_nesterov) / AdadeltaOptimizer(rho, epsilon) as created
+// at SURFGAN_3D/optimization.py:17-22,29-35, fused with the EMA update like Adam above.  TF's update rules
+// (training_ops: ApplyGradientDescent, ApplyMomentum, ApplyAdadelta):
+//   SGD       p -= lr * g
+//   Momentum  a = h * a + g;  p -= nesterov ? lr * g + lr * h * a : lr * a
+//   Adadelta  a = h * a + (1-h) g^2;  u = sqrt(a2 + eps) * rsqrt(a + eps) * g;  p -= lr * u;  a2 = h * a2 + (1-h) u^2
+template <int KIND>
+__device__ __forceinline__ void optim_rule(float& p, float g, float& s1, float& s2, float lr, float h, float eps,
+                                           int nesterov) {
+  if (KIND == SG_OPT_SGD) {
+    p -= lr * g;
+  } else if (KIND == SG_OPT_MOMENTUM) {
+    s1 = h * s1 + g;
+    p -= nesterov ? (lr * g + lr * h * s1) : lr * s1;
+  } else {
+    s1 = h * s1 + (1.f - h) * g * g;
+    const float u = sqrtf(s2 + eps) * rsqrtf(s1 + eps) * g;
+    p -= lr * u;
+    s2 = h * s2 + (1.f - h) * u * u;
+  }
+}
+
+template <int KIND>
+__global__ void optim_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ s1,
+                                  float* __restrict__ s2, float* __restrict__ ema, int64_t numel, float lr, float h,
+                                  float eps, int nesterov, float gscale, float ema_decay) {
+  const int64_t nv = numel / 4;
+  const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  const float omd = 1.f - ema_decay;
+  for (int64_t i = tid0; i < nv; i += stride) {
+    f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
+    const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i] * gscale;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    if (KIND != SG_OPT_SGD) a = reinterpret_cast<f32x4*>(s1)[i];
+    if (KIND == SG_OPT_ADADELTA) b = reinterpret_cast<f32x4*>(s2)[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {   // (ext-vector elements cannot bind to references)
+      float pe = pp[e], ae = a[e], be = b[e];
+      optim_rule<KIND>(pe, gg[e], ae, be, lr, h, eps, nesterov);
+      pp[e] = pe; a[e] = ae; b[e] = be;
+    }
+    if (KIND != SG_OPT_SGD) reinterpret_cast<f32x4*>(s1)[i] = a;
+    if (KIND == SG_OPT_ADADELTA) reinterpret_cast<f32x4*>(s2)[i] = b;
+    reinterpret_cast<f32x4*>(p)[i] = pp;
+    if (ema) {
+      f32x4 ee = reinterpret_cast<f32x4*>(ema)[i];
+      ee -= omd * (ee - pp);
+      reinterpret_cast<f32x4*>(ema)[i] = ee;
+    }
+  }
+  for (int64_t i = nv * 4 + tid0; i < numel; i += stride) {
+    float pp = p[i], a = KIND != SG_OPT_SGD ? s1[i] : 0.f, b = KIND == SG_OPT_ADADELTA ? s2[i] : 0.f;
+    optim_rule<KIND>(pp, g[i] * gscale, a, b, lr, h, eps, nesterov);
+    if (KIND != SG_OPT_SGD) s1[i] = a;
+    if (KIND == SG_OPT_ADADELTA) s2[i] = b;
+    p[i] = pp;
+    if (ema) ema[i] -= omd * (ema[i] - pp);
+  }
+}
+
 __global__ __launch_bounds__(256) void segment_sumsq_kernel(const float* __restrict__ flat,
                                                             const int64_t* __restrict__ offsets,
                                                             float* __restrict__ out) {
@@ -74,6 +134,32 @@ extern "C" int sg_adam_ema(float* p, const float* g, float* m, float* v, float* 
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, sg_st(st), p, g, m, v, ema, numel, lr_t,
                      b1, b2, eps, gscale, ema_decay);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_optim_step(int kind, float* p, const float* g, float* s1, float* s2, float* ema, int64_t numel,
+                             float lr, float h, float eps, int nesterov, float gscale, float ema_decay,
+                             sg_stream_t st) {
+  if (!p || !g || numel < 1) return SG_EINVAL;
+  if (kind != SG_OPT_SGD && kind != SG_OPT_MOMENTUM && kind != SG_OPT_ADADELTA) return SG_EINVAL;
+  if ((kind != SG_OPT_SGD && !s1) || (kind == SG_OPT_ADADELTA && !s2)) return SG_EINVAL;
+  if (!sg_aligned16(p) || !sg_aligned16(g) || (s1 && !sg_aligned16(s1)) || (s2 && !sg_aligned16(s2)) ||
+      (ema && !sg_aligned16(ema)))
+    return SG_EALIGN;
+  int64_t blocks = (numel / 4 + 255) / 256;
+  if (blocks < 1) blocks = 1;
+  if (blocks > 2048) blocks = 2048;
+  const dim3 grid((unsigned)blocks), blk(256);
+  if (kind == SG_OPT_SGD)
+    hipLaunchKernelGGL(optim_step_kernel<SG_OPT_SGD>, grid, blk, 0, sg_st(st), p, g, s1, s2, ema, numel, lr, h, eps,
+                       nesterov, gscale, ema_decay);
+  else if (kind == SG_OPT_MOMENTUM)
+    hipLaunchKernelGGL(optim_step_kernel<SG_OPT_MOMENTUM>, grid, blk, 0, sg_st(st), p, g, s1, s2, ema, numel, lr, h,
+                       eps, nesterov, gscale, ema_decay);
+  else
+    hipLaunchKernelGGL(optim_step_kernel<SG_OPT_ADADELTA>, grid, blk, 0, sg_st(st), p, g, s1, s2, ema, numel, lr, h,
+                       eps, nesterov, gscale, ema_decay);
   SG_LAUNCH_CHECK();
   return SG_OK;
 }

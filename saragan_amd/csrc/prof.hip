@@ -3,20 +3,71 @@
 #include <mutex>
 #include <vector>
 #include <string.h>
+#include <stdlib.h>
+#include <atomic>
 
 namespace {
-struct Rec { int kind; sg_conv_shape shape; int dtype; hipEvent_t e0, e1; bool ok; };
+struct Rec { int kind; sg_conv_shape shape; int dtype; hipEvent_t e0, e1; bool ok; const char* name; };
 std::mutex g_mu;
 bool g_on = false;
 std::vector<Rec> g_recs;
-const char* kVersion = "saragan_hip 0.1 (gfx950)";
+const char* kVersion = "saragan_hip 0.2 (gfx950)";
 }  // namespace
 
 bool sg_prof_on() { return g_on; }
+thread_local const char* sg_tls_kernel = "";
+
+namespace {
+std::atomic<const sg_config*> g_cfg{nullptr};
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
+const sg_config* read_config() {
+  sg_config* c = new sg_config;   // snapshots are never freed: a launch may still hold the previous one
+  c->fwd_lds = env_int("SG_FWD_LDS", 80 * 1024);
+  c->fwd_tg = env_int("SG_FWD_TG", 0);
+  c->fwd_v1 = env_int("SG_FWD_V1", 0);
+  c->fwd_no_pw = env_int("SG_FWD_NO_PW", 0);
+  c->fwd_no_dense = env_int("SG_FWD_NO_DENSE", 0);
+  c->fwd_no_v3 = env_int("SG_FWD_NO_V3", 0);
+  c->fwd_no_v3s = env_int("SG_FWD_NO_V3S", 0);
+  c->fwd_no_v4 = env_int("SG_FWD_NO_V4", 0);
+  c->fwd_no_v5 = env_int("SG_FWD_NO_V5", 0);
+  c->fwd3_gx = env_int("SG_FWD3_GX", 0);
+  c->fwd3_no_lean = env_int("SG_FWD3_NO_LEAN", 0);
+  c->fwd4_gx = env_int("SG_FWD4_GX", 0);
+  c->fwd4_no_lean = env_int("SG_FWD4_NO_LEAN", 0);
+  c->fwd4_no_wres = env_int("SG_FWD4_NO_WRES", 0);
+  c->wgrad_v1 = env_int("SG_WGRAD_V1", 0);
+  c->wgrad_no_v3 = env_int("SG_WGRAD_NO_V3", 0);
+  c->dbg_flags = env_int("SG_DBG_FLAGS", 0);
+  return c;
+}
+}  // namespace
+
+const sg_config& sg_cfg() {
+  const sg_config* c = g_cfg.load(std::memory_order_acquire);
+  if (c == nullptr) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    c = g_cfg.load(std::memory_order_acquire);
+    if (c == nullptr) {
+      c = read_config();
+      g_cfg.store(c, std::memory_order_release);
+    }
+  }
+  return *c;
+}
+
+extern "C" int sg_config_reload(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_cfg.store(read_config(), std::memory_order_release);
+  return SG_OK;
+}
 
 void sg_prof_begin(int kind, const sg_conv_shape* s, sg_dtype dt, hipStream_t st, int* slot) {
   std::lock_guard<std::mutex> lk(g_mu);
-  Rec r; r.kind = kind; r.shape = *s; r.dtype = (int)dt; r.ok = false;
+  Rec r; r.kind = kind; r.shape = *s; r.dtype = (int)dt; r.ok = false; r.name = "";
   if (hipEventCreate(&r.e0) != hipSuccess) { *slot = -1; return; }
   if (hipEventCreate(&r.e1) != hipSuccess) { (void)hipEventDestroy(r.e0); *slot = -1; return; }
   (void)hipEventRecord(r.e0, st);
@@ -31,6 +82,11 @@ void sg_prof_end(int slot, hipStream_t st) {
   if (idx < 0 || idx >= (int)g_recs.size()) return;
   (void)hipEventRecord(g_recs[idx].e1, st);
   g_recs[idx].ok = ok;
+}
+
+void sg_prof_name(int slot, const char* name) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (slot >= 0 && slot < (int)g_recs.size()) g_recs[slot].name = name;
 }
 
 extern "C" const char* sg_version(void) { return kVersion; }
@@ -75,6 +131,8 @@ extern "C" int sg_prof_collect(sg_prof_entry* out, int32_t max_entries, int32_t*
       out[n].kind = r.kind; out[n].shape = r.shape; out[n].dtype = r.dtype; out[n].launches = 0; out[n].total_ms = 0;
       const sg_conv_shape& s = r.shape;
       out[n].flops_per_launch = 2.0 * s.n * s.d * s.h * s.w * (double)s.cin * s.cout * s.kd * s.kh * s.kw;
+      strncpy(out[n].kernel, r.name ? r.name : "", sizeof(out[n].kernel) - 1);
+      out[n].kernel[sizeof(out[n].kernel) - 1] = 0;
       ++n;
     }
     out[j].launches += 1;

@@ -295,12 +295,7 @@ static int launch_wgrad(WgradArgs& a, const sg_conv_shape* s, hipStream_t st) {
   const size_t lds = (size_t)a.xbytes + a.ybytes + BM * 4;
   if (lds > 160 * 1024) return SG_EINVAL;
   auto kern = conv_wgrad_kernel<T, BM>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  SG_ALLOW_160K_LDS(kern);
   const int pairs = a.ciT * a.coT;
   int P = sg_cdiv(768, pairs);
   if (P > a.ntiles) P = a.ntiles;
@@ -308,6 +303,7 @@ static int launch_wgrad(WgradArgs& a, const sg_conv_shape* s, hipStream_t st) {
   for (int tap0 = 0; tap0 < a.taps; tap0 += 4 * WG_MAXT) {
     a.tap0 = tap0;
     a.taps_blk = a.taps - tap0 < 4 * WG_MAXT ? a.taps - tap0 : 4 * WG_MAXT;
+    SG_KNAME("conv_wgrad<%s,%d>", sg_tname<T>(), BM);
     hipLaunchKernelGGL(kern, dim3((unsigned)P, (unsigned)pairs), dim3(256), lds, st, a);
     SG_LAUNCH_CHECK();
   }
@@ -562,13 +558,9 @@ static int launch_wgrad2(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   const size_t lds = 2ull * (a.xbytes + a.ybytes);
   if (lds > 160 * 1024) return SG_OK;
   auto kern = conv_wgrad2_kernel<KD, KH, KW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  SG_ALLOW_160K_LDS(kern);
   a.tap0 = 0; a.taps_blk = a.taps;
+  SG_KNAME("conv_wgrad2<%d,%d,%d>", KD, KH, KW);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);
   SG_LAUNCH_CHECK();
   *used = true;
@@ -901,13 +893,9 @@ static int launch_wgrad3(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   const size_t lds = 2ull * (a.xbytes + a.ybytes);
   if (lds > 160 * 1024) return SG_OK;
   auto kern = conv_wgrad3_kernel<KD, KH, KW>;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  SG_ALLOW_160K_LDS(kern);
   a.tap0 = 0; a.taps_blk = a.taps;
+  SG_KNAME("conv_wgrad3<%d,%d,%d>", KD, KH, KW);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);
   SG_LAUNCH_CHECK();
   *used = true;
@@ -947,6 +935,7 @@ extern "C" int sg_conv3d_wgrad_bias(const void* x, const void* dy, float* dw, fl
       if (nb > 1024) nb = 1024;
       float* part = reinterpret_cast<float*>(workspace);
       const int ones = (dbias != nullptr && small_is_cin) ? 1 : 0;   // the big side is dy: its column sums are the bias gradient
+      SG_KNAME("pw_wgrad_partial");
       if (dt == SG_BF16)
         hipLaunchKernelGGL(pw_wgrad_partial_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, hs, (const bf16_t*)sm,
                            (const bf16_t*)bg, part, nvox, cs, cb, ones);
@@ -970,18 +959,18 @@ extern "C" int sg_conv3d_wgrad_bias(const void* x, const void* dy, float* dw, fl
   WgradArgs a;
   a.dbias = dbias;
   bool db_done = false;
-  a.dbg_flags = getenv("SG_DBG_FLAGS") ? atoi(getenv("SG_DBG_FLAGS")) : 0;
+  a.dbg_flags = sg_cfg().dbg_flags;
   a.x = x; a.dy = dy; a.dwt = reinterpret_cast<float*>(workspace);
   a.cin = s->cin; a.cout = s->cout;
   a.taps = s->kd * s->kh * s->kw; a.kh = s->kh; a.kw = s->kw;
   a.ciT = sg_cdiv(s->cin, 32); a.coT = sg_cdiv(s->cout, 32);
   int rc = SG_OK;
   bool used = false;
-  if (dt == SG_BF16 && !getenv("SG_WGRAD_V1") && !getenv("SG_WGRAD_NO_V3")) {
+  if (dt == SG_BF16 && !sg_cfg().wgrad_v1 && !sg_cfg().wgrad_no_v3) {
     if (s->kd == 3 && s->kh == 3 && s->kw == 3) rc = launch_wgrad3<3, 3, 3>(a, s, hs, &used);
     db_done = used;   // the sliding-halo kernel accumulates the bias gradient in its spare tap slot
   }
-  if (rc == SG_OK && !used && dt == SG_BF16 && !getenv("SG_WGRAD_V1")) {
+  if (rc == SG_OK && !used && dt == SG_BF16 && !sg_cfg().wgrad_v1) {
     if (s->kd == 3 && s->kh == 3 && s->kw == 3) rc = launch_wgrad2<3, 3, 3>(a, s, hs, &used);
     else if (s->kd == 1 && s->kh == 3 && s->kw == 3) rc = launch_wgrad2<1, 3, 3>(a, s, hs, &used);
   }

@@ -1,85 +1,135 @@
-"""Mirror of SURFGAN_3D/dataset.py for the training loop: NumpyPathDataset (path dataset over `*.npy`
-volumes, shuffled sample buffer, batch / batch_mpi / repeat / split_by_fraction) and the numpy
-normalisation helpers, plus a pinned-memory prefetcher that overlaps np.load + host-to-device copies with the
-step (the reference loads synchronously on the training thread, optuna_objective.py:422-428).
+"""Per-phase `.npy` volume source for the training loop: the interface of SURFGAN_3D/dataset.py
+(`NumpyPathDataset.batch / batch_mpi / repeat / split_by_fraction`, `normalize_numpy`; reference dataset.py:78-118,
+163-349, protocol self-test :357-395) on a design of its own:
 
-batch_mpi(): the reference lets rank 0 draw the global batch and MPI-scatters the file lists
-(dataset.py:307-333).  Here every rank keeps the SAME sample buffer (same shuffle seed) and takes its
-column of the (-1, world) reshape, which is exactly what the scatter delivered: no collective on the data path.
+* a dataset is a table of files plus an **index deck** (`_Deck`): a queue of integer positions into the table,
+  reshuffled epoch by epoch from a private `random.Random(seed)`.  Drawing a batch pops positions; file names only
+  appear when a batch is materialised.  `samplebuffer` is kept as a property (a path view of the deck) because the
+  reference's callers and its self-test inspect it.
+* `batch_mpi()`: the reference lets rank 0 draw `batch * world` paths and MPI-scatters the columns of the
+  `(-1, world)` reshape (dataset.py:307-333).  Here every rank owns the same deck (same seed, sorted table) and
+  takes column `rank` itself: same partition of every epoch, no collective on the data path.
+* scratch staging (dataset.py:163-200): ONE process per node (`local_rank == 0`) copies, through a temporary name
+  and an atomic rename so a half-written file is never visible under its final name; every process then waits until
+  the whole table is present (the reference's busy-wait, dataset.py:176-177).
+* `PinnedPrefetcher`: a ring of preallocated pinned host buffers and device buffers.  A worker thread fills slot
+  after slot (np.load straight into the pinned buffer, normalise in place, `hipMemcpyAsync` on a side stream); a
+  slot is reused only after an event recorded on the CONSUMER's stream, once the consumer has moved on to the next
+  batch, has completed -- the step that reads a batch can never see it overwritten.
 """
-import copy
 import glob
 import os
+import queue
 import random
 import shutil
 import threading
-import queue
+import time
 
 import numpy as np
 
 
+def _norm_args(mean, stddev, what):
+    """Both given -> True, neither -> False (with the reference's notice), one of them -> error (dataset.py:87-95)."""
+    if (mean is None) != (stddev is None):
+        given, missing = ('data_stddev', 'data_mean') if mean is None else ('data_mean', 'data_stddev')
+        raise Exception(f"ERROR: {given} was defined, but {missing} was not. Either define both to apply input "
+                        f"normalization, or define neither to not apply input normalization")
+    if mean is None:
+        print(f"INFO: no data_mean or data_stddev was defined, not {what} of the input data")
+        return False
+    return True
+
+
 def normalize_numpy(unnormalized_input, mean, stddev, verbose=False):
-    """dataset.py:78-97."""
-    if mean is None and stddev is None:
-        print("INFO: no data_mean or data_stddev was defined, not normalizing the input data")
+    """(x - mean) / stddev, or x unchanged when neither is given (reference dataset.py:78-97)."""
+    if not _norm_args(mean, stddev, 'normalizing'):
         return unnormalized_input
-    elif mean is None and stddev is not None:
-        raise Exception("ERROR: data_stddev was defined, but data_mean was not. Either define both to apply input normalization, or define neither to not apply input normalization")
-    elif mean is not None and stddev is None:
-        raise Exception("ERROR: data_mean was defined, but data_stddev was not. Either define both to apply input normalization, or define neither to not apply input normalization")
     return (unnormalized_input - mean) / stddev
 
 
 def invert_normalize_numpy(normalized_input, mean, stddev, verbose=False):
-    """dataset.py:99-118."""
-    if mean is None and stddev is None:
-        print("INFO: no data_mean or data_stddev was defined, not inverting normalizing of the input data")
+    """x * stddev + mean (reference dataset.py:99-118)."""
+    if not _norm_args(mean, stddev, 'inverting normalizing'):
         return normalized_input
-    elif mean is None and stddev is not None:
-        raise Exception("ERROR: data_stddev was defined, but data_mean was not. Either define both to apply input normalization, or define neither to not apply input normalization")
-    elif mean is not None and stddev is None:
-        raise Exception("ERROR: data_mean was defined, but data_stddev was not. Either define both to apply input normalization, or define neither to not apply input normalization")
     return (normalized_input * stddev) + mean
 
 
-class NumpyPathDataset:
-    """dataset.py:155-349."""
+class _Deck:
+    """Queue of table positions; `refill()` appends one freshly shuffled epoch (reference `repeat()`)."""
 
-    def __init__(self, npy_dir, scratch_dir, copy_files, is_correct_phase, rank=0, world_size=1, seed=None):
-        self.npy_files = sorted(glob.glob(npy_dir + '*.npy'))   # sorted: every rank must see the same order
+    def __init__(self, size, rng):
+        self.size, self.rng = size, rng
+        self.cards = []
+        self.refill()
+
+    def refill(self):
+        epoch = list(range(self.size))
+        self.rng.shuffle(epoch)
+        self.cards.extend(epoch)
+
+    def draw(self, count, refill):
+        """Pops `count` positions.  Short deck: refill until it is long enough, or (refill=False) hand out the rest
+        WITHOUT consuming it, as the reference does (dataset.py:276-278)."""
+        while count > len(self.cards):
+            if not refill or self.size == 0:
+                return list(self.cards)
+            self.refill()
+        out, self.cards = self.cards[:count], self.cards[count:]
+        return out
+
+
+class NumpyPathDataset:
+    """Files `npy_dir*.npy` (optionally staged under `scratch_dir`), drawn epoch-wise in shuffled order."""
+
+    def __init__(self, npy_dir, scratch_dir, copy_files, is_correct_phase, rank=0, world_size=1, seed=None,
+                 stage_timeout=3600.0):
+        self.rank, self.world_size = int(rank), int(world_size)
+        self._rng = random.Random(seed) if seed is not None else random.Random()
+        self.npy_files = sorted(glob.glob(npy_dir + '*.npy'))   # sorted: every rank must hold the same table
         print(f"Length of dataset: {len(self.npy_files)}")
-        self.rank, self.world_size = rank, world_size
-        self._rng = random.Random(seed) if seed is not None else random
-        if scratch_dir is not None and scratch_dir[-1] == '/':
-            scratch_dir = scratch_dir[:-1]
-        if scratch_dir is None:
+        staged = scratch_dir is not None and is_correct_phase
+        if staged:
+            root = scratch_dir.rstrip('/')
+            self.scratch_dir = os.path.normpath(root + npy_dir)
+            self.scratch_files = [os.path.normpath(root + f) for f in self.npy_files]
+            if copy_files:
+                self._stage(self.npy_files, self.scratch_files)
+            self._await_files(self.scratch_files, stage_timeout)
+        else:
             self.scratch_dir = os.path.normpath(npy_dir)
             self.scratch_files = list(self.npy_files)
-        else:
-            self.scratch_dir = os.path.normpath(scratch_dir + npy_dir) if is_correct_phase else npy_dir
-            self._copy_files_to_scratch(scratch_dir, copy_files, is_correct_phase)
-            self.scratch_files = sorted(glob.glob(self.scratch_dir + '/*.npy'))
-            assert len(self.scratch_files) == len(self.npy_files)
-        self._init_samplebuffer()
-        if len(self.scratch_files) > 0:
-            test_npy_array = np.load(self.scratch_files[0], mmap_mode='r')[np.newaxis, ...]
-            self.shape, self.dtype = test_npy_array.shape, test_npy_array.dtype
-            del test_npy_array
+        self._deck = _Deck(len(self.scratch_files), self._rng)
+        self.shape = self.dtype = None
+        if self.scratch_files:
+            probe = np.load(self.scratch_files[0], mmap_mode='r')
+            self.shape, self.dtype = (1,) + tuple(probe.shape), probe.dtype
+            del probe
 
-    def _copy_files_to_scratch(self, scratch_dir, copy_files, is_correct_phase):
-        if copy_files and is_correct_phase:
-            os.makedirs(self.scratch_dir, exist_ok=True)
-            for f in self.npy_files:
-                if not os.path.isfile(os.path.normpath(scratch_dir + f)):
-                    shutil.copy(f, os.path.normpath(scratch_dir + f))
+    # ---- scratch staging ----------------------------------------------------------------------------------
+    @staticmethod
+    def _stage(sources, targets):
+        for src, dst in zip(sources, targets):
+            if os.path.isfile(dst):
+                continue
+            os.makedirs(os.path.dirname(dst), exist_ok=True)
+            tmp = f'{dst}.part{os.getpid()}'
+            shutil.copy(src, tmp)
+            os.replace(tmp, dst)       # atomic: readers see the whole file or none
 
-    def _init_samplebuffer(self):
-        self.samplebuffer = self.scratch_files[:]
-        self._rng.shuffle(self.samplebuffer)
+    @staticmethod
+    def _await_files(paths, timeout):
+        deadline = time.time() + timeout
+        missing = list(paths)
+        while missing:
+            missing = [p for p in missing if not os.path.isfile(p)]
+            if missing:
+                if time.time() > deadline:
+                    raise TimeoutError(f'{len(missing)} file(s) never reached the scratch directory, e.g. {missing[0]}')
+                time.sleep(0.2)
 
+    # ---- the table ----------------------------------------------------------------------------------------
     def __iter__(self):
-        for path in self.scratch_files:
-            yield path
+        return iter(self.scratch_files)
 
     def __getitem__(self, idx):
         return self.scratch_files[idx]
@@ -87,124 +137,191 @@ class NumpyPathDataset:
     def __len__(self):
         return len(self.scratch_files)
 
-    def split_by_fraction(self, fraction):
-        nsamples_dataset1 = int(np.round(fraction * len(self.scratch_files)) + 1e-5)
-        nsamples_dataset2 = len(self.scratch_files)
-        assert nsamples_dataset1 > 0 and nsamples_dataset2 > 0
-        return self.split_by_index(nsamples_dataset1)
+    def _subset(self, lo, hi):
+        part = object.__new__(NumpyPathDataset)
+        part.__dict__.update(self.__dict__)
+        part.npy_files, part.scratch_files = self.npy_files[lo:hi], self.scratch_files[lo:hi]
+        part._rng = random.Random(self._rng.random())       # children shuffle independently of the parent
+        part._deck = _Deck(len(part.scratch_files), part._rng)
+        return part
 
     def split_by_index(self, index):
-        dataset1, dataset2 = copy.deepcopy(self), copy.deepcopy(self)
-        dataset1.scratch_files, dataset2.scratch_files = self.scratch_files[0:index], self.scratch_files[index:]
-        dataset1.npy_files, dataset2.npy_files = self.npy_files[0:index], self.npy_files[index:]
-        dataset1._init_samplebuffer()
-        dataset2._init_samplebuffer()
-        return dataset1, dataset2
+        """Two datasets: table rows [0, index) and [index, end)."""
+        return self._subset(0, index), self._subset(index, len(self.scratch_files))
 
-    def _load_batch_from_filelist(self, batch_paths):
-        batch = [np.load(path).astype('float32') for path in batch_paths]
-        if len(batch) > 0:
-            batch = np.stack(batch)
-            batch = batch[:, np.newaxis, ...]
-        return batch
+    def split_by_fraction(self, fraction):
+        """E.g. 0.8 -> (first 80 % of the table, the rest), rounded to the nearest sample (dataset.py:218-233)."""
+        first = int(np.round(fraction * len(self.scratch_files)) + 1e-5)
+        assert first > 0 and len(self.scratch_files) > 0
+        return self.split_by_index(first)
 
-    def batch_paths(self, batch_size, auto_repeat=True):
-        if batch_size > len(self.samplebuffer):
-            if auto_repeat:
-                self.repeat()
-                return self.batch_paths(batch_size, auto_repeat)
-            paths = self.samplebuffer
-        else:
-            paths = self.samplebuffer[0:batch_size]
-            self.samplebuffer = self.samplebuffer[batch_size:]
-        return paths
+    # ---- the deck -----------------------------------------------------------------------------------------
+    @property
+    def samplebuffer(self):
+        return [self.scratch_files[i] for i in self._deck.cards]
 
-    def batch(self, batch_size, auto_repeat=True, verbose=False):
-        paths = self.batch_paths(batch_size, auto_repeat)
-        if verbose:
-            print("Got batch:")
-            for element in paths:
-                print(element)
-        return self._load_batch_from_filelist(paths)
-
-    def batch_mpi_paths(self, batch_size, auto_repeat=True):
-        world = self.world_size
-        global_batch_size = batch_size * world
-        if global_batch_size > len(self.samplebuffer):
-            if auto_repeat:
-                self.repeat()
-                return self.batch_mpi_paths(batch_size, auto_repeat)
-            paths = list(self.samplebuffer)
-            while len(paths) % world > 0:
-                paths.append(None)
-        else:
-            paths = self.samplebuffer[0:global_batch_size]
-            self.samplebuffer = self.samplebuffer[global_batch_size:]
-        mine = [paths[i] for i in range(self.rank, len(paths), world)]   # column `rank` of reshape(-1, world)
-        while len(mine) > 0 and mine[-1] is None:
-            mine.pop()
-        return mine
-
-    def batch_mpi(self, batch_size, auto_repeat=True, verbose=False):
-        mine = self.batch_mpi_paths(batch_size, auto_repeat)
-        if verbose:
-            print(f"Worker: {self.rank}. Got batch: {mine}")
-        return self._load_batch_from_filelist(mine)
+    @samplebuffer.setter
+    def samplebuffer(self, paths):
+        pos = {p: i for i, p in enumerate(self.scratch_files)}
+        self._deck.cards = [pos[p] for p in paths]
 
     def repeat(self):
-        new_samplebuffer = self.scratch_files[:]
-        self._rng.shuffle(new_samplebuffer)
-        self.samplebuffer.extend(new_samplebuffer)
+        self._deck.refill()
 
     def print_samplebuffer(self):
         for path in self.samplebuffer:
             print(path)
 
+    def batch_paths(self, batch_size, auto_repeat=True):
+        return [self.scratch_files[i] for i in self._deck.draw(batch_size, auto_repeat)]
+
+    def batch_mpi_paths(self, batch_size, auto_repeat=True):
+        """This rank's share of the next global batch: entries rank, rank + world, ... of the drawn positions (column
+        `rank` of the reference's reshape(-1, world) before its scatter; a short last draw gives the low ranks one
+        more sample, which is what padding with None and stripping it per rank did, dataset.py:316-338)."""
+        drawn = self._deck.draw(batch_size * self.world_size, auto_repeat)
+        return [self.scratch_files[i] for i in drawn[self.rank::self.world_size]]
+
+    # ---- materialising ------------------------------------------------------------------------------------
+    def load_into(self, paths, out):
+        """np.load every path into out[i, 0] (float32, channel axis added); `out` may be pinned memory."""
+        for i, p in enumerate(paths):
+            np.copyto(out[i, 0], np.load(p), casting='unsafe')
+        return out
+
+    def _load_batch_from_filelist(self, batch_paths):
+        """[N, 1, Z, Y, X] float32; an empty list stays an empty list (dataset.py:254-262)."""
+        if len(batch_paths) == 0:
+            return []
+        first = np.load(batch_paths[0])
+        out = np.empty((len(batch_paths), 1) + first.shape, dtype=np.float32)
+        out[0, 0] = first
+        self.load_into(batch_paths[1:], out[1:])
+        return out
+
+    def batch(self, batch_size, auto_repeat=True, verbose=False):
+        paths = self.batch_paths(batch_size, auto_repeat)
+        if verbose:
+            print("Got batch:")
+            for p in paths:
+                print(p)
+        return self._load_batch_from_filelist(paths)
+
+    def batch_mpi(self, batch_size, auto_repeat=True, verbose=False):
+        paths = self.batch_mpi_paths(batch_size, auto_repeat)
+        if verbose:
+            print(f"Worker: {self.rank}. Got batch: {paths}")
+        return self._load_batch_from_filelist(paths)
+
+
+class _Slot:
+    __slots__ = ('host', 'dev', 'ready', 'released')
+
 
 class PinnedPrefetcher:
-    """Background np.load -> normalise -> pinned buffer -> async H2D copy on a side stream, `depth` batches
-    ahead.  next() returns a device tensor whose copy the current stream has been made to wait for."""
+    """Keeps `depth` batches in flight: np.load -> pinned buffer (normalised in place) -> async copy on a side stream.
+
+    next() makes the caller's current stream wait for the copy and returns the slot's device tensor.  The tensor stays
+    valid until the call AFTER the next one: calling next() again records, on the caller's stream, the event that
+    releases the previous slot, and the worker does not touch a slot before that event has completed."""
 
     def __init__(self, dataset, batch_size, distributed, mean=None, stddev=None, device='cuda', depth=2):
         import torch
         self.torch = torch
-        self.ds, self.bs, self.dist = dataset, batch_size, distributed
-        self.mean, self.std = mean, stddev
+        self.ds, self.bs, self.dist = dataset, int(batch_size), bool(distributed)
+        self.normalise = _norm_args(mean, stddev, 'normalizing') if (mean is not None or stddev is not None) else False
+        self.mean, self.std = (np.float32(mean), np.float32(stddev)) if self.normalise else (None, None)
         self.device = torch.device(device)
-        self.q = queue.Queue(maxsize=depth)
-        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == 'cuda' else None
-        self._stop = False
-        self.th = threading.Thread(target=self._work, daemon=True)
+        self.cuda = self.device.type == 'cuda'
+        self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self.nslots = depth + 2                       # `depth` queued + one at the consumer + one being filled
+        self.slots = []
+        self.free = queue.Queue()
+        self.full = queue.Queue(maxsize=depth)
+        self.held = None                              # slot index the consumer is reading
+        self.error = None
+        self._stop = threading.Event()
+        for i in range(self.nslots):
+            self.slots.append(None)
+            self.free.put(i)
+        self.th = threading.Thread(target=self._work, name='saragan-prefetch', daemon=True)
         self.th.start()
+
+    def _make_slot(self, shape):
+        torch = self.torch
+        s = _Slot()
+        s.host = torch.empty(shape, dtype=torch.float32, pin_memory=self.cuda)
+        s.dev = torch.empty(shape, dtype=torch.float32, device=self.device) if self.cuda else s.host
+        s.ready = torch.cuda.Event() if self.cuda else None
+        s.released = None
+        return s
 
     def _work(self):
         torch = self.torch
-        while not self._stop:
-            paths = self.ds.batch_mpi_paths(self.bs) if self.dist else self.ds.batch_paths(self.bs)
-            arr = self.ds._load_batch_from_filelist(paths)
-            if self.mean is not None and self.std is not None:
-                arr = (arr - np.float32(self.mean)) / np.float32(self.std)
-            host = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32))
-            if self.stream is not None:
-                host = host.pin_memory()
-                with torch.cuda.stream(self.stream):
-                    dev = host.to(self.device, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record(self.stream)
-                self.q.put((dev, ev, host))
-            else:
-                self.q.put((host, None, host))
+        try:
+            if self.cuda:
+                torch.cuda.set_device(self.device)
+            while not self._stop.is_set():
+                try:
+                    i = self.free.get(timeout=0.1)
+                except queue.Empty:
+                    continue
+                paths = self.ds.batch_mpi_paths(self.bs) if self.dist else self.ds.batch_paths(self.bs)
+                shape = (len(paths),) + tuple(self.ds.shape)
+                slot = self.slots[i]
+                if slot is None or tuple(slot.host.shape) != shape:
+                    slot = self.slots[i] = self._make_slot(shape)
+                if slot.released is not None:
+                    slot.released.synchronize()       # the consumer's kernels that read this slot are done
+                    slot.released = None
+                host = slot.host.numpy()
+                self.ds.load_into(paths, host)
+                if self.normalise:
+                    np.subtract(host, self.mean, out=host)
+                    np.divide(host, self.std, out=host)
+                if self.cuda:
+                    with torch.cuda.stream(self.stream):
+                        slot.dev.copy_(slot.host, non_blocking=True)
+                        slot.ready.record(self.stream)
+                while not self._stop.is_set():
+                    try:
+                        self.full.put(i, timeout=0.1)
+                        break
+                    except queue.Full:
+                        continue
+        except BaseException as e:   # surfaced by next(): a dead loader must not look like a slow one
+            self.error = e
+
+    def _release_held(self):
+        if self.held is None:
+            return
+        slot = self.slots[self.held]
+        if self.cuda:
+            slot.released = self.torch.cuda.Event()
+            slot.released.record(self.torch.cuda.current_stream(self.device))
+        self.free.put(self.held)
+        self.held = None
 
     def next(self):
-        dev, ev, _host = self.q.get()
-        if ev is not None:
-            self.torch.cuda.current_stream().wait_event(ev)
-        return dev
+        self._release_held()
+        while True:
+            if self.error is not None:
+                raise RuntimeError('prefetch worker failed') from self.error
+            try:
+                i = self.full.get(timeout=0.5)
+                break
+            except queue.Empty:
+                if not self.th.is_alive() and self.error is None:
+                    raise RuntimeError('prefetch worker exited')
+        slot = self.slots[i]
+        if self.cuda:
+            self.torch.cuda.current_stream(self.device).wait_event(slot.ready)
+        self.held = i
+        return slot.dev
 
     def close(self):
-        self._stop = True
-        try:
-            while True:
-                self.q.get_nowait()
-        except queue.Empty:
-            pass
+        self._stop.set()
+        self.th.join(timeout=10.0)
+        if self.cuda:
+            self.torch.cuda.current_stream(self.device).synchronize()
+        self.slots = []

@@ -764,6 +764,16 @@ def adam_ema_(p, g, m, v, ema, lr, beta1, beta2, step, eps=1e-8, gscale=1.0, ema
                           float(beta2), float(eps), float(gscale), float(ema_decay), _stream()), 'sg_adam_ema')
 
 
+def optim_step_(kind, p, g, s1, s2, ema, lr, h=0.0, eps=0.0, nesterov=False, gscale=1.0, ema_decay=0.99):
+    """In-place fused SGD / Momentum / Adadelta (+ EMA) over flat f32 buffers (sg_optim_step)."""
+    lib = _lib.load()
+    _req_cuda(p, g, s1, s2, ema)
+    clear_pack_cache()      # the kernel rewrites parameters behind torch's version counters
+    check(lib.sg_optim_step(int(kind), _ptr(p), _ptr(g), _ptr(s1), _ptr(s2), _ptr(ema), p.numel(), float(lr), float(h),
+                            float(eps), 1 if nesterov else 0, float(gscale), float(ema_decay), _stream()),
+          'sg_optim_step')
+
+
 def segment_sumsq(flat, offsets_dev, nseg):
     lib = _lib.load()
     out = torch.empty(nseg, device=flat.device, dtype=torch.float32)

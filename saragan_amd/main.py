@@ -73,6 +73,12 @@ def build_parser():
     p.add_argument('--adam_beta2', type=none_or_float, default=0.9)
     p.add_argument('--d_use_different_beta2', default=False, action='store_true')
     p.add_argument('--d_adam_beta2', type=none_or_float, default=0.9)
+    p.add_argument('--rho', type=none_or_float, default=0.95)
+    p.add_argument('--d_use_different_rho', default=False, action='store_true')
+    p.add_argument('--d_rho', type=none_or_float, default=0.95)
+    p.add_argument('--momentum', type=none_or_float, default=0.9)
+    p.add_argument('--d_use_different_momentum', default=False, action='store_true')
+    p.add_argument('--d_momentum', type=none_or_float, default=0.9)
     p.add_argument('--data_mean', default=None, type=float)
     p.add_argument('--data_stddev', default=None, type=float)
     p.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'], help='activation / MFMA input type (new flag)')
@@ -89,6 +95,15 @@ def finalize_args(args):
         args.d_adam_beta1 = args.adam_beta1
     if not args.d_use_different_beta2:
         args.d_adam_beta2 = args.adam_beta2
+    if not args.d_use_different_rho:
+        args.d_rho = args.rho
+    if not args.d_use_different_momentum:
+        args.d_momentum = args.momentum
+    for n in ('g', 'd'):       # main.py:384-399: ramp lengths default to half the mixing / stabilising images
+        if getattr(args, f'{n}_lr_increase') and not getattr(args, f'{n}_lr_rise_niter'):
+            setattr(args, f'{n}_lr_rise_niter', int(args.mixing_nimg / 2))
+        if getattr(args, f'{n}_lr_decrease') and not getattr(args, f'{n}_lr_decay_niter'):
+            setattr(args, f'{n}_lr_decay_niter', int(args.stabilizing_nimg / 2))
     if args.kernel_spec is None or args.filter_spec is None:
         if args.network_size is None:
             raise SystemExit('give --kernel_spec and --filter_spec, or --network_size for the legacy presets')

@@ -57,33 +57,72 @@ class AdamOptimizer(_Optimizer):
                         self.epsilon, gscale, ema_decay)
 
 
-class GradientDescentOptimizer(_Optimizer):
-    """tf.train.GradientDescentOptimizer: p -= lr * g (sg_axpby on the flat f32 range)."""
+class _FusedRule(_Optimizer):
+    """Optimisers on sg_optim_step: one launch per contiguous range updates parameters, state and the EMA shadow."""
+    KIND, SLOTS = None, ()
+
+    def _hyper(self):
+        return dict(h=0.0, eps=0.0, nesterov=False)
 
     def apply(self, prefix, flat, ranges, gscale, ema_flat, ema_decay):
+        st = self._slots(prefix, flat, self.SLOTS)
         self.t += 1
         lr = self.lr_value()
         for (o, n) in ranges:
-            p, g = flat['param'][o:o + n], flat['grad'][o:o + n]
-            F._lib.check(F._lib.load().sg_axpby(F._ptr(p), F._ptr(g), F._ptr(p), 1.0, -lr * gscale, n, F._lib.SG_F32,
-                                                F._stream()), 'sg_axpby')
-            if ema_flat is not None:
-                F.adam_ema_(p, None, None, None, ema_flat[o:o + n], 0.0, 0.0, 0.0, 1, ema_decay=ema_decay)
+            s1 = st[self.SLOTS[0]][o:o + n] if len(self.SLOTS) > 0 else None
+            s2 = st[self.SLOTS[1]][o:o + n] if len(self.SLOTS) > 1 else None
+            F.optim_step_(self.KIND, flat['param'][o:o + n], flat['grad'][o:o + n], s1, s2,
+                          None if ema_flat is None else ema_flat[o:o + n], lr, gscale=gscale, ema_decay=ema_decay,
+                          **self._hyper())
+
+
+class GradientDescentOptimizer(_FusedRule):
+    """tf.train.GradientDescentOptimizer(learning_rate): p -= lr * g (optimization.py:17-18,29-30)."""
+    KIND = F._lib.SG_OPT_SGD
+
+
+class MomentumOptimizer(_FusedRule):
+    """tf.train.MomentumOptimizer(learning_rate, momentum, use_nesterov): accum = momentum * accum + g;
+    p -= lr * g + lr * momentum * accum (Nesterov, what optimization.py:21-22,34-35 asks for) or lr * accum."""
+    KIND, SLOTS = F._lib.SG_OPT_MOMENTUM, ('accum',)
+
+    def __init__(self, learning_rate, momentum, use_nesterov=False):
+        super().__init__(learning_rate)
+        self.momentum, self.use_nesterov = float(momentum), bool(use_nesterov)
+
+    def _hyper(self):
+        return dict(h=self.momentum, eps=0.0, nesterov=self.use_nesterov)
+
+
+class AdadeltaOptimizer(_FusedRule):
+    """tf.train.AdadeltaOptimizer(learning_rate, rho, epsilon) (optimization.py:19-20,31-32: epsilon 1e-07)."""
+    KIND, SLOTS = F._lib.SG_OPT_ADADELTA, ('accum', 'accum_update')
+
+    def __init__(self, learning_rate, rho=0.95, epsilon=1e-8):
+        super().__init__(learning_rate)
+        self.rho, self.epsilon = float(rho), float(epsilon)
+
+    def _hyper(self):
+        return dict(h=self.rho, eps=self.epsilon, nesterov=False)
 
 
 def get_optimizer(d_lr, g_lr, args):
-    """optimization.py:6-45.  Adam and SGD are implemented on the HIP path; Momentum/Adadelta raise."""
-    def make(kind, lr, b1, b2):
+    """optimization.py:6-45: Adam / SGD / Adadelta / Momentum (Nesterov), one per network."""
+    def make(kind, lr, b1, b2, rho, momentum):
         if kind == 'Adam':
             return AdamOptimizer(learning_rate=lr, beta1=b1, beta2=b2)
         elif kind == 'SGD':
             return GradientDescentOptimizer(learning_rate=lr)
-        elif kind in ('Adadelta', 'Momentum'):
-            raise NotImplementedError(f'optimizer {kind} has no HIP kernel yet (Adam is the reference default)')
+        elif kind == 'Adadelta':
+            return AdadeltaOptimizer(learning_rate=lr, rho=rho, epsilon=1e-07)
+        elif kind == 'Momentum':
+            return MomentumOptimizer(learning_rate=lr, momentum=momentum, use_nesterov=True)
         print(f"ERROR: optimizer argument {kind} not recognized or implemented")
         raise NotImplementedError
-    optimizer_gen = make(args.optimizer, g_lr, args.adam_beta1, args.adam_beta2)
-    optimizer_disc = make(args.d_optimizer, d_lr, args.d_adam_beta1, args.d_adam_beta2)
+    rho, mom = getattr(args, 'rho', 0.95), getattr(args, 'momentum', 0.9)
+    optimizer_gen = make(args.optimizer, g_lr, args.adam_beta1, args.adam_beta2, rho, mom)
+    optimizer_disc = make(args.d_optimizer, d_lr, args.d_adam_beta1, args.d_adam_beta2, getattr(args, 'd_rho', rho),
+                          getattr(args, 'd_momentum', mom))
     return optimizer_gen, optimizer_disc
 
 

@@ -22,14 +22,15 @@ from .utils import (get_base_shape, get_current_input_shape, get_num_phases, get
 from .varstore import VariableStore, set_compute_dtype, use_store
 
 
-def get_numpy_dataset(phase, starting_phase, start_shape, dataset_path, scratch_path, verbose, rank, world, seed):
-    """utils.py:195-204."""
+def get_numpy_dataset(phase, starting_phase, start_shape, dataset_path, scratch_path, verbose, rank, world, seed,
+                      local_rank=0):
+    """utils.py:195-204.  One process per NODE stages the files to scratch (hvd.local_rank() == 0 in the reference)."""
     size = get_xy_dim(phase, start_shape)
     data_path = os.path.join(dataset_path, f'{size}x{size}/')
     if verbose:
         print(f'Phase {phase}: reading data from dir {data_path}')
-    return NumpyPathDataset(data_path, scratch_path, copy_files=(rank == 0), is_correct_phase=phase >= starting_phase,
-                            rank=rank, world_size=world, seed=seed)
+    return NumpyPathDataset(data_path, scratch_path, copy_files=(local_rank == 0),
+                            is_correct_phase=phase >= starting_phase, rank=rank, world_size=world, seed=seed)
 
 
 def run_training(args, device=None, max_steps_per_phase=None, log_every=1):
@@ -64,7 +65,8 @@ def run_training(args, device=None, max_steps_per_phase=None, log_every=1):
         np.random.seed(seed); random.seed(seed); torch.manual_seed(seed)   # :102-109
         L.set_random_source(L.RandomSource(seed * 1000 + phase, device))
         npy_data = get_numpy_dataset(phase, args.starting_phase, args.start_shape, args.dataset_path,
-                                     args.scratch_path, verbose, rank, global_size, seed=args.seed)
+                                     args.scratch_path, verbose, rank if horovod else 0, global_size, seed=args.seed,
+                                     local_rank=local)
         batch_size = max(1, args.base_batch_size // (2 ** (phase - 1)))            # :127
         if args.max_global_batch_size is not None:                                # :130-136 (quirk Q6: float)
             max_local_batch_size = args.max_global_batch_size / global_size

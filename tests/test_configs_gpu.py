@@ -1,0 +1,337 @@
+"""BASELINE.json configurations at their own sizes, HIP path vs the CPU oracle.
+
+* config 1  (pgan 'xs' phase 1, 4x4x1, latent 256, batch 4, fp32): two whole steps replayed by the oracle IN the test:
+  losses, sample, every gradient, post-Adam weights, EMA.  Tolerances of SURVEY section 8c (fp32 path).
+* config 2  (pgan 'xs' phase 4, 32x32x8, latent 256): one whole step at batch 4 in fp32 against the oracle, and the
+  same step in bf16 (the bench dtype) with every gradient checked in relative L2.
+* configs 3 / 4 (pgan 's' 128x128x32, 'm' 256x256x64 with fade-in): the top-level layers at their EXACT shapes,
+  n = 1-2, both dtypes: forward, data gradient and weight gradient.  A full-tensor CPU convolution at 64x256x256 is
+  ~0.5 TFLOP, so the oracle is evaluated on boxes (corners, faces, interior, tile seams) of the output -- a
+  convolution is local, so a box of the output depends on the box + halo of the input only -- and the weight
+  gradient through its linearity: with dy zero outside a box, dw equals the oracle's dw of that box.  Plus the
+  fade-in lerps and the whole config-3 / config-4 step through size-independent properties (finite values, bf16
+  gradient norms against an fp32 HIP run of the same step).
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from oracle import pgan_oracle as O
+from tests.cfgutil import assert_adam_close, build_product, make_case, pick, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _np(t):
+    return t.detach().double().cpu().numpy()
+
+
+def _check_step_vs_oracle(case, dtype, steps, tol_loss, tol_act, tol_grad, tol_w, strategy='simultaneous'):
+    store, tup, ph, ema, sess, _ = build_product(case, dtype, strategy)
+    mixing = case['freeze'] is not None
+    tg, td, gg_h, gv, dg_h, dv, _, _ = pick(tup, mixing)
+    p = {k: v.clone() for k, v in case['p0'].items()}
+    shadow = {k: v.clone() for k, v in p.items()}
+    ag, ad = O.TFAdam(0.0, 0.9), O.TFAdam(0.0, 0.9)
+    feed = {ph: case['real'].float()}
+    ema_op = ema.apply()
+    for s in range(steps):
+        ref = O.step_simultaneous(p, ag, ad, shadow, case['rnd'], case['real'], case['alpha'], case['cfg'], 1e-3, 1e-3,
+                                  freeze=case['freeze'])
+        _, _, gl, dl, gs, gg, dg = sess.run([tg, td, tup[2], tup[3], tup[5], gg_h, dg_h], feed_dict=feed)
+        sess.run(ema_op)
+        np.testing.assert_allclose(float(gl), float(ref['gen_loss']), rtol=tol_loss[0], atol=tol_loss[1], err_msg=f'gen_loss step {s}')
+        np.testing.assert_allclose(float(dl), float(ref['disc_loss']), rtol=tol_loss[0], atol=tol_loss[1], err_msg=f'disc_loss step {s}')
+        r = _np(ref['gen_sample'])
+        np.testing.assert_allclose(_np(gs), r, rtol=tol_act[0], atol=tol_act[1] * max(1.0, np.abs(r).max()))
+        for hv, grads, refs in ((gv, gg, ref['g_grads']), (dv, dg, ref['d_grads'])):
+            assert [v.key for v in hv] == list(refs.keys())
+            for v, g in zip(hv, grads):
+                assert rel_l2(g, refs[v.key]) <= tol_grad, (v.key, rel_l2(g, refs[v.key]))
+        for k, v in store.vars.items():
+            assert_adam_close(v, p[k], 1e-3, tol_w, k)
+            assert_adam_close(ema.average(k), shadow[k], 1e-3 * 0.01, tol_w, 'ema:' + k)
+    return store
+
+
+def test_config1_xs_phase1_full_size_fp32():
+    """configs[0]: 'xs' phase 1, 4x4x1, batch 4, latent 256, fp32; G/D = dense 256 -> 4096, conv 256 -> 256 at (1,4,4)."""
+    case = make_case('xs', 1, 256, 4, alpha=0.0, loss_fn='wgan', seed=11)
+    assert case['p0']['generator/generator_in/dense/weight'].shape == (256, 4096)
+    assert case['p0']['discriminator/discriminator_out/weight'].shape == (1, 3, 3, 256, 256)
+    _check_step_vs_oracle(case, torch.float32, 2, (1e-4, 1e-5), (1e-4, 1e-5), 1e-3, 1e-4)
+    case = make_case('xs', 1, 256, 4, alpha=0.0, loss_fn='logistic', gp_weight=1.0, seed=12)   # the CLI default loss
+    _check_step_vs_oracle(case, torch.float32, 1, (1e-4, 1e-5), (1e-4, 1e-5), 1e-3, 1e-4)
+
+
+def test_config2_xs_phase4_step_fp32_and_bf16():
+    """configs[1]: 'xs' phase 4 -> [N,1,8,32,32], latent 256.  Batch 4 keeps the fp64 oracle replay to seconds."""
+    case = make_case('xs', 4, 256, 4, alpha=0.0, loss_fn='wgan', seed=21)
+    assert case['real'].shape == (4, 1, 8, 32, 32)
+    _check_step_vs_oracle(case, torch.float32, 1, (1e-4, 1e-5), (1e-4, 1e-5), 1e-3, 1e-4)
+    # bf16 storage / MFMA (the precision BASELINE assigns to this config) against the same fp64 replay
+    ref = O.step_simultaneous({k: v.clone() for k, v in case['p0'].items()}, O.TFAdam(0.0, 0.9), O.TFAdam(0.0, 0.9), None,
+                              case['rnd'], case['real'], 0.0, case['cfg'], 1e-3, 1e-3)
+    store, tup, ph, ema, sess, _ = build_product(case, torch.bfloat16)
+    _, _, gl, dl, gs, gg, dg = sess.run([tup[0], tup[1], tup[2], tup[3], tup[5], tup[6], tup[8]], feed_dict={ph: case['real'].float()})
+    np.testing.assert_allclose(float(gl), float(ref['gen_loss']), rtol=2e-2, atol=2e-2)
+    np.testing.assert_allclose(float(dl), float(ref['disc_loss']), rtol=2e-2, atol=2e-2 * max(1.0, abs(float(ref['disc_loss']))))
+    assert rel_l2(gs, ref['gen_sample']) <= 2e-2
+    worst = {}
+    for hv, grads, refs in ((tup[7], gg, ref['g_grads']), (tup[9], dg, ref['d_grads'])):
+        for v, g in zip(hv, grads):
+            worst[v.key] = rel_l2(g, refs[v.key])
+    bad = {k: e for k, e in worst.items() if e > 6e-2}
+    assert not bad, bad
+    from saragan_amd.varstore import set_compute_dtype
+    set_compute_dtype(torch.float32)
+
+
+# ---------------------------------------------------------------------------------------------------
+# configs 3 and 4: exact top-level layer shapes
+# ---------------------------------------------------------------------------------------------------
+def _boxes(sp, k):
+    """Output boxes (lo, hi) covering the corners, a face, the interior and tile seams of a D x H x W volume."""
+    d, h, w = sp
+    bd, bh, bw = min(d, 6), min(h, 10), min(w, 40)
+    pts = [(0, 0, 0), (d - bd, h - bh, w - bw), (0, h - bh, 0), (d - bd, 0, w - bw),
+           (max(0, d // 2 - 3), max(0, h // 2 - 5), max(0, w // 2 - 20)),      # interior, across the 32-wide tile seam
+           (max(0, d // 2 - 3), 2, max(0, w - bw - 13))]
+    return [((a, b, c), (a + bd, b + bh, c + bw)) for a, b, c in pts]
+
+
+def _oracle_box(x, wt, lo, hi, k):
+    """conv3d (cross-correlation, SAME) of x [n,cin,D,H,W] (CPU f64) restricted to the output box [lo, hi)."""
+    pd, ph_, pw = k[0] // 2, k[1] // 2, k[2] // 2
+    _, _, D, H, W = x.shape
+    a0, b0, c0 = max(lo[0] - pd, 0), max(lo[1] - ph_, 0), max(lo[2] - pw, 0)
+    a1, b1, c1 = min(hi[0] + pd, D), min(hi[1] + ph_, H), min(hi[2] + pw, W)
+    crop = x[:, :, a0:a1, b0:b1, c0:c1]
+    pad = (pw - (lo[2] - c0), pw - (c1 - hi[2]), ph_ - (lo[1] - b0), ph_ - (b1 - hi[1]), pd - (lo[0] - a0), pd - (a1 - hi[0]))
+    return TF.conv3d(TF.pad(crop, pad), wt)
+
+
+LAYERS = [
+    # tag, n, cin, cout, (d,h,w), upsample_in
+    ('cfg3 D conv_1 32->32 @32x128x128', 2, 32, 32, (32, 128, 128), False),
+    ('cfg3 D conv_2 32->64 @32x128x128', 2, 32, 64, (32, 128, 128), False),
+    ('cfg3 G conv_1 64->32 ups @32x128x128', 2, 64, 32, (32, 128, 128), True),
+    ('cfg3 dgrad of 32->64 = 64->32 @32x128x128', 2, 64, 32, (32, 128, 128), False),
+    ('cfg3 D conv 64->128 @16x64x64', 2, 64, 128, (16, 64, 64), False),
+    ('cfg3 G conv 128->64 ups @16x64x64', 2, 128, 64, (16, 64, 64), True),
+    ('cfg4 D conv_1 32->32 @64x256x256', 1, 32, 32, (64, 256, 256), False),
+    ('cfg4 D conv_2 32->64 @64x256x256', 1, 32, 64, (64, 256, 256), False),
+    ('cfg4 G conv_1 64->32 ups @64x256x256', 1, 64, 32, (64, 256, 256), True),
+]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('layer', LAYERS, ids=[l[0] for l in LAYERS])
+def test_top_level_layers_exact_shapes(layer, dtype):
+    """conv3d + bias + LeakyReLU (+ fused nearest x2) forward, data gradient and weight gradient at the exact
+    configs[2] / configs[3] layer shapes, against the oracle on boxes of the volume."""
+    from saragan_amd import functional as F
+    tag, n, cin, cout, sp, ups = layer
+    k = (3, 3, 3)
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(zlib.crc32(tag.encode()) % 1000)
+    in_sp = tuple(s // 2 for s in sp) if ups else sp
+    x = torch.randn((n, cin, *in_sp), generator=g).to(dtype)
+    w = torch.randn((*k, cin, cout), generator=g)
+    b = torch.randn(cout, generator=g) * 0.1
+    coef = O.runtime_coef(w.shape, 'leaky_relu', 0.2)
+    wq = (w * coef).to(dtype).double()                      # the kernel rounds coef*w to the compute dtype
+    wt = wq.permute(4, 3, 0, 1, 2).contiguous()
+    xd = x.to(dev).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+    wd = w.to(dev).requires_grad_(True)
+    bd = b.to(dev).requires_grad_(True)
+    y = F.conv3d(xd, wd, coef, bias=bd, act=True, slope=0.2, upsample_in=ups)
+    assert tuple(y.shape) == (n, cout, *sp)
+    rt, at = (1e-4, 1e-5) if dtype == torch.float32 else (1e-2, 1e-2)
+    x64 = x.double()
+    xfull = O.upscale3d(x64) if ups else x64
+    yc = y.detach().double().cpu()
+    assert torch.isfinite(yc).all()
+    scale = float(yc.abs().max())
+    for lo, hi in _boxes(sp, k):
+        ref = _oracle_box(xfull, wt, lo, hi, k) + b.double().reshape(1, -1, 1, 1, 1)
+        ref = torch.maximum(ref, ref * 0.2)
+        got = yc[:, :, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=rt, atol=at * scale, err_msg=f'{tag} fwd box {lo}')
+    # backward with an upstream gradient that is non-zero in ONE box: dx is local, dw / db are that box's
+    lo, hi = _boxes(sp, k)[4]
+    gy = torch.zeros((n, cout, *sp), dtype=dtype)
+    gbox = torch.randn((n, cout, hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]), generator=g).to(dtype)
+    gy[:, :, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = gbox
+    gx, gw, gb = torch.autograd.grad(y, [xd, wd, bd], gy.to(dev).contiguous(memory_format=torch.channels_last_3d))
+    # oracle on the box + halo only
+    a0, b0, c0 = max(lo[0] - 1, 0), max(lo[1] - 1, 0), max(lo[2] - 1, 0)
+    a1, b1, c1 = min(hi[0] + 1, sp[0]), min(hi[1] + 1, sp[1]), min(hi[2] + 1, sp[2])
+    if ups:   # crop in low-resolution coordinates, aligned to even high-resolution coordinates
+        a0, b0, c0 = a0 // 2 * 2, b0 // 2 * 2, c0 // 2 * 2
+        a1, b1, c1 = -(-a1 // 2) * 2, -(-b1 // 2) * 2, -(-c1 // 2) * 2
+        xs = x64[:, :, a0 // 2:a1 // 2, b0 // 2:b1 // 2, c0 // 2:c1 // 2].clone().requires_grad_(True)
+        xin = O.upscale3d(xs)
+    else:
+        xs = x64[:, :, a0:a1, b0:b1, c0:c1].clone().requires_grad_(True)
+        xin = xs
+    wr = wq.clone().requires_grad_(True)
+    br = b.double().clone().requires_grad_(True)
+    # pad so that the crop's conv output is aligned with [a0,a1) etc. and volume borders stay zero-padded
+    yr = TF.conv3d(TF.pad(xin, (1, 1, 1, 1, 1, 1)), wr.permute(4, 3, 0, 1, 2)) + br.reshape(1, -1, 1, 1, 1)
+    yr = O.leaky_relu(yr, 0.2)
+    yr_box = yr[:, :, lo[0] - a0:hi[0] - a0, lo[1] - b0:hi[1] - b0, lo[2] - c0:hi[2] - c0]
+    interior = (lo[0] - a0 >= 1 or a0 == 0) and (lo[1] - b0 >= 1 or b0 == 0) and (lo[2] - c0 >= 1 or c0 == 0)
+    assert interior
+    gxr, gwr, gbr = torch.autograd.grad(yr_box, [xs, wr, br], gbox.double())
+    gxc = gx.detach().double().cpu()
+    if ups:
+        got_x = gxc[:, :, a0 // 2:a1 // 2, b0 // 2:b1 // 2, c0 // 2:c1 // 2]
+    else:
+        got_x = gxc[:, :, a0:a1, b0:b1, c0:c1]
+    sx = float(gxr.abs().max())
+    np.testing.assert_allclose(got_x.numpy(), gxr.numpy(), rtol=rt, atol=at * sx, err_msg=f'{tag} dgrad')
+    outside = gxc.clone()
+    if ups:
+        outside[:, :, a0 // 2:a1 // 2, b0 // 2:b1 // 2, c0 // 2:c1 // 2] = 0
+    else:
+        outside[:, :, a0:a1, b0:b1, c0:c1] = 0
+    assert float(outside.abs().max()) == 0.0, f'{tag}: data gradient leaked outside the box + halo'
+    refw = (gwr * coef).numpy()
+    rtw, atw = (1e-4, 1e-5) if dtype == torch.float32 else (2e-3, 2e-3)
+    np.testing.assert_allclose(_np(gw), refw, rtol=rtw, atol=atw * np.abs(refw).max(), err_msg=f'{tag} wgrad')
+    np.testing.assert_allclose(_np(gb), gbr.numpy(), rtol=rtw, atol=atw * float(gbr.abs().max()), err_msg=f'{tag} bias grad')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_wgrad_dense_full_volume_config3(dtype):
+    """Weight gradient with a DENSE upstream gradient over the whole 32x128x128 volume (every tile contributes):
+    32 -> 32, n = 1, against torch's CPU convolution backward in fp32 inputs / fp64 accumulation of the oracle."""
+    from saragan_amd import functional as F
+    g = torch.Generator().manual_seed(5)
+    sp, cin, cout = (32, 128, 128), 32, 32
+    x = torch.randn((1, cin, *sp), generator=g).to(dtype)
+    gy = torch.randn((1, cout, *sp), generator=g).to(dtype)
+    dev = torch.device('cuda:0')
+    dw, db = F.raw_wgrad(x.to(dev), gy.to(dev), (3, 3, 3), 1.0, want_db=True)
+    xr = x.double()
+    wr = torch.zeros((cout, cin, 3, 3, 3), dtype=torch.float64, requires_grad=True)
+    yr = TF.conv3d(xr, wr, padding=1)
+    (gw,) = torch.autograd.grad(yr, wr, gy.double())
+    ref = gw.permute(2, 3, 4, 1, 0).numpy()
+    rt, at = (1e-4, 1e-5) if dtype == torch.float32 else (2e-3, 2e-3)
+    np.testing.assert_allclose(_np(dw), ref, rtol=rt, atol=at * np.abs(ref).max())
+    np.testing.assert_allclose(_np(db), gy.double().sum(dim=(0, 2, 3, 4)).numpy(), rtol=rt, atol=at * 1e3)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_fade_in_lerps_config4_sizes(dtype):
+    """Phase-7 fade-in at 256x256x64, alpha in (0,1): generator image lerp (pgan/generator.py:100-101) on
+    [2,1,64,256,256] and discriminator feature lerp (pgan/discriminator.py:105) on [2,64,32,128,128]; up/down-scale of
+    the image branch (to_rgb_6 upscaled, image downscaled for from_rgb_6)."""
+    from saragan_amd import functional as F
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(9)
+    alpha = 0.3
+    rt, at = (1e-5, 1e-6) if dtype == torch.float32 else (1e-2, 1e-2)
+    for shape in ((2, 1, 64, 256, 256), (2, 64, 32, 128, 128)):
+        a = torch.randn(shape, generator=g).to(dtype)
+        b = torch.randn(shape, generator=g).to(dtype)
+        ad = a.to(dev).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+        bd = b.to(dev).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+        out = F.lerp(ad, bd, alpha, 1 - alpha)
+        ref = alpha * a.double() + (1 - alpha) * b.double()
+        np.testing.assert_allclose(_np(out), ref.numpy(), rtol=rt, atol=at)
+        ga, gb = torch.autograd.grad(out, [ad, bd], torch.ones_like(out))
+        assert abs(float(ga.float().mean()) - alpha) < 1e-2 and abs(float(gb.float().mean()) - (1 - alpha)) < 1e-2
+    img = torch.randn((2, 1, 64, 256, 256), generator=g).to(dtype)
+    imgd = img.to(dev).contiguous(memory_format=torch.channels_last_3d)
+    np.testing.assert_allclose(_np(F.downscale2x(imgd)), O.downscale3d(img.double()).numpy(), rtol=rt, atol=at)
+    low = torch.randn((2, 1, 32, 128, 128), generator=g).to(dtype)
+    lowd = low.to(dev).contiguous(memory_format=torch.channels_last_3d)
+    np.testing.assert_array_equal(_np(F.upscale2x(lowd)), O.upscale3d(low.double()).numpy())
+
+
+def _grad_norms(case, dtype, batch_keys=None):
+    store, tup, ph, ema, sess, _ = build_product(case, dtype)
+    mixing = case['freeze'] is not None
+    tg, td, gg_h, gv, dg_h, dv, _, _ = pick(tup, mixing)
+    _, _, gl, dl, gs, gg, dg = sess.run([tg, td, tup[2], tup[3], tup[5], gg_h, dg_h], feed_dict={ph: case['real'].float()})
+    sess.run(ema.apply())
+    torch.cuda.synchronize()
+    norms = {}
+    for hv, grads in ((gv, gg), (dv, dg)):
+        for v, g in zip(hv, grads):
+            assert torch.isfinite(g).all(), v.key
+            norms[v.key] = float(torch.linalg.vector_norm(g.float()))
+    for k, v in store.vars.items():
+        assert torch.isfinite(v).all(), k
+    assert np.isfinite(float(gl)) and np.isfinite(float(dl)) and torch.isfinite(gs.float()).all()
+    out = dict(gen_loss=float(gl), disc_loss=float(dl), norms=norms, sample=gs.float().cpu())
+    del store, tup, sess, ema
+    from saragan_amd import functional as F
+    F.clear_pack_cache()
+    torch.cuda.empty_cache()
+    return out
+
+
+def test_config3_whole_step_properties():
+    """configs[2]: pgan 's' phase 6, [n,1,32,128,128], latent 512.  One whole step in bf16 and in fp32 on the HIP path
+    (batch 4: the fp32 run holds every activation twice as wide): everything finite, losses agree, and every bf16
+    gradient norm is within 10 % of the fp32 run's (Frobenius norms are stable under bf16 rounding noise)."""
+    case = make_case('s', 6, 512, 4, alpha=0.0, loss_fn='wgan', seed=31, dtype=torch.float32)
+    assert case['real'].shape == (4, 1, 32, 128, 128)
+    f32 = _grad_norms(case, torch.float32)
+    b16 = _grad_norms(case, torch.bfloat16)
+    assert abs(b16['gen_loss'] - f32['gen_loss']) <= 3e-2 * max(1.0, abs(f32['gen_loss']))
+    assert abs(b16['disc_loss'] - f32['disc_loss']) <= 3e-2 * max(1.0, abs(f32['disc_loss']))
+    assert rel_l2(b16['sample'], f32['sample']) <= 2e-2
+    bad = {k: (b16['norms'][k], v) for k, v in f32['norms'].items() if abs(b16['norms'][k] - v) > 0.10 * v + 1e-12}
+    assert not bad, bad
+    from saragan_amd.varstore import set_compute_dtype
+    set_compute_dtype(torch.float32)
+
+
+def test_config3_bench_batch_runs_bf16():
+    """The bench workload itself (batch 32 per GPU, bf16): two steps, finite losses and weights."""
+    case = make_case('s', 6, 512, 32, alpha=0.0, loss_fn='wgan', seed=32, dtype=torch.float32)
+    store, tup, ph, ema, sess, _ = build_product(case, torch.bfloat16)
+    for _ in range(2):
+        _, _, gl, dl = sess.run([tup[0], tup[1], tup[2], tup[3]], feed_dict={ph: case['real'].float()})
+        sess.run(ema.apply())
+        assert np.isfinite(float(gl)) and np.isfinite(float(dl))
+    for k, v in store.vars.items():
+        assert torch.isfinite(v).all(), k
+    from saragan_amd.varstore import set_compute_dtype
+    set_compute_dtype(torch.float32)
+
+
+def test_config4_m_phase7_fade_in_step():
+    """configs[3]: pgan 'm' final phase 256x256x64 WITH fade-in (alpha 0.5, freeze train ops, quirk Q4), local batch 2
+    (global 16 on 8 GPUs), bf16: the step fits and runs, everything is finite, previous-phase variables stay put and
+    the new layers move."""
+    case = make_case('m', 7, 512, 2, alpha=0.5, loss_fn='wgan', seed=41, dtype=torch.float32)
+    assert case['real'].shape == (2, 1, 64, 256, 256)
+    nparam = sum(v.numel() for k, v in case['p0'].items() if k.startswith('generator/'))
+    assert nparam > 100e6          # 107.5 M parameters per network
+    store, tup, ph, ema, sess, _ = build_product(case, torch.bfloat16)
+    tg, td, gg_h, gv, dg_h, dv, _, _ = pick(tup, True)
+    before = {k: v.detach().clone() for k, v in store.vars.items()}
+    _, _, gl, dl, gs, gg, dg = sess.run([tg, td, tup[2], tup[3], tup[5], gg_h, dg_h], feed_dict={ph: case['real'].float()})
+    sess.run(ema.apply())
+    assert tuple(gs.shape) == (2, 1, 64, 256, 256) and torch.isfinite(gs.float()).all()
+    assert np.isfinite(float(gl)) and np.isfinite(float(dl))
+    new = {v.key for v in gv} | {v.key for v in dv}
+    assert any('block_7' in k for k in new) and not any('block_6' in k for k in new)
+    for g_ in list(gg) + list(dg):
+        assert torch.isfinite(g_).all() and float(g_.abs().max()) > 0
+    for k, v in store.vars.items():
+        moved = not torch.equal(v.detach(), before[k])
+        assert moved == (k in new), k
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    print(f'config 4 step: peak {peak:.1f} GiB, gen_loss {float(gl):.4f}, disc_loss {float(dl):.4f}')
+    from saragan_amd.varstore import set_compute_dtype
+    set_compute_dtype(torch.float32)

@@ -193,3 +193,63 @@ def test_cli_flags_of_the_reference_parse():
     assert unknown == ['--calc_metrics', '--compute_FID']
     assert args.d_adam_beta1 == pytest.approx(0.130724) and args.d_optimizer == 'Adam'
     assert args.filter_spec[0] == [128, 128] and len(args.kernel_spec) >= 5   # ops.py:223-232: 5*16*16 voxels -> list index 2
+
+
+def test_scratch_staging_waits_for_the_copier(tmp_path):
+    """Only the node's first process copies (through a temporary name + rename); the others wait until the whole table
+    is present (reference dataset.py:163-200: local_rank-0 copy and the busy-wait at :176-177)."""
+    import threading
+    import time
+    from saragan_amd.dataset import NumpyPathDataset
+    src = tmp_path / 'data' / '8x8'
+    src.mkdir(parents=True)
+    for i in range(6):
+        np.save(src / f'{i:03d}.npy', np.full((2, 8, 8), i, dtype=np.int16))
+    scratch = tmp_path / 'scratch'
+    made = {}
+
+    def waiter():
+        made['waiter'] = NumpyPathDataset(str(src) + '/', str(scratch) + '/', False, True, rank=1, world_size=2, seed=5)
+
+    th = threading.Thread(target=waiter)
+    th.start()
+    time.sleep(0.5)
+    assert th.is_alive() and 'waiter' not in made          # nothing staged yet: still waiting
+    copier = NumpyPathDataset(str(src) + '/', str(scratch) + '/', True, True, rank=0, world_size=2, seed=5)
+    th.join(timeout=20)
+    assert not th.is_alive()
+    w = made['waiter']
+    assert w.scratch_files == copier.scratch_files and len(w) == 6
+    assert all(f.startswith(str(scratch)) and os.path.isfile(f) for f in w.scratch_files)
+    assert not [f for f in os.listdir(w.scratch_dir) if '.part' in f]
+    assert w.samplebuffer == copier.samplebuffer           # same seed, same table: same deck on every rank
+    # phases other than the running one are not staged at all
+    other = NumpyPathDataset(str(src) + '/', str(scratch) + '/', False, False, seed=5)
+    assert other.scratch_files == other.npy_files
+    with pytest.raises(TimeoutError):
+        NumpyPathDataset(str(src) + '/', str(tmp_path / 'never') + '/', False, True, stage_timeout=0.3)
+
+
+def test_pinned_prefetcher_host_path(tmp_path):
+    """The prefetcher hands out every sample of an epoch once, normalised, through its slot ring (CPU buffers here)."""
+    from saragan_amd.dataset import NumpyPathDataset, PinnedPrefetcher
+    d = tmp_path / '8x8'
+    d.mkdir()
+    for i in range(8):
+        np.save(d / f'{i:03d}.npy', np.full((2, 8, 8), 100 + i, dtype=np.int16))
+    ds = NumpyPathDataset(str(d) + '/', None, False, True, seed=2)
+    pf = PinnedPrefetcher(ds, 2, False, mean=100.0, stddev=2.0, device='cpu', depth=2)
+    seen = []
+    for _ in range(8):                                     # two epochs through a ring of four slots
+        b = pf.next()
+        assert tuple(b.shape) == (2, 1, 2, 8, 8) and b.dtype.is_floating_point
+        seen += [float(v) for v in b[:, 0, 0, 0, 0]]
+    pf.close()
+    assert sorted(seen[:8]) == [i / 2.0 for i in range(8)] and sorted(seen[8:]) == sorted(seen[:8])
+    ds2 = NumpyPathDataset(str(d) + '/', None, False, True, seed=2)
+    bad = PinnedPrefetcher(ds2, 2, False, device='cpu')
+    ds2.scratch_files[:] = [str(d / 'missing.npy')] * 8    # the worker dies: next() must say so, not hang
+    with pytest.raises(RuntimeError):
+        for _ in range(6):
+            bad.next()
+    bad.close()

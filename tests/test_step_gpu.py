@@ -156,3 +156,143 @@ def test_variable_names_created_by_networks_match_plan():
     created.pop('generator/generator_block_4/conv_1/weight', None)   # partial creation by the failing call
     assert {k: tuple(v) for k, v in plan.items()} == {k: v for k, v in created.items() if k in plan}
     assert set(created) - set(plan) <= {'generator/to_rgb_3/weight', 'generator/to_rgb_3/bias'}
+
+
+@pytest.mark.parametrize('name', FIXTURES[1:])
+def test_step_bf16_every_gradient_weight_and_ema(golden_dir, name):
+    """bf16 storage / MFMA (the mode the bench number is quoted in) against the fp64 fixtures: EVERY G and D gradient
+    (relative L2 per tensor; they pass through the GP double backward), the post-Adam weights and the EMA shadows after
+    one and two steps.  With beta1 = 0 a first update is -lr * sign(g): elements whose gradient is below bf16 noise may
+    land 2 lr away, at most 5 % of a tensor."""
+    from tests.cfgutil import assert_adam_close, rel_l2
+    fx = load_step_fixture(os.path.join(golden_dir, name), torch.float64)
+    store, tup, ph, ema, sess = _build(fx, torch.bfloat16)
+    mixing = fx['freeze'] is not None
+    tg, td = (tup[12], tup[16]) if mixing else (tup[0], tup[1])
+    gg_h, gv, dg_h, dv = (tup[13], tup[14], tup[17], tup[18]) if mixing else (tup[6], tup[7], tup[8], tup[9])
+    feed = {ph: fx['real'].float()}
+    _, _, gg, dg = sess.run([tg, td, gg_h, dg_h], feed_dict=feed)
+    sess.run(ema.apply())
+    worst = {}
+    for hv, grads, refs in ((gv, gg, fx['gg']), (dv, dg, fx['dg'])):
+        assert [v.key for v in hv] == list(refs.keys())
+        for v, g in zip(hv, grads):
+            worst[v.key] = rel_l2(g, refs[v.key])
+    bad = {k: e for k, e in worst.items() if e > 8e-2}
+    assert not bad, bad
+    for k, p in store.vars.items():
+        assert_adam_close(p, fx['p1'][k], 1e-3, 1e-3, f'p1:{k}', max_flip_frac=0.05)
+        assert_adam_close(ema.average(k), fx['ema1'][k], 1e-5, 1e-3, f'ema1:{k}', max_flip_frac=0.05)
+    sess.run([tg, td], feed_dict=feed)
+    sess.run(ema.apply())
+    for k, p in store.vars.items():   # second step: both arithmetic's weights have moved, differences add up
+        d = (p.detach().double().cpu() - fx['p2'][k]).abs().max()
+        assert float(d) <= 4.4e-3 + 1e-3 * float(fx['p2'][k].abs().max()), (k, float(d))
+    from saragan_amd.varstore import set_compute_dtype
+    set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize('name', [FIXTURES[3], FIXTURES[1]])
+def test_global_norm_clipping_matches_oracle(golden_dir, name):
+    """--g_clipping / --d_clipping (optimization.py:66-71): tf.clip_by_global_norm(grads, 1.0) before the update, and
+    the max per-variable norm of the CLIPPED gradients; oracle.clip_by_global_norm replayed in fp64."""
+    import saragan_amd.optimization as opt
+    from oracle import pgan_oracle as O
+    from saragan_amd.ExtendedEMA import ExtendedEMA
+    from saragan_amd.networks import loss as L
+    from saragan_amd.networks.ops import ScalarVariable
+    from saragan_amd.networks.pgan.discriminator import discriminator
+    from saragan_amd.networks.pgan.generator import generator
+    from saragan_amd.varstore import VariableStore, set_compute_dtype, use_store
+    fx = load_step_fixture(os.path.join(golden_dir, name), torch.float64)
+    # scale the initial weights up so that both global norms exceed 1 and the clip is active
+    p0 = {k: v * (1.5 if k.endswith('weight') else 1.0) for k, v in fx['p0'].items()}
+    set_compute_dtype(torch.float32)
+    store = VariableStore('cuda', seed=0)
+    L.set_random_source(L.InjectedRandom({k: v.float() for k, v in fx['rnd'].items()}))
+    alpha = ScalarVariable(fx['alpha'], 'alpha')
+    og = opt.AdamOptimizer(ScalarVariable(1e-3, 'g_lr'), 0.0, 0.9)
+    od = opt.AdamOptimizer(ScalarVariable(1e-3, 'd_lr'), 0.0, 0.9)
+    ph = opt.Placeholder([4, 1, 1, 1, 1])
+    cfg = fx['cfg']
+    with use_store(store):
+        tup = opt.optimize_step(og, od, generator, discriminator, ph, LATENT, alpha, fx['phase'], BASE_SHAPE, KERNEL_SPEC,
+                                FILTER_SPEC, 'leaky_relu', 0.2, fx['loss_fn'], cfg['gp_weight'], 'simultaneous', True, True,
+                                0.01, None if fx['freeze'] is None else list(fx['freeze']))
+    store.load_state_dict(p0, strict=True)
+    mixing = fx['freeze'] is not None
+    tg, td = (tup[12], tup[16]) if mixing else (tup[0], tup[1])
+    mg_h, md_h = (tup[15], tup[19]) if mixing else (tup[10], tup[11])
+    sess = opt.Session('cuda')
+    _, _, mgn, mdn = sess.run([tg, td, mg_h, md_h], feed_dict={ph: fx['real'].float()})
+    p = {k: v.clone() for k, v in p0.items()}
+    # unclipped gradients first, to make sure the clip bites in this case
+    probe = O.step_simultaneous({k: v.clone() for k, v in p0.items()}, O.TFAdam(0.0, 0.9), O.TFAdam(0.0, 0.9), None, fx['rnd'],
+                                fx['real'], fx['alpha'], fx['cfg'], 1e-3, 1e-3, freeze=fx['freeze'])
+    gn_g = float(torch.sqrt(sum((g * g).sum() for g in probe['g_grads'].values())))
+    gn_d = float(torch.sqrt(sum((g * g).sum() for g in probe['d_grads'].values())))
+    assert gn_d > 1.0, gn_d
+    ref = O.step_simultaneous(p, O.TFAdam(0.0, 0.9), O.TFAdam(0.0, 0.9), None, fx['rnd'], fx['real'], fx['alpha'], fx['cfg'],
+                              1e-3, 1e-3, freeze=fx['freeze'], g_clipping=True, d_clipping=True)
+    want_g = max(float(torch.linalg.vector_norm(g)) for g in ref['g_grads'].values())
+    want_d = max(float(torch.linalg.vector_norm(g)) for g in ref['d_grads'].values())
+    np.testing.assert_allclose(float(mgn), want_g, rtol=1e-3)
+    np.testing.assert_allclose(float(mdn), want_d, rtol=1e-3)
+    assert want_d <= 1.0 + 1e-9 and (gn_g <= 1.0 or want_g <= 1.0 + 1e-9)
+    for k, v in store.vars.items():
+        np.testing.assert_allclose(v.detach().double().cpu().numpy(), p[k].numpy(), rtol=1e-4, atol=2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize('kind', ['SGD', 'Momentum', 'Adadelta'])
+@pytest.mark.parametrize('strategy', ['simultaneous', 'alternate'])
+def test_other_optimizers_match_oracle(golden_dir, kind, strategy):
+    """--optimizer SGD / Momentum (Nesterov) / Adadelta (optimization.py:17-22,29-35) on the fused sg_optim_step kernel:
+    three steps against the oracle's TF update rules, with global-norm clipping on (with these rules, unlike Adam, the
+    clip scale reaches the weights).  'alternate' + SGD also covers the stale packed-weight hazard: the generator loss
+    must see the discriminator that the first half of the step has just updated."""
+    import argparse
+    import saragan_amd.optimization as opt
+    from oracle import pgan_oracle as O
+    from saragan_amd.ExtendedEMA import ExtendedEMA
+    from saragan_amd.networks import loss as L
+    from saragan_amd.networks.ops import ScalarVariable
+    from saragan_amd.networks.pgan.discriminator import discriminator
+    from saragan_amd.networks.pgan.generator import generator
+    from saragan_amd.varstore import VariableStore, set_compute_dtype, use_store
+    fx = load_step_fixture(os.path.join(golden_dir, FIXTURES[3]), torch.float64)
+    lr = {'SGD': 2e-3, 'Momentum': 1e-3, 'Adadelta': 1.0}[kind]
+    set_compute_dtype(torch.float32)
+    store = VariableStore('cuda', seed=0)
+    L.set_random_source(L.InjectedRandom({k: v.float() for k, v in fx['rnd'].items()}))
+    a = argparse.Namespace(optimizer=kind, d_optimizer=kind, adam_beta1=0.0, adam_beta2=0.9, d_adam_beta1=0.0,
+                           d_adam_beta2=0.9, rho=0.9, d_rho=0.9, momentum=0.8, d_momentum=0.8)
+    og, od = opt.get_optimizer(ScalarVariable(lr, 'd_lr'), ScalarVariable(lr, 'g_lr'), a)
+    ph = opt.Placeholder([4, 1, 1, 1, 1])
+    cfg = fx['cfg']
+    clip = strategy == 'simultaneous'
+    with use_store(store):
+        tup = opt.optimize_step(og, od, generator, discriminator, ph, LATENT, ScalarVariable(fx['alpha'], 'alpha'), fx['phase'],
+                                BASE_SHAPE, KERNEL_SPEC, FILTER_SPEC, 'leaky_relu', 0.2, fx['loss_fn'], cfg['gp_weight'],
+                                strategy, clip, clip, 0.01, None)
+    store.load_state_dict(fx['p0'], strict=True)
+    ema = ExtendedEMA(list(store.vars.keys()), 0.99, graph=tup[0].graph)
+    sess = opt.Session('cuda')
+    mk = {'SGD': O.TFSGD, 'Momentum': lambda: O.TFMomentum(0.8, True), 'Adadelta': lambda: O.TFAdadelta(0.9, 1e-7)}[kind]
+    rg, rd = mk(), mk()
+    p = {k: v.clone() for k, v in fx['p0'].items()}
+    shadow = {k: v.clone() for k, v in p.items()}
+    for step in range(3):
+        _, _, gl, dl = sess.run([tup[0], tup[1], tup[2], tup[3]], feed_dict={ph: fx['real'].float()})
+        sess.run(ema.apply())
+        if strategy == 'simultaneous':
+            ref = O.step_simultaneous(p, rg, rd, shadow, fx['rnd'], fx['real'], fx['alpha'], fx['cfg'], lr, lr,
+                                      g_clipping=True, d_clipping=True)
+        else:
+            ref = O.step_alternate(p, rg, rd, shadow, fx['rnd'], fx['real'], fx['alpha'], fx['cfg'], lr, lr)
+        np.testing.assert_allclose(float(gl), float(ref['gen_loss']), rtol=1e-4, atol=1e-5, err_msg=f'step {step}')
+        np.testing.assert_allclose(float(dl), float(ref['disc_loss']), rtol=1e-4, atol=1e-5, err_msg=f'step {step}')
+        for k, v in store.vars.items():
+            np.testing.assert_allclose(v.detach().double().cpu().numpy(), p[k].numpy(), rtol=2e-4, atol=2e-5,
+                                       err_msg=f'{kind} step {step} {k}')
+            np.testing.assert_allclose(ema.average(k).double().cpu().numpy(), shadow[k].numpy(), rtol=2e-4, atol=2e-5,
+                                       err_msg=f'{kind} ema step {step} {k}')

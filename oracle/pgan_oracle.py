@@ -267,12 +267,13 @@ def variable_shapes(phase: int, base_shape: Sequence[int], latent_dim: int, kern
 
 
 def init_params(phase, base_shape, latent_dim, kernel_spec, filter_spec, seed=0,
-                dtype=torch.float64, bias_std: float = 0.0) -> Params:
+                dtype=torch.float64, bias_std: float = 0.0, arch: str = 'pgan') -> Params:
     """weight ~ N(0,1) (ops.py:118-119, lrmul 1), bias zeros (ops.py:131).  `bias_std` > 0 draws
     non-zero biases so that parity tests exercise the bias path."""
     gen = torch.Generator().manual_seed(seed)
     p: Params = {}
-    for name, shape in variable_shapes(phase, base_shape, latent_dim, kernel_spec, filter_spec).items():
+    shapes = ARCHS[arch][2](phase, base_shape, latent_dim, kernel_spec, filter_spec)
+    for name, shape in shapes.items():
         if name.endswith('weight'):
             p[name] = torch.randn(shape, generator=gen, dtype=torch.float64).to(dtype)
         else:
@@ -338,6 +339,124 @@ def discriminator(p: Params, x, alpha, phase, latent_dim, activation, kernel_spe
 
 
 # ----------------------------------------------------------------------------------------------
+# networks/pgandeep/{generator,discriminator}.py: N = len(kernel_spec[phase]) convolutions per block
+# ----------------------------------------------------------------------------------------------
+def variable_shapes_deep(phase: int, base_shape: Sequence[int], latent_dim: int, kernel_spec, filter_spec
+                         ) -> Dict[str, Tuple[int, ...]]:
+    """Variables of pgandeep in creation order (pgandeep/generator.py:26-122, pgandeep/discriminator.py:25-131).
+    tf.get_variable sizes a conv weight from the tensor that reaches it (ops.py:148): track the running width."""
+    ch = base_shape[0]
+    v0 = int(np.prod(base_shape[1:]))
+    fs, ks = filter_spec, kernel_spec
+    out: Dict[str, Tuple[int, ...]] = {}
+    g = 'generator/'
+    c = _spec(fs, 0, 0)
+    out[g + 'generator_in/dense/weight'] = (latent_dim, v0 * c)
+    out[g + 'generator_in/dense/bias'] = (v0 * c,)
+    for j in range(1, len(ks[0])):                                   # pgandeep/generator.py:37-43
+        out[g + f'generator_in/conv_{j}/weight'] = (*_spec(ks, 0, j), c, _spec(fs, 0, j))
+        out[g + f'generator_in/conv_{j}/bias'] = (_spec(fs, 0, j),)
+        c = _spec(fs, 0, j)
+    for i in range(2, phase + 1):
+        if i == phase:
+            out[g + f'to_rgb_{phase - 1}/weight'] = (1, 1, 1, c, ch)
+            out[g + f'to_rgb_{phase - 1}/bias'] = (ch,)
+        for j in range(1, len(ks[i - 1]) + 1):                       # pgandeep/generator.py:63-71
+            out[g + f'generator_block_{i}/conv_{j}/weight'] = (*_spec(ks, i - 1, j - 1), c, _spec(fs, i - 1, j - 1))
+            out[g + f'generator_block_{i}/conv_{j}/bias'] = (_spec(fs, i - 1, j - 1),)
+            c = _spec(fs, i - 1, j - 1)
+    out[g + f'to_rgb_{phase}/weight'] = (1, 1, 1, c, ch)
+    out[g + f'to_rgb_{phase}/bias'] = (ch,)
+    d = 'discriminator/'
+    c = _spec(fs, phase - 1, 1)                                      # pgandeep/discriminator.py:112
+    out[d + f'from_rgb_{phase}/weight'] = (1, 1, 1, ch, c)
+    out[d + f'from_rgb_{phase}/bias'] = (c,)
+    for i in reversed(range(2, phase + 1)):
+        n = len(ks[i - 1])
+        for j in range(1, n + 1):                                    # pgandeep/discriminator.py:27-38
+            nf = _spec(fs, i - 2, n - 1) if j == n else _spec(fs, i - 1, n - j - 1)
+            out[d + f'discriminator_block_{i}/conv_{j}/weight'] = (*_spec(ks, i - 1, 1), c, nf)
+            out[d + f'discriminator_block_{i}/conv_{j}/bias'] = (nf,)
+            c = nf
+        if i == phase:
+            out[d + f'from_rgb_{phase - 1}/weight'] = (1, 1, 1, ch, _spec(fs, phase - 2, 1))
+            out[d + f'from_rgb_{phase - 1}/bias'] = (_spec(fs, phase - 2, 1),)
+    n0 = len(ks[0])
+    for j in range(1, n0):                                           # pgandeep/discriminator.py:66-72
+        nf = _spec(fs, 0, n0 - j - 1)
+        out[d + f'discriminator_out/conv_{j}/weight'] = (*_spec(ks, 0, n0 - j), c, nf)
+        out[d + f'discriminator_out/conv_{j}/bias'] = (nf,)
+        c = nf
+    out[d + 'discriminator_out/dense_1/weight'] = (v0 * c, latent_dim)
+    out[d + 'discriminator_out/dense_1/bias'] = (latent_dim,)
+    out[d + 'discriminator_out/dense_2/weight'] = (latent_dim, 1)
+    out[d + 'discriminator_out/dense_2/bias'] = (1,)
+    return out
+
+
+def generator_deep(p: Params, z, alpha, phase, base_shape, activation, kernel_spec, filter_spec, param=None,
+                   conditioning=None):
+    """pgandeep/generator.py:97-122."""
+    if conditioning is not None:
+        raise NotImplementedError()
+    g = 'generator/'
+
+    def stage(x, scope):
+        x = conv3d(x, p[scope + '/weight'], activation, param)
+        return pixel_norm(act(apply_bias(x, p[scope + '/bias']), activation, param))
+
+    x = dense(z, p[g + 'generator_in/dense/weight'], activation, param)
+    x = act(apply_bias(x, p[g + 'generator_in/dense/bias']), activation, param)
+    x = x.reshape(-1, _spec(filter_spec, 0, 0), *base_shape[1:])
+    for j in range(1, len(kernel_spec[0])):
+        x = stage(x, g + f'generator_in/conv_{j}')
+    x_upsample = None
+    for i in range(2, phase + 1):
+        if i == phase:
+            t = conv3d(x, p[g + f'to_rgb_{phase - 1}/weight'], 'linear')
+            x_upsample = upscale3d(apply_bias(t, p[g + f'to_rgb_{phase - 1}/bias']))
+        x = upscale3d(x)
+        for j in range(1, len(kernel_spec[i - 1]) + 1):
+            x = stage(x, g + f'generator_block_{i}/conv_{j}')
+    x_out = apply_bias(conv3d(x, p[g + f'to_rgb_{phase}/weight'], 'linear'), p[g + f'to_rgb_{phase}/bias'])
+    if x_upsample is not None:
+        x_out = alpha * x_upsample + (1 - alpha) * x_out
+    return x_out
+
+
+def discriminator_deep(p: Params, x, alpha, phase, latent_dim, activation, kernel_spec, filter_spec, param=None,
+                       conditioning=None):
+    """pgandeep/discriminator.py:97-131."""
+    if conditioning is not None:
+        raise NotImplementedError()
+    d = 'discriminator/'
+
+    def stage(x, scope):
+        x = conv3d(x, p[scope + '/weight'], activation, param)
+        return act(apply_bias(x, p[scope + '/bias']), activation, param)
+
+    x_downscale = x
+    x = stage(x, d + f'from_rgb_{phase}')
+    for i in reversed(range(2, phase + 1)):
+        for j in range(1, len(kernel_spec[i - 1]) + 1):
+            x = stage(x, d + f'discriminator_block_{i}/conv_{j}')
+        x = downscale3d(x)
+        if i == phase:
+            t = stage(downscale3d(x_downscale), d + f'from_rgb_{phase - 1}')
+            x = alpha * t + (1 - alpha) * x
+    for j in range(1, len(kernel_spec[0])):
+        x = stage(x, d + f'discriminator_out/conv_{j}')
+    x = dense(x, p[d + 'discriminator_out/dense_1/weight'], activation, param)
+    x = act(apply_bias(x, p[d + 'discriminator_out/dense_1/bias']), activation, param)
+    x = dense(x, p[d + 'discriminator_out/dense_2/weight'], 'linear')
+    return apply_bias(x, p[d + 'discriminator_out/dense_2/bias'])
+
+
+ARCHS = {'pgan': (generator, discriminator, variable_shapes),
+         'pgandeep': (generator_deep, discriminator_deep, variable_shapes_deep)}
+
+
+# ----------------------------------------------------------------------------------------------
 # networks/loss.py  (all randomness is injected: TF and torch RNG streams cannot be matched)
 # ----------------------------------------------------------------------------------------------
 def _softplus(x):
@@ -346,11 +465,12 @@ def _softplus(x):
 
 def forward_simultaneous(p: Params, real, z, noise_real, noise_fake, gamma, alpha, phase, base_shape,
                          latent_dim, kernel_spec, filter_spec, activation, leakiness, loss_fn,
-                         gp_weight, noise_stddev):
+                         gp_weight, noise_stddev, arch='pgan'):
     """networks/loss.py:101-165, including quirk Q1: slopes reduce over axes (1,2,3) of the 5-D
     gradient, so slopes has shape [N, W] (loss.py:140)."""
     net = dict(phase=phase, activation=activation, kernel_spec=kernel_spec, filter_spec=filter_spec,
                param=leakiness)
+    generator, discriminator = ARCHS[arch][:2]      # networks.<arch> (optuna_objective.py:64-65)
     gen_sample = generator(p, z, alpha, base_shape=base_shape, **net)
     real_n = real + noise_real * noise_stddev
     fake_n = gen_sample + noise_fake * noise_stddev
@@ -378,11 +498,12 @@ def forward_simultaneous(p: Params, real, z, noise_real, noise_fake, gamma, alph
 
 
 def forward_discriminator(p: Params, real, z, noise_real, noise_fake, gamma, alpha, phase, base_shape,
-                          latent_dim, kernel_spec, filter_spec, activation, leakiness, loss_fn,
-                          gp_weight, noise_stddev):
+                         latent_dim, kernel_spec, filter_spec, activation, leakiness, loss_fn,
+                         gp_weight, noise_stddev, arch='pgan'):
     """networks/loss.py:42-98 (alternate mode; GP reduces over (1,2,3,4): loss.py:79)."""
     net = dict(phase=phase, activation=activation, kernel_spec=kernel_spec, filter_spec=filter_spec,
                param=leakiness)
+    generator, discriminator = ARCHS[arch][:2]      # networks.<arch> (optuna_objective.py:64-65)
     gen_sample = generator(p, z, alpha, base_shape=base_shape, **net)
     real_n = real + noise_real * noise_stddev
     fake_n = gen_sample + noise_fake * noise_stddev
@@ -405,10 +526,11 @@ def forward_discriminator(p: Params, real, z, noise_real, noise_fake, gamma, alp
 
 
 def forward_generator(p: Params, real, z, noise_real, noise_fake, alpha, phase, base_shape, latent_dim,
-                      kernel_spec, filter_spec, activation, leakiness, loss_fn, noise_stddev):
+                      kernel_spec, filter_spec, activation, leakiness, loss_fn, noise_stddev, arch='pgan'):
     """networks/loss.py:4-39."""
     net = dict(phase=phase, activation=activation, kernel_spec=kernel_spec, filter_spec=filter_spec,
                param=leakiness)
+    generator, discriminator = ARCHS[arch][:2]      # networks.<arch> (optuna_objective.py:64-65)
     gen_sample = generator(p, z, alpha, base_shape=base_shape, **net)
     fake_n = gen_sample + noise_fake * noise_stddev
     disc_fake_g = discriminator(p, fake_n, alpha, latent_dim=latent_dim, **net)

@@ -54,6 +54,9 @@ def pgan_variable_shapes(phase, base_shape, latent_dim, kernel_spec, filter_spec
     return out
 
 
+variable_shapes = pgan_variable_shapes      # every architecture package exposes `variables.variable_shapes`
+
+
 def preset_specs(size, base_shape, num_phases):
     """kernel_spec / filter_spec equal to the legacy presets: filters from networks/ops.py:201-236, kernel per
     dimension 1 if the extent is < 3 else 3 (networks/ops.py:25-29); reproduces out.txt's parameter counts."""

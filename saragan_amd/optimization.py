@@ -6,6 +6,7 @@ returns lightweight handles bound to a StepGraph; `Session.run([...handles...], 
 batch})` executes ONE pass of the hot path for exactly the requested fetches: forward (4 discriminator passes,
 gradient penalty), backward, gradient all-reduce (if the optimizer is wrapped by
 parallel.DistributedOptimizer), optional global-norm clipping, and the fused TF-Adam(+EMA) kernel."""
+import importlib
 import math
 
 import numpy as np
@@ -343,7 +344,14 @@ def optimize_step(optimizer_gen, optimizer_disc, generator, discriminator, real_
     if loss_fn not in ('wgan', 'logistic'):
         raise ValueError(f"Unknown loss function: {loss_fn}")
     store = current_store()
-    shapes = pgan_variable_shapes(phase, base_shape, latent_dim, kernel_spec, filter_spec)
+    # the architecture's own variable plan (networks/<arch>/variables.py), found from the generator's module the way
+    # the reference finds the networks themselves (optuna_objective.py:64-65)
+    arch_pkg = getattr(generator, '__module__', '').rsplit('.', 1)[0]
+    try:
+        plan = importlib.import_module(arch_pkg + '.variables').variable_shapes
+    except (ImportError, AttributeError, ValueError):
+        plan = pgan_variable_shapes
+    shapes = plan(phase, base_shape, latent_dim, kernel_spec, filter_spec)
     for name, shp in shapes.items():           # create in the reference's order (weights N(0,1), biases 0)
         store.get(name, shp, 'normal' if name.endswith('weight') else 'zeros')
     freeze_names = None if freeze_vars is None else [_key(v) for v in freeze_vars]

@@ -16,3 +16,18 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture
+def sg_env(monkeypatch):
+    """Sets SG_* diagnostic switches for one test.  The library reads them once, so a new snapshot is taken after every
+    change (sg_config_reload) and again when the test's environment is restored."""
+    from saragan_amd import _lib
+
+    def set_(**kv):
+        for k, v in kv.items():
+            monkeypatch.setenv(k, str(v))
+        assert _lib.load().sg_config_reload() == 0
+    yield set_
+    monkeypatch.undo()
+    _lib.load().sg_config_reload()

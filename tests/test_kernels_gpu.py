@@ -291,11 +291,11 @@ def test_fused_mask_chain_first_and_second_order(big, dtype):
 
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('cout', [32, 64])
-def test_upconv_fused_gather_pingpong_kernel(cout, dtype, monkeypatch):
+def test_upconv_fused_gather_pingpong_kernel(cout, dtype, sg_env):
     """conv3d(upscale3d(x)) with Cin = 64 through the streamed ping-pong kernel's buffer-addressed x2 gather
     (boundary and interior tiles) against the oracle."""
     from saragan_amd import functional as F
-    monkeypatch.setenv('SG_FWD4_GX', '8')       # reach the ping-pong kernel with a small tensor (>= 16 tiles)
+    sg_env(SG_FWD4_GX=8)       # reach the ping-pong kernel with a small tensor (>= 16 tiles)
     n, cin, sp = 2, 64, (4, 8, 32)
     x = rnd((n, cin, *sp), 51, dtype)
     w = rnd((3, 3, 3, cin, cout), 52, dtype)
@@ -311,12 +311,12 @@ def test_upconv_fused_gather_pingpong_kernel(cout, dtype, monkeypatch):
 
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('cout', [32, 64])
-def test_upconv_subpixel_matches_oracle(cout, dtype, monkeypatch):
+def test_upconv_subpixel_matches_oracle(cout, dtype, sg_env, monkeypatch):
     """conv3d(upscale3d(x)) in sub-pixel form (eight 2x2x2-tap launches on the low-resolution input, stride-2
     scatter epilogue with bias + LeakyReLU + pixel-norm + sign words) against the oracle's 27-tap formulation, and
     against the library's own fused-gather path."""
     from saragan_amd import functional as F
-    monkeypatch.setenv('SG_FWD4_GX', '8')       # reach the ping-pong kernel with a small tensor (>= 16 tiles)
+    sg_env(SG_FWD4_GX=8)       # reach the ping-pong kernel with a small tensor (>= 16 tiles)
     n, cin, sp = 2, 16, (4, 16, 32)
     x = rnd((n, cin, *sp), 41, dtype)
     w = rnd((3, 3, 3, cin, cout), 42, dtype)

@@ -32,6 +32,7 @@ def main():
             for k in ('SG_FWD_NO_V3', 'SG_FWD_NO_V4'):
                 os.environ.pop(k, None)
             os.environ.update(env)
+            lib.sg_config_reload()
             y = torch.empty(n, d, h, w, cout, device=dev, dtype=torch.bfloat16)
             _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep), dt, st))
             torch.cuda.synchronize()
@@ -50,6 +51,7 @@ def main():
         for env in ({}, {'SG_WGRAD_V1': '1'}):
             os.environ.pop('SG_WGRAD_V1', None)
             os.environ.update(env)
+            lib.sg_config_reload()
             dw = torch.empty(3, 3, 3, cin, cout, device=dev)
             db = torch.empty(cout, device=dev)
             _lib.check(lib.sg_conv3d_wgrad_bias(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), 1.0,

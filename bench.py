@@ -2,25 +2,43 @@
 """bench.py -- G+D training-step throughput of the pgan hot path on MI355X (BASELINE.json metric:
 3D volumes/sec/node at 128x128x32).
 
-  python bench.py --gpus N --steps K --warmup W         (N == 1: run directly; N > 1: under torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W [--config 1..5]
+
+N == 1 runs in this process.  N > 1: under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process
+IS one rank; started plainly, bench.py spawns N fresh rank processes itself (before anything touches a GPU), waits for
+them and exits non-zero unless all N came up and finished.  One rank per GPU, RCCL (torch.distributed backend "nccl").
 
 One "step" = one pass of the hot path over one synthetic batch already resident in HBM: G forward, 4 D forwards,
 gradient penalty (double backward), G and D backward, gradient all-reduce (N > 1), fused TF-Adam + EMA.
-Workload at every N: pgan 's' (filters 512,512,128,128,64,32), phase 6 -> volumes [n,1,32,128,128], latent 512,
-bf16 storage/MFMA with f32 accumulation and f32 master weights, WGAN-GP (gp 10), stabilising phase (alpha 0),
-per-GPU batch fixed (weak scaling).  Prints ONE JSON line on rank 0.
+Default workload (BASELINE.json configs[2], the configuration the metric is quoted on): pgan 's' (filters
+512,512,128,128,64,32), phase 6 -> volumes [n,1,32,128,128], latent 512, bf16 storage / MFMA with f32 accumulation and
+f32 master weights, WGAN-GP (gp 10), stabilising phase (alpha 0), per-GPU batch fixed (weak scaling).
+--config selects the other BASELINE configurations (1: xs phase 1 fp32 batch 4; 2: xs phase 4 bf16 batch 32;
+4: 'm' phase 7 with fade-in, batch 2; 5: 2-D pgan 1024^2 fp32).
+
+Rank 0 prints ONE JSON line.  At N == 1 on the default workload the same line also carries (`extras`) the fp32 rate
+of the same workload and the rate with the `.npy` loader (NumpyPathDataset + PinnedPrefetcher over synthetic files)
+inside the timed loop, and `cpu_baseline`: whole G+D steps of the CPU oracle timed on this host.
 """
 import argparse
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+CONFIGS = {   # BASELINE.json configs[i-1]: SURVEY.md section 8d
+    1: dict(size='xs', phase=1, latent=256, batch=4, dtype='f32', alpha=0.0, dims=3),
+    2: dict(size='xs', phase=4, latent=256, batch=32, dtype='bf16', alpha=0.0, dims=3),
+    3: dict(size='s', phase=6, latent=512, batch=32, dtype='bf16', alpha=0.0, dims=3),
+    4: dict(size='m', phase=7, latent=512, batch=2, dtype='bf16', alpha=0.5, dims=3),
+    5: dict(size='xs', phase=9, latent=512, batch=4, dtype='f32', alpha=0.0, dims=2),
+}
 
 
 def parse():
@@ -28,20 +46,76 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=32, help='per-GPU batch')
-    ap.add_argument('--size', default='s')
-    ap.add_argument('--phase', type=int, default=6)
-    ap.add_argument('--latent', type=int, default=512)
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    ap.add_argument('--config', type=int, default=3, choices=sorted(CONFIGS))
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the configuration\'s)')
+    ap.add_argument('--size', default=None)
+    ap.add_argument('--phase', type=int, default=None)
+    ap.add_argument('--latent', type=int, default=None)
+    ap.add_argument('--dtype', default=None, choices=['bf16', 'f32'])
     ap.add_argument('--loss', default='wgan', choices=['wgan', 'logistic'])
-    ap.add_argument('--alpha', type=float, default=0.0, help='0: stabilising phase; >0: mixing (freeze ops)')
+    ap.add_argument('--alpha', type=float, default=None, help='0: stabilising phase; >0: mixing (freeze ops)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the fp32 and loader-in-the-loop legs')
     ap.add_argument('--dump-prof', action='store_true', help='per-shape conv kernel table on stderr')
-    ap.add_argument('--cpu-budget-s', type=float, default=30.0)
-    return ap.parse_args()
+    ap.add_argument('--cpu-budget-s', type=float, default=14.0)
+    args = ap.parse_args()
+    c = CONFIGS[args.config]
+    for k in ('size', 'phase', 'latent', 'batch', 'dtype', 'alpha'):
+        if getattr(args, k) is None:
+            setattr(args, k, c[k])
+    args.dims = c['dims']
+    return args
 
 
-def build(args, device):
+# -----------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: spawn the ranks (this process never touches a GPU)
+# -----------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    import socket
+    import torch   # device_count() does not initialise the GPU
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but only {have} device(s) are visible', file=sys.stderr)
+        return 3
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    line = [ln for ln in (out0 or '').splitlines() if ln.startswith('{')]
+    if any(codes) or not line:
+        print(f'bench.py: rank exit codes {codes}', file=sys.stderr)
+        return 1
+    rec = json.loads(line[-1])
+    if rec.get('n_gpus') != args.gpus:
+        print(f"bench.py: {args.gpus} ranks requested, {rec.get('n_gpus')} took part", file=sys.stderr)
+        return 1
+    print(line[-1], flush=True)
+    return 0
+
+
+# -----------------------------------------------------------------------------------------------------
+# workload
+# -----------------------------------------------------------------------------------------------------
+def specs(args):
+    if args.dims == 2:
+        from saragan_amd.networks.pgan2d import preset_specs_2d, BASE_SHAPE_2D
+        ks, fs = preset_specs_2d(args.size, 9)
+        return BASE_SHAPE_2D, ks, fs
+    from saragan_amd.networks.pgan.variables import preset_specs
+    base_shape = (1, 1, 4, 4)
+    ks, fs = preset_specs(args.size, base_shape, 8)
+    return base_shape, ks, fs
+
+
+def build(args, device, dtype):
+    import torch
     import saragan_amd.optimization as opt
     from saragan_amd import parallel
     from saragan_amd.ExtendedEMA import ExtendedEMA
@@ -49,12 +123,11 @@ def build(args, device):
     from saragan_amd.networks.ops import ScalarVariable
     from saragan_amd.networks.pgan.discriminator import discriminator
     from saragan_amd.networks.pgan.generator import generator
-    from saragan_amd.networks.pgan.variables import pgan_variable_shapes, preset_specs
+    from saragan_amd.networks.pgan.variables import pgan_variable_shapes
     from saragan_amd.varstore import VariableStore, set_compute_dtype, use_store
 
-    set_compute_dtype(torch.bfloat16 if args.dtype == 'bf16' else torch.float32)
-    base_shape = (1, 1, 4, 4)
-    ks, fs = preset_specs(args.size, base_shape, 8)
+    set_compute_dtype(torch.bfloat16 if dtype == 'bf16' else torch.float32)
+    base_shape, ks, fs = specs(args)
     rank = parallel.rank()
     store = VariableStore(device, seed=42)            # same initial weights on every rank (then broadcast anyway)
     L.set_random_source(L.RandomSource(42 + rank, device))
@@ -79,19 +152,27 @@ def build(args, device):
     sess = opt.Session(device)
     tg, td = (tup[12], tup[16]) if freeze is not None else (tup[0], tup[1])
     return dict(store=store, sess=sess, ph=ph, train=[tg, td], ema_op=ema.apply(), ks=ks, fs=fs,
-                base_shape=base_shape, shape=ph.shape, losses=[tup[3], tup[2]])
+                base_shape=base_shape, shape=ph.shape, losses=[tup[3], tup[2]], graph=graph)
+
+
+def synthetic_volume(shape, idx):
+    """One LIDC-shaped synthetic sample: clip(N(1024,512),0,4095) as int16 (HU + 1024)."""
+    import numpy as np
+    rng = np.random.default_rng(1234 + idx)
+    return np.clip(rng.normal(1024, 512, size=shape), 0, 4095).astype(np.int16)
 
 
 def synthetic_batch(shape, idx, device):
-    """LIDC-shaped synthetic volumes: clip(N(1024,512),0,4095) int16, normalised with
-    mean 1024 / std 1024, resident in HBM."""
-    rng = np.random.default_rng(1234 + idx)
-    v = np.clip(rng.normal(1024, 512, size=shape), 0, 4095).astype(np.int16).astype(np.float32)
+    """A batch of them, normalised with mean 1024 / std 1024 (scripts/example_normal_run.jb:72), resident in HBM."""
+    import numpy as np
+    import torch
+    v = synthetic_volume(shape, idx).astype(np.float32)
     return torch.from_numpy((v - 1024.0) / 1024.0).to(device)
 
 
 def conv_flops_per_volume(ks, fs, phase, base_shape, latent):
     """Forward conv/dense FLOPs of G and of D per volume (2*Cin*Cout*k*voxels), BASELINE.md section 2."""
+    import numpy as np
     from saragan_amd.networks.pgan.variables import pgan_variable_shapes
     shapes = pgan_variable_shapes(phase, base_shape, latent, ks, fs)
 
@@ -104,12 +185,9 @@ def conv_flops_per_volume(ks, fs, phase, base_shape, latent):
         if len(shp) == 2:
             fl = 2.0 * shp[0] * shp[1]
         else:
-            parts = name.split('/')
             level = 1
-            for p in parts:
-                if p.startswith('generator_block_') or p.startswith('discriminator_block_'):
-                    level = int(p.split('_')[-1])
-                if p.startswith('to_rgb_') or p.startswith('from_rgb_'):
+            for p in name.split('/'):
+                if p.startswith(('generator_block_', 'discriminator_block_', 'to_rgb_', 'from_rgb_')):
                     level = int(p.split('_')[-1])
             fl = 2.0 * np.prod(shp) * vox(level)
         if name.startswith('generator/'):
@@ -120,64 +198,122 @@ def conv_flops_per_volume(ks, fs, phase, base_shape, latent):
 
 
 def cpu_baseline(args, cfg, budget_s):
-    """The CPU restatement (oracle/, fp32 torch-CPU, kind "port") timed on this host on a BOUNDED sample of the same
-    workload: one discriminator forward pass over one volume (a full G+D step of this network takes ~5 minutes on
-    256 host threads).  D-forward is F_D of the step's 3*F_G + 12*F_D algorithmic FLOPs; the step rate is that
-    time scaled by the FLOP ratio (backward passes are not faster than forward on the CPU, so this favours the CPU)."""
+    """Whole G+D optimisation steps of the CPU restatement (oracle/, fp32 torch-CPU, kind "port": TF1 cannot run here,
+    SURVEY section 8c) timed on this host at batch 1 of the same workload -- forward, gradient penalty with its double
+    backward, both backward passes, TF-Adam.  Bounded: steps are repeated until `budget_s` of CPU time is spent."""
+    import torch
     from oracle import pgan_oracle as O
     nthreads = min(os.cpu_count() or 1, 16)   # a 1-GPU box's CPU share; more threads oversubscribe and run slower
     torch.set_num_threads(nthreads)
     ks, fs, base_shape = cfg['ks'], cfg['fs'], cfg['base_shape']
     p = O.init_params(args.phase, base_shape, args.latent, ks, fs, seed=1, dtype=torch.float32)
     img = tuple(cfg['shape'][1:])
-    real = torch.randn(1, *img)
-    fg, fd = conv_flops_per_volume(ks, fs, args.phase, base_shape, args.latent)
-    ratio = (3 * fg + 12 * fd) / fd
+    ocfg = dict(phase=args.phase, base_shape=base_shape, latent_dim=args.latent, kernel_spec=ks, filter_spec=fs,
+                activation='leaky_relu', leakiness=0.2, loss_fn=args.loss, gp_weight=10.0 if args.loss == 'wgan' else 1.0,
+                noise_stddev=0.01)
+    nb = 1 if args.config != 1 else args.batch
+    freeze = None
+    if args.alpha > 0 and args.phase > 1:
+        freeze = list(O.variable_shapes(args.phase - 1, base_shape, args.latent, ks, fs).keys())
+    ag, ad = O.TFAdam(0.0, 0.9), O.TFAdam(0.0, 0.9)
     reps, t0 = 0, time.time()
-    with torch.no_grad():
-        while True:
-            O.discriminator(p, real, args.alpha, args.phase, args.latent, 'leaky_relu', ks, fs, param=0.2)
-            reps += 1
-            if time.time() - t0 > 12.0 and reps >= 3:   # ~12 s of CPU work
-                break
+    while True:
+        rnd = O.draw_randomness(nb, args.latent, img, 100 + reps, dtype=torch.float32)
+        real = torch.randn(nb, *img)
+        O.step_simultaneous(p, ag, ad, None, rnd, real, args.alpha, ocfg, 1e-3, 1e-3, freeze=freeze)
+        reps += 1
+        if time.time() - t0 >= budget_s:
+            break
     dt = (time.time() - t0) / reps
-    return dict(value=float(1.0 / (dt * ratio)), unit='volumes/s', cores=nthreads, kind='port',
-                sample=f'{reps} discriminator forward pass(es) over one {img[1]}x{img[2]}x{img[3]} volume '
-                       f'({dt:.1f} s each, fp32 torch-CPU restatement in oracle/), scaled by the step/forward '
-                       f'FLOP ratio {ratio:.1f}')
+    return dict(value=float(nb / dt), unit='volumes/s', cores=nthreads, kind='port',
+                sample=f'{reps} whole G+D step(s) of the fp32 torch-CPU oracle at batch {nb} of this workload '
+                       f'({dt:.1f} s per step: G forward, 4 D forwards, GP double backward, G and D backward, TF-Adam)')
 
 
 def pmc_traffic(entry, dtype):
     """Bytes per launch that crossed the L2's memory side for this (kind, shape), from the committed rocprofv3 counter
-    passes (profiles/r01_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, tools/pmc_probe.py + tools/pmc_summary.py; the
-    counters cannot be read from inside this process).  Mean over the epilogue variants measured; None when this
-    shape / batch / dtype was not part of the counter run."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_pmc_traffic.json')
-    if not os.path.exists(path):
-        return None
-    tab = json.load(open(path))
-    if tab.get('dtype') != dtype:
-        return None
-    s = entry.shape
-    key = dict(n=s.n, d=s.d, h=s.h, w=s.w, cin=s.cin, cout=s.cout, k=[s.kd, s.kh, s.kw])
-    kind = 'fwd' if entry.kind == 0 else 'wgrad'
-    hits = [e['traffic_bytes'] for e in tab['entries'] if e['kind'] == kind and e['shape'] == key]
-    if not hits or s.upsample_in:
-        return None
-    return round(sum(hits) / len(hits))
+    passes (profiles/r02_pmc_traffic.json, else r01: FETCH_SIZE x2 + WRITE_SIZE; tools/pmc_probe.py +
+    tools/pmc_summary.py; the counters cannot be read from inside this process).  Mean over the epilogue variants
+    measured; None when this shape / batch / dtype was not part of the counter run."""
+    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+        path = os.path.join(ROOT, 'profiles', name)
+        if not os.path.exists(path):
+            continue
+        tab = json.load(open(path))
+        if tab.get('dtype') != dtype:
+            continue
+        s = entry.shape
+        key = dict(n=s.n, d=s.d, h=s.h, w=s.w, cin=s.cin, cout=s.cout, k=[s.kd, s.kh, s.kw])
+        kind = 'fwd' if entry.kind == 0 else 'wgrad'
+        hits = [e['traffic_bytes'] for e in tab['entries'] if e['kind'] == kind and e['shape'] == key and
+                (not e.get('kernel') or e['kernel'] == entry.kernel.decode())]
+        if hits and not s.upsample_in:
+            return round(sum(hits) / len(hits))
+    return None
+
+
+def timed_steps(step, nsteps, barrier):
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(nsteps):
+        step(i)
+    barrier()
+    return time.perf_counter() - t0
+
+
+def loader_leg(args, cfg, device, nsteps, barrier):
+    """The same step with the data path inside the timed loop (SURVEY section 8d "loader included"): synthetic
+    `{xy}x{xy}/NNNN.npy` int16 volumes on local disk, NumpyPathDataset drawing batches, PinnedPrefetcher loading,
+    normalising and copying them host-to-device on a side stream while the step runs."""
+    import numpy as np
+    from saragan_amd.dataset import NumpyPathDataset, PinnedPrefetcher
+    shape = cfg['shape']
+    tmp = tempfile.mkdtemp(prefix='saragan_bench_')
+    try:
+        d = os.path.join(tmp, f'{shape[-1]}x{shape[-1]}')
+        os.makedirs(d)
+        nfiles = max(2 * args.batch, 64)
+        for i in range(nfiles):
+            np.save(os.path.join(d, f'{i:04d}.npy'), synthetic_volume(tuple(shape[2:]), 10_000 + i))
+        ds = NumpyPathDataset(d + '/', None, False, True, seed=42)
+        pf = PinnedPrefetcher(ds, args.batch, False, mean=1024.0, stddev=1024.0, device=device, depth=2)
+        sess, ph = cfg['sess'], cfg['ph']
+
+        def step(i):
+            sess.run(cfg['train'], feed_dict={ph: pf.next()})
+            sess.run(cfg['ema_op'])
+        for i in range(2):
+            step(i)
+        dt = timed_steps(step, nsteps, barrier)
+        pf.close()
+        mb = nfiles * np.prod(shape[2:]) * 2 / 2 ** 20
+        return dict(value=round(args.batch * nsteps / dt, 3), ms_per_step=round(dt / nsteps * 1e3, 3), steps=nsteps,
+                    note=f'loader in the timed loop: {nfiles} synthetic int16 .npy volumes ({mb:.0f} MiB) on local disk, '
+                         f'np.load -> pinned ring -> async H2D on a side stream, 2 batches ahead')
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
+    import ctypes as C
+    import torch
     from saragan_amd import _lib, parallel
     rank, world, local = parallel.init_distributed()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: every rank must be started (torch.distributed.run, '
+                         f'or plain `python bench.py --gpus N`, which spawns them)')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     device = torch.device('cuda', local % max(1, torch.cuda.device_count()))   # (rehearsals may stack ranks on one GPU)
     torch.cuda.set_device(device)
-    cfg = build(args, device)
+    comm = None
+    if world > 1:
+        dist = torch.distributed
+        comm = dict(backend=dist.get_backend(), world_size=dist.get_world_size())
+    cfg = build(args, device, args.dtype)
     sess, ph = cfg['sess'], cfg['ph']
     batches = [synthetic_batch(cfg['shape'], rank * 1000 + i, device) for i in range(4)]
 
@@ -185,16 +321,15 @@ def main():
         sess.run(cfg['train'], feed_dict={ph: batches[i % len(batches)]})
         sess.run(cfg['ema_op'])
 
-    for i in range(args.warmup):
-        step(i)
-    lib = _lib.load()
-
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    for i in range(args.warmup):
+        step(i)
+    lib = _lib.load()
     barrier()
     lib.sg_prof_enable(1)
     t0 = time.perf_counter()
@@ -203,62 +338,86 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     # kernel timings (HIP events recorded on the launch stream inside the timed region)
-    import ctypes as C
     ents = (_lib.ProfEntry * 256)()
     n_ent = C.c_int32(0)
     lib.sg_prof_collect(ents, 256, C.byref(n_ent))
     lib.sg_prof_enable(0)
+    losses = [float(v) for v in sess.run(cfg['losses'] + cfg['train'], feed_dict={ph: batches[0]})[:2]]
+    if not all(l == l and abs(l) < 1e30 for l in losses):
+        raise SystemExit(f'non-finite losses after the timed steps: {losses}')
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     if rank != 0:
         return
+    rows = sorted((ents[i] for i in range(n_ent.value)), key=lambda e: -e.total_ms)
     if args.dump_prof:
-        rows = sorted((ents[i] for i in range(n_ent.value)), key=lambda e: -e.total_ms)
         for e in rows:
             s_ = e.shape
-            print(f"{'fwd ' if e.kind == 0 else 'wgrd'} n{s_.n} {s_.d}x{s_.h}x{s_.w} {s_.cin:4d}->{s_.cout:4d} k{s_.kd}{s_.kh}{s_.kw} "
-                  f"ups{s_.upsample_in} calls/step {e.launches / args.steps:5.1f} avg {e.total_ms / e.launches * 1e3:8.1f} us "
-                  f"ms/step {e.total_ms / args.steps:7.3f} TF/s {e.flops_per_launch / (e.total_ms / e.launches) / 1e9:7.1f}",
-                  file=sys.stderr)
+            print(f"{'fwd ' if e.kind == 0 else 'wgrd'} {e.kernel.decode():28s} n{s_.n} {s_.d}x{s_.h}x{s_.w} {s_.cin:4d}->{s_.cout:4d} "
+                  f"k{s_.kd}{s_.kh}{s_.kw} ups{s_.upsample_in} calls/step {e.launches / args.steps:5.1f} "
+                  f"avg {e.total_ms / e.launches * 1e3:8.1f} us ms/step {e.total_ms / args.steps:7.3f} "
+                  f"TF/s {e.flops_per_launch / (e.total_ms / e.launches) / 1e9:7.1f}", file=sys.stderr)
     vols = args.batch * world * args.steps
     value = vols / dt
-    # dominant kernel = the (kind, shape) with the largest total time
-    best = None
-    for i in range(n_ent.value):
-        e = ents[i]
-        if best is None or e.total_ms > best.total_ms:
-            best = e
     peak = 2500.0 if args.dtype == 'bf16' else 157.3
     roof = None
-    if best is not None and best.launches > 0:
+    if rows and rows[0].launches > 0:        # dominant kernel = the (kind, shape) with the largest total time
+        best = rows[0]
         avg_ms = best.total_ms / best.launches
         ach = best.flops_per_launch / (avg_ms * 1e-3) / 1e12
         s = best.shape
         roof = dict(bound='mfma', achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
-                    traffic=pmc_traffic(best, args.dtype),
-                    kernel=('conv_fwd_kernel' if best.kind == 0 else 'conv_wgrad_kernel'),
+                    traffic=pmc_traffic(best, args.dtype), kernel=best.kernel.decode(),
                     shape=dict(n=s.n, d=s.d, h=s.h, w=s.w, cin=s.cin, cout=s.cout, k=[s.kd, s.kh, s.kw],
                                upsample_in=s.upsample_in),
-                    launches=int(best.launches), avg_ms=round(avg_ms, 4),
-                    flops_per_launch=best.flops_per_launch)
+                    launches=int(best.launches), avg_ms=round(avg_ms, 4), flops_per_launch=best.flops_per_launch,
+                    algorithmic_bytes=int(s.n * s.d * s.h * s.w * (s.cin / (8 if s.upsample_in else 1) + s.cout) *
+                                          (2 if args.dtype == 'bf16' else 4)))
     fg, fd = conv_flops_per_volume(cfg['ks'], cfg['fs'], args.phase, cfg['base_shape'], args.latent)
     # executed conv work: G fwd+dgrad+wgrad; D: 3 forwards, 3 (wgan: the G loss reuses the D-loss data gradient)
     # or 4 data-gradient passes, 2 weight-gradient passes, 2 convs of the GP double backward + its weight gradient
     step_gf = (3 * fg + (11 if args.loss == 'wgan' else 12) * fd) / 1e9
-    total_conv_ms = sum(ents[i].total_ms for i in range(n_ent.value))
-    out = dict(metric='3D volumes/sec/node (G+D step) at 128x128x32', value=round(value, 3), unit='volumes/s',
+    total_conv_ms = sum(e.total_ms for e in rows)
+    sh = cfg['shape']
+    dims = 'x'.join(str(v) for v in (sh[3], sh[4], sh[2])) if args.dims == 3 else f'{sh[3]}x{sh[4]}'
+    unit = 'volumes/s' if args.dims == 3 else 'images/s'
+    out = dict(metric=f"3D volumes/sec/node (G+D step) at {dims}" if args.dims == 3 else f"2D images/sec/node (G+D step) at {dims}",
+               value=round(value, 3), unit=unit,
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
                higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype, data='synthetic',
-               config=dict(workload=f"pgan '{args.size}' phase {args.phase} G+D step, volumes "
-                                    f"{cfg['shape'][2]}x{cfg['shape'][3]}x{cfg['shape'][4]}, {args.loss}-gp, "
-                                    f"simultaneous, alpha {args.alpha}",
+               config=dict(workload=f"BASELINE configs[{args.config - 1}]: pgan '{args.size}' phase {args.phase} G+D step, "
+                                    f"{'volumes' if args.dims == 3 else 'images'} {'x'.join(str(v) for v in sh[2:])}, "
+                                    f"{args.loss}-gp, simultaneous, alpha {args.alpha}",
                            local_batch=args.batch, global_batch=args.batch * world, latent_dim=args.latent,
-                           parallelism=f'dp{world}', step_gflop_per_volume=round(step_gf, 1),
+                           parallelism=f'dp{world}', collective=comm, step_gflop_per_volume=round(step_gf, 1),
                            step_mfma_tflops=round(value * step_gf / 1e3 / world, 2),
-                           conv_kernel_ms_per_step=round(total_conv_ms / args.steps, 3)),
+                           conv_kernel_ms_per_step=round(total_conv_ms / args.steps, 3),
+                           losses_after=dict(disc=round(losses[0], 4), gen=round(losses[1], 4))),
                roofline=roof)
+    if world == 1 and args.config == 3 and not args.no_extras:
+        extras = {}
+        extras['loader_in_loop'] = loader_leg(args, cfg, device, max(3, args.steps // 2), barrier)
+        # the same workload in fp32 storage / f32-input MFMA (the reference's arithmetic, ops.py:147-150)
+        del cfg, sess, batches
+        from saragan_amd import functional as F
+        F.clear_pack_cache()
+        torch.cuda.empty_cache()
+        cfg32 = build(args, device, 'f32')
+        b32 = [synthetic_batch(cfg32['shape'], i, device) for i in range(2)]
+
+        def step32(i):
+            cfg32['sess'].run(cfg32['train'], feed_dict={cfg32['ph']: b32[i % 2]})
+            cfg32['sess'].run(cfg32['ema_op'])
+        step32(0)
+        n32 = 3
+        dt32 = timed_steps(step32, n32, barrier)
+        extras['f32'] = dict(value=round(args.batch * n32 / dt32, 3), ms_per_step=round(dt32 / n32 * 1e3, 3), steps=n32,
+                             step_mfma_tflops=round(args.batch * n32 / dt32 * step_gf / 1e3, 2), peak_tflops=157.3,
+                             note='same workload, fp32 storage and v_mfma_f32_32x32x2_f32 (1/16 of the bf16 MFMA rate)')
+        out['extras'] = extras
+        cfg = cfg32
     if world == 1 and not args.no_cpu_baseline:
         out['cpu_baseline'] = cpu_baseline(args, cfg, args.cpu_budget_s)
     print(json.dumps(out), flush=True)

@@ -198,7 +198,10 @@ def dense(x, fmaps, activation, lrmul=1, param=None):
     if len(x.shape) > 2:
         x = x.reshape(x.shape[0], int(np.prod(x.shape[1:])))
     w = get_weight([x.shape[1], fmaps], activation, lrmul=lrmul, param=param)
-    return _LazyConv(x.to(compute_dtype()), w.var, w.coef, False)
+    # the discriminator's logit layer (one output unit) runs in f32 whatever the compute dtype: the losses add terms
+    # 1000x apart (wgan drift 1e-3 * D(real)^2 next to D(fake) - D(real), loss.py:146-151), below bf16 resolution
+    dt = torch.float32 if fmaps == 1 else compute_dtype()
+    return _LazyConv(x.to(dt), w.var, w.coef, False)
 
 
 def conv3d(x, fmaps, kernel, activation, param=None, lrmul=1):

@@ -104,10 +104,10 @@ def spawn_ranks(args):
 # workload
 # -----------------------------------------------------------------------------------------------------
 def specs(args):
-    if args.dims == 2:
-        from saragan_amd.networks.pgan2d import preset_specs_2d, BASE_SHAPE_2D
-        ks, fs = preset_specs_2d(args.size, 9)
-        return BASE_SHAPE_2D, ks, fs
+    if args.dims == 2:      # SURFGAN_2D: 1024^2 = 4 * 2^8 -> 9 phases (SURFGAN_2D/main.py:53), base (3,4,4), legacy triple
+        from saragan_amd.networks2d.ops import num_filters
+        from saragan_amd.networks2d.pgan.variables import legacy_spec
+        return (3, 1, 4, 4), None, legacy_spec(9, num_filters(1, 9, size=args.size), args.size)
     from saragan_amd.networks.pgan.variables import preset_specs
     base_shape = (1, 1, 4, 4)
     ks, fs = preset_specs(args.size, base_shape, 8)
@@ -121,10 +121,14 @@ def build(args, device, dtype):
     from saragan_amd.ExtendedEMA import ExtendedEMA
     from saragan_amd.networks import loss as L
     from saragan_amd.networks.ops import ScalarVariable
-    from saragan_amd.networks.pgan.discriminator import discriminator
-    from saragan_amd.networks.pgan.generator import generator
-    from saragan_amd.networks.pgan.variables import pgan_variable_shapes
     from saragan_amd.varstore import VariableStore, set_compute_dtype, use_store
+    if args.dims == 2:
+        from saragan_amd.networks2d.pgan.spec_api import discriminator, generator
+        from saragan_amd.networks2d.pgan.variables import variable_shapes as pgan_variable_shapes
+    else:
+        from saragan_amd.networks.pgan.discriminator import discriminator
+        from saragan_amd.networks.pgan.generator import generator
+        from saragan_amd.networks.pgan.variables import pgan_variable_shapes
 
     set_compute_dtype(torch.bfloat16 if dtype == 'bf16' else torch.float32)
     base_shape, ks, fs = specs(args)
@@ -170,10 +174,13 @@ def synthetic_batch(shape, idx, device):
     return torch.from_numpy((v - 1024.0) / 1024.0).to(device)
 
 
-def conv_flops_per_volume(ks, fs, phase, base_shape, latent):
+def conv_flops_per_volume(ks, fs, phase, base_shape, latent, dims=3):
     """Forward conv/dense FLOPs of G and of D per volume (2*Cin*Cout*k*voxels), BASELINE.md section 2."""
     import numpy as np
-    from saragan_amd.networks.pgan.variables import pgan_variable_shapes
+    if dims == 2:
+        from saragan_amd.networks2d.pgan.variables import variable_shapes as pgan_variable_shapes
+    else:
+        from saragan_amd.networks.pgan.variables import pgan_variable_shapes
     shapes = pgan_variable_shapes(phase, base_shape, latent, ks, fs)
 
     def vox(level):
@@ -206,11 +213,15 @@ def cpu_baseline(args, cfg, budget_s):
     nthreads = min(os.cpu_count() or 1, 16)   # a 1-GPU box's CPU share; more threads oversubscribe and run slower
     torch.set_num_threads(nthreads)
     ks, fs, base_shape = cfg['ks'], cfg['fs'], cfg['base_shape']
+    if args.dims == 2:       # the 2-D networks as D == 1 volumes of the same restatement (oracle.specs_2d)
+        ks, fs = O.specs_2d(fs['num_phases'], fs['size'])
     p = O.init_params(args.phase, base_shape, args.latent, ks, fs, seed=1, dtype=torch.float32)
     img = tuple(cfg['shape'][1:])
     ocfg = dict(phase=args.phase, base_shape=base_shape, latent_dim=args.latent, kernel_spec=ks, filter_spec=fs,
                 activation='leaky_relu', leakiness=0.2, loss_fn=args.loss, gp_weight=10.0 if args.loss == 'wgan' else 1.0,
                 noise_stddev=0.01)
+    if args.dims == 2:
+        ocfg['gp_full'] = True
     nb = 1 if args.config != 1 else args.batch
     freeze = None
     if args.alpha > 0 and args.phase > 1:
@@ -330,18 +341,36 @@ def main():
     for i in range(args.warmup):
         step(i)
     lib = _lib.load()
+
+    def collect():
+        ents = (_lib.ProfEntry * 256)()
+        n_ent = C.c_int32(0)
+        lib.sg_prof_collect(ents, 256, C.byref(n_ent))
+        return sorted((ents[i] for i in range(n_ent.value)), key=lambda e: -e.total_ms)
+
+    # (untimed) two steps with every conv launch bracketed by HIP events: the per-shape table and the dominant kernel.
+    # Two event records per launch x ~600 launches cost ~10 % of a step, so the TIMED region below brackets only the
+    # dominant (kind, shape)'s launches -- its duration is still measured inside the timed region.
+    ncal = 2
+    barrier()
+    lib.sg_prof_enable(1)
+    for i in range(ncal):
+        step(args.warmup + i)
+    barrier()
+    table = collect()
+    lib.sg_prof_enable(0)
+    if table:
+        lib.sg_prof_set_filter(table[0].kind, C.byref(table[0].shape))
     barrier()
     lib.sg_prof_enable(1)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(args.warmup + i)
+        step(args.warmup + ncal + i)
     barrier()
     dt = time.perf_counter() - t0
-    # kernel timings (HIP events recorded on the launch stream inside the timed region)
-    ents = (_lib.ProfEntry * 256)()
-    n_ent = C.c_int32(0)
-    lib.sg_prof_collect(ents, 256, C.byref(n_ent))
+    timed = collect()
     lib.sg_prof_enable(0)
+    lib.sg_prof_set_filter(0, None)
     losses = [float(v) for v in sess.run(cfg['losses'] + cfg['train'], feed_dict={ph: batches[0]})[:2]]
     if not all(l == l and abs(l) < 1e30 for l in losses):
         raise SystemExit(f'non-finite losses after the timed steps: {losses}')
@@ -351,20 +380,20 @@ def main():
         dt = float(t.item())
     if rank != 0:
         return
-    rows = sorted((ents[i] for i in range(n_ent.value)), key=lambda e: -e.total_ms)
+    rows = table
     if args.dump_prof:
         for e in rows:
             s_ = e.shape
             print(f"{'fwd ' if e.kind == 0 else 'wgrd'} {e.kernel.decode():28s} n{s_.n} {s_.d}x{s_.h}x{s_.w} {s_.cin:4d}->{s_.cout:4d} "
-                  f"k{s_.kd}{s_.kh}{s_.kw} ups{s_.upsample_in} calls/step {e.launches / args.steps:5.1f} "
-                  f"avg {e.total_ms / e.launches * 1e3:8.1f} us ms/step {e.total_ms / args.steps:7.3f} "
+                  f"k{s_.kd}{s_.kh}{s_.kw} ups{s_.upsample_in} calls/step {e.launches / ncal:5.1f} "
+                  f"avg {e.total_ms / e.launches * 1e3:8.1f} us ms/step {e.total_ms / ncal:7.3f} "
                   f"TF/s {e.flops_per_launch / (e.total_ms / e.launches) / 1e9:7.1f}", file=sys.stderr)
     vols = args.batch * world * args.steps
     value = vols / dt
     peak = 2500.0 if args.dtype == 'bf16' else 157.3
     roof = None
-    if rows and rows[0].launches > 0:        # dominant kernel = the (kind, shape) with the largest total time
-        best = rows[0]
+    if timed and timed[0].launches > 0:      # dominant kernel = the (kind, shape) with the largest total time
+        best = timed[0]
         avg_ms = best.total_ms / best.launches
         ach = best.flops_per_launch / (avg_ms * 1e-3) / 1e12
         s = best.shape
@@ -375,11 +404,11 @@ def main():
                     launches=int(best.launches), avg_ms=round(avg_ms, 4), flops_per_launch=best.flops_per_launch,
                     algorithmic_bytes=int(s.n * s.d * s.h * s.w * (s.cin / (8 if s.upsample_in else 1) + s.cout) *
                                           (2 if args.dtype == 'bf16' else 4)))
-    fg, fd = conv_flops_per_volume(cfg['ks'], cfg['fs'], args.phase, cfg['base_shape'], args.latent)
+    fg, fd = conv_flops_per_volume(cfg['ks'], cfg['fs'], args.phase, cfg['base_shape'], args.latent, args.dims)
     # executed conv work: G fwd+dgrad+wgrad; D: 3 forwards, 3 (wgan: the G loss reuses the D-loss data gradient)
     # or 4 data-gradient passes, 2 weight-gradient passes, 2 convs of the GP double backward + its weight gradient
     step_gf = (3 * fg + (11 if args.loss == 'wgan' else 12) * fd) / 1e9
-    total_conv_ms = sum(e.total_ms for e in rows)
+    total_conv_ms = sum(e.total_ms for e in rows) * args.steps / ncal
     sh = cfg['shape']
     dims = 'x'.join(str(v) for v in (sh[3], sh[4], sh[2])) if args.dims == 3 else f'{sh[3]}x{sh[4]}'
     unit = 'volumes/s' if args.dims == 3 else 'images/s'

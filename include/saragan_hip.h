@@ -148,6 +148,14 @@ int sg_upscale2x_masked(const void* x, void* y, const void* mask_bits, float mas
  * gain = 1 is the gradient of upscale3d (ops.py:284).  (d,h,w) = INPUT extent, all even. */
 int sg_downscale2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
                    float gain, sg_dtype dt, sg_stream_t st);
+/* The same two operations with a factor of 1 or 2 PER DIMENSION (fd, fh, fw): (1,2,2) are upscale2d / downscale2d of the
+ * 2-D tree on D == 1 tensors (SURFGAN_2D/networks/ops.py:176-231); (1,2,1) finishes a D x W-pooled convolution output.
+ * sg_upscale_nn: x [n,d,h,w,c] -> y [n,d*fd,h*fh,w*fw,c], optional sign-word mask of a tensor shaped like y.
+ * sg_downscale_sum: x [n,d,h,w,c] (INPUT extent, divisible by the factors) -> y [n,d/fd,h/fh,w/fw,c] = gain * block sum. */
+int sg_upscale_nn(const void* x, void* y, const void* mask_bits, float mask_slope, int32_t n, int32_t d, int32_t h,
+                  int32_t w, int32_t c, int32_t fd, int32_t fh, int32_t fw, float gain, sg_dtype dt, sg_stream_t st);
+int sg_downscale_sum(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c, int32_t fd,
+                     int32_t fh, int32_t fw, float gain, sg_dtype dt, sg_stream_t st);
 /* out = wa*a + wb*b     (fade-in lerp pgan/generator.py:100-101, pgan/discriminator.py:105; b may be NULL) */
 int sg_axpby(const void* a, const void* b, void* out, float wa, float wb, int64_t numel, sg_dtype dt,
              sg_stream_t st);
@@ -205,6 +213,10 @@ typedef struct {
   char kernel[64];     /* kernel family + template arguments the dispatcher chose for this shape, e.g. "conv_fwd4<bf16,2,1,3,3,3>" */
 } sg_prof_entry;
 int sg_prof_enable(int on);
+/* Restrict the timing to ONE (kind, shape) (NULL: every launch again): two event records per launch are not free, and a
+ * throughput measurement that wants the dominant kernel's duration from inside its own timed region brackets only
+ * that kernel's launches. */
+int sg_prof_set_filter(int kind, const sg_conv_shape* shape);
 int sg_prof_collect(sg_prof_entry* out, int32_t max_entries, int32_t* n_entries);
 
 /* The SG_* environment switches (kernel-selection overrides for diagnosis, e.g. SG_FWD_NO_V4=1) are read once, at the

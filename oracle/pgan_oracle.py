@@ -465,9 +465,11 @@ def _softplus(x):
 
 def forward_simultaneous(p: Params, real, z, noise_real, noise_fake, gamma, alpha, phase, base_shape,
                          latent_dim, kernel_spec, filter_spec, activation, leakiness, loss_fn,
-                         gp_weight, noise_stddev, arch='pgan'):
+                         gp_weight, noise_stddev, arch='pgan', gp_full=False):
     """networks/loss.py:101-165, including quirk Q1: slopes reduce over axes (1,2,3) of the 5-D
-    gradient, so slopes has shape [N, W] (loss.py:140)."""
+    gradient, so slopes has shape [N, W] (loss.py:140).  gp_full: the 2-D tree's version of this function reduces
+    its 4-D gradient over (1,2,3) = every non-batch axis (SURFGAN_2D/networks/loss.py:130-137); on the D == 1
+    volumes used here that is axes (1,2,3,4), slopes [N] -> [N,1]."""
     net = dict(phase=phase, activation=activation, kernel_spec=kernel_spec, filter_spec=filter_spec,
                param=leakiness)
     generator, discriminator = ARCHS[arch][:2]      # networks.<arch> (optuna_objective.py:64-65)
@@ -479,7 +481,10 @@ def forward_simultaneous(p: Params, real, z, noise_real, noise_fake, gamma, alph
     interpolates = (gamma * real_n + (1 - gamma) * fake_n.detach()).requires_grad_(True)
     d_int = discriminator(p, interpolates, alpha, latent_dim=latent_dim, **net)
     (gradients,) = torch.autograd.grad(d_int.sum(), interpolates, create_graph=True)
-    slopes = torch.sqrt(torch.sum(gradients * gradients, dim=(1, 2, 3)))
+    if gp_full:
+        slopes = torch.sqrt(torch.sum(gradients * gradients, dim=(1, 2, 3, 4))).reshape(-1, 1)
+    else:
+        slopes = torch.sqrt(torch.sum(gradients * gradients, dim=(1, 2, 3)))
     disc_fake_g = discriminator(p, fake_n, alpha, latent_dim=latent_dim, **net)
     if loss_fn == 'wgan':
         gp_loss = gp_weight * (slopes - 1) ** 2
@@ -729,6 +734,20 @@ def step_alternate(p: Params, adam_g: TFAdam, adam_d: TFAdam, shadow: Optional[P
         ema_update(shadow, p, ema_beta)
     return dict(gen_loss=gen_loss.detach(), disc_loss=disc_loss.detach(), gp_loss=gp_loss.detach(),
                 gen_sample=gen_sample.detach(), g_grads=g_grads, d_grads=d_grads)
+
+
+def specs_2d(num_phases: int, size: str):
+    """The 2-D pgan (SURFGAN_2D/networks/pgan/*.py, legacy signature with base_dim = num_filters(1)) written as
+    kernel / filter specs of the 3-D restatement on D == 1 volumes: base_shape (C,1,4,4), kernels (1,3,3) (k() of the
+    2-D extents, all >= 3), filters num_filters_2d(l) (SURFGAN_2D/networks/ops.py:139-158)."""
+    lists = {
+        'xxs': [64] * 8 + [32, 16, 8, 4, 2], 'xs': [128] * 8 + [64, 32, 16, 8, 4], 's': [256] * 8 + [128, 64, 32, 16, 8],
+        'm': [512] * 8 + [256, 128, 64, 32, 16], 'l': [512] * 9 + [256, 128, 64, 32],
+        'xl': [1024] * 9 + [512, 256, 128, 64], 'xxl': [2048] * 9 + [1024, 512, 256, 128]}
+    fl = lists[size][-num_phases:]
+    fs = [[f, f] for f in fl]
+    ks = [[[1, 3, 3], [1, 3, 3]] for _ in fl]
+    return ks, fs
 
 
 def draw_randomness(n, latent_dim, img_shape, seed, dtype=torch.float64):

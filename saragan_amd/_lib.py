@@ -59,6 +59,8 @@ SIGNATURES = {
     'sg_upscale2x': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
     'sg_upscale2x_masked': (C.c_int, [_p, _p, _p, _f, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
     'sg_downscale2x': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
+    'sg_upscale_nn': (C.c_int, [_p, _p, _p, _f, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
+    'sg_downscale_sum': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
     'sg_axpby': (C.c_int, [_p, _p, _p, _f, _f, _i64, C.c_int, _p]),
     'sg_add_noise': (C.c_int, [_p, _p, _f, _u64, _u64, _i64, C.c_int, _p]),
     'sg_sumsq_ndhwc_keep_w': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, C.c_int, _p]),
@@ -70,6 +72,7 @@ SIGNATURES = {
     'sg_segment_sumsq': (C.c_int, [_p, _p, _p, _i32, _p]),
     'sg_prof_enable': (C.c_int, [C.c_int]),
     'sg_prof_collect': (C.c_int, [C.POINTER(ProfEntry), _i32, C.POINTER(_i32)]),
+    'sg_prof_set_filter': (C.c_int, [C.c_int, _SHP]),
     'sg_config_reload': (C.c_int, []),
 }
 

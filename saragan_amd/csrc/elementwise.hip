@@ -342,20 +342,25 @@ __global__ void pixel_norm_scalar_kernel(const T* __restrict__ a, const T* __res
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Nearest-neighbour up-sampling / sum-pooling by a factor of 1 or 2 PER DIMENSION (shift sd, sh, sw in {0, 1}): (1,1,1)
+// is upscale3d / downscale3d, (0,1,1) the 2-D twins (SURFGAN_2D/networks/ops.py:176-231), (0,1,0) the H-only pooling
+// that finishes a convolution's fused D x W pooling.
 template <typename T, bool VEC>
 __global__ void upscale2x_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int d, int h, int w, int c,
-                                 float gain, const uint32_t* __restrict__ mask_bits, float mask_slope) {
+                                 int sd, int sh, int sw, float gain, const uint32_t* __restrict__ mask_bits,
+                                 float mask_slope) {
   constexpr int E = VEC ? Piece<T>::E : 1;
   const int P = c / E;
-  const int64_t total = (int64_t)n * (2 * d) * (2 * h) * (2 * w) * P;
+  const int OD = d << sd, OH = h << sh, OW = w << sw;
+  const int64_t total = (int64_t)n * OD * OH * OW * P;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int p = (int)(i % P);
     int64_t q = i / P;
-    const int ow = (int)(q % (2 * w)); q /= 2 * w;
-    const int oh = (int)(q % (2 * h)); q /= 2 * h;
-    const int od = (int)(q % (2 * d));
-    const int nn = (int)(q / (2 * d));
-    const int64_t src = ((((int64_t)nn * d + (od >> 1)) * h + (oh >> 1)) * w + (ow >> 1)) * c + (int64_t)p * E;
+    const int ow = (int)(q % OW); q /= OW;
+    const int oh = (int)(q % OH); q /= OH;
+    const int od = (int)(q % OD);
+    const int nn = (int)(q / OD);
+    const int64_t src = ((((int64_t)nn * d + (od >> sd)) * h + (oh >> sh)) * w + (ow >> sw)) * c + (int64_t)p * E;
     if (VEC) {
       Piece<T> pc;
       pc.load(x + src);
@@ -364,9 +369,9 @@ __global__ void upscale2x_kernel(const T* __restrict__ x, T* __restrict__ y, int
         for (int e = 0; e < Piece<T>::E; ++e) pc.v[e] *= gain;
       }
       if (mask_bits) {
-        const uint32_t sw = piece_signs(mask_bits, i / P, (c + 31) >> 5, p * E);
+        const uint32_t sw_ = piece_signs(mask_bits, i / P, (c + 31) >> 5, p * E);
 #pragma unroll
-        for (int e = 0; e < Piece<T>::E; ++e) pc.v[e] = ((sw >> e) & 1u) ? pc.v[e] * mask_slope : pc.v[e];
+        for (int e = 0; e < Piece<T>::E; ++e) pc.v[e] = ((sw_ >> e) & 1u) ? pc.v[e] * mask_slope : pc.v[e];
       }
       pc.store(y + i * E);
     } else {
@@ -381,31 +386,33 @@ __global__ void upscale2x_kernel(const T* __restrict__ x, T* __restrict__ y, int
 // block instead of 64-bit divisions per 16-byte piece (the flat kernel reached 3 TB/s).
 template <typename T>
 __global__ __launch_bounds__(256) void upscale2x_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int d, int h, int w,
-                                                             int c, float gain, const uint32_t* __restrict__ mask_bits,
-                                                             float mask_slope, int64_t nrows) {
+                                                             int c, int sd, int sh, int sw, float gain,
+                                                             const uint32_t* __restrict__ mask_bits, float mask_slope,
+                                                             int64_t nrows) {
   constexpr int E = Piece<T>::E;
   const int P = c / E, nw = (c + 31) >> 5;
-  const int per_row = 2 * w * P;
+  const int OD = d << sd, OH = h << sh, OW = w << sw;
+  const int per_row = OW * P;
   for (int64_t row = blockIdx.x; row < nrows; row += gridDim.x) {
-    const int oh = (int)(row % (2 * h));
-    const int64_t q = row / (2 * h);
-    const int od = (int)(q % (2 * d));
-    const int64_t nn = q / (2 * d);
-    const T* xrow = x + (((nn * d + (od >> 1)) * h + (oh >> 1)) * (int64_t)w) * c;
-    T* yrow = y + row * (int64_t)(2 * w) * c;
-    const uint32_t* mrow = mask_bits ? mask_bits + row * (int64_t)(2 * w) * nw : nullptr;
+    const int oh = (int)(row % OH);
+    const int64_t q = row / OH;
+    const int od = (int)(q % OD);
+    const int64_t nn = q / OD;
+    const T* xrow = x + (((nn * d + (od >> sd)) * h + (oh >> sh)) * (int64_t)w) * c;
+    T* yrow = y + row * (int64_t)OW * c;
+    const uint32_t* mrow = mask_bits ? mask_bits + row * (int64_t)OW * nw : nullptr;
     for (int i = threadIdx.x; i < per_row; i += 256) {
       const int ow = i / P, p = i - ow * P;
       Piece<T> pc;
-      pc.load(xrow + (int64_t)(ow >> 1) * c + p * E);
+      pc.load(xrow + (int64_t)(ow >> sw) * c + p * E);
       if (gain != 1.f) {
 #pragma unroll
         for (int e = 0; e < E; ++e) pc.v[e] *= gain;
       }
       if (mrow) {
-        const uint32_t sw = mrow[ow * nw + ((p * E) >> 5)] >> ((p * E) & 31);
+        const uint32_t sw_ = mrow[ow * nw + ((p * E) >> 5)] >> ((p * E) & 31);
 #pragma unroll
-        for (int e = 0; e < E; ++e) pc.v[e] = ((sw >> e) & 1u) ? pc.v[e] * mask_slope : pc.v[e];
+        for (int e = 0; e < E; ++e) pc.v[e] = ((sw_ >> e) & 1u) ? pc.v[e] * mask_slope : pc.v[e];
       }
       pc.store(yrow + (int64_t)i * E);
     }
@@ -414,10 +421,10 @@ __global__ __launch_bounds__(256) void upscale2x_rows_kernel(const T* __restrict
 
 template <typename T, bool VEC>
 __global__ void downscale2x_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int d, int h, int w, int c,
-                                   float gain) {
+                                   int sd, int sh, int sw, float gain) {
   constexpr int E = VEC ? Piece<T>::E : 1;
   const int P = c / E;
-  const int od = d / 2, oh = h / 2, ow = w / 2;
+  const int od = d >> sd, oh = h >> sh, ow = w >> sw;
   const int64_t total = (int64_t)n * od * oh * ow * P;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int p = (int)(i % P);
@@ -431,9 +438,10 @@ __global__ void downscale2x_kernel(const T* __restrict__ x, T* __restrict__ y, i
     for (int e = 0; e < Piece<T>::E; ++e) s[e] = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
+      const int kd = k >> 2, kh = (k >> 1) & 1, kw = k & 1;
+      if (kd > sd || kh > sh || kw > sw) continue;     // uniform: a factor-1 dimension has one tap
       const int64_t src =
-          ((((int64_t)nn * d + (2 * xd + (k >> 2))) * h + (2 * xh + ((k >> 1) & 1))) * w + (2 * xw + (k & 1))) * c +
-          (int64_t)p * E;
+          ((((int64_t)nn * d + ((xd << sd) + kd)) * h + ((xh << sh) + kh)) * w + ((xw << sw) + kw)) * c + (int64_t)p * E;
       if (VEC) {
         Piece<T> pc;
         pc.load(x + src);
@@ -794,29 +802,56 @@ extern "C" int sg_pixel_norm_act_bwd(const void* dy, const void* y, const float*
   return SG_OK;
 }
 
-extern "C" int sg_upscale2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
-                            float gain, sg_dtype dt, sg_stream_t st) {
-  return sg_upscale2x_masked(x, y, nullptr, 0.f, n, d, h, w, c, gain, dt, st);
-}
+static int sg_factor_shift(int32_t f) { return f == 1 ? 0 : (f == 2 ? 1 : -1); }
 
-extern "C" int sg_upscale2x_masked(const void* x, void* y, const void* mask_bits, float mask_slope, int32_t n, int32_t d,
-                                   int32_t h, int32_t w, int32_t c, float gain, sg_dtype dt, sg_stream_t st) {
-  if (!x || !y || n < 1 || d < 1 || h < 1 || w < 1 || c < 1) return SG_EINVAL;
+extern "C" int sg_upscale_nn(const void* x, void* y, const void* mask_bits, float mask_slope, int32_t n, int32_t d,
+                             int32_t h, int32_t w, int32_t c, int32_t fd, int32_t fh, int32_t fw, float gain,
+                             sg_dtype dt, sg_stream_t st) {
+  const int sd = sg_factor_shift(fd), sh = sg_factor_shift(fh), sw = sg_factor_shift(fw);
+  if (!x || !y || n < 1 || d < 1 || h < 1 || w < 1 || c < 1 || sd < 0 || sh < 0 || sw < 0) return SG_EINVAL;
   hipStream_t hs = sg_st(st);
   const int E = dt == SG_BF16 ? 8 : 4;
   const bool vec = (c % E == 0) && sg_aligned16(x) && sg_aligned16(y);
-  if (vec && 2 * w * (c / E) >= 128) {   // enough pieces per output row to fill a block
-    const int64_t nrows = (int64_t)n * 2 * d * 2 * h;
+  if (vec && (w << sw) * (c / E) >= 128) {   // enough pieces per output row to fill a block
+    const int64_t nrows = (int64_t)n * (d << sd) * (h << sh);
     const int rb = (int)(nrows < 16384 ? nrows : 16384);
-#define LR(T) hipLaunchKernelGGL((upscale2x_rows_kernel<T>), dim3(rb), dim3(256), 0, hs, (const T*)x, (T*)y, d, h, w, c, gain, (const uint32_t*)mask_bits, mask_slope, nrows)
+#define LR(T) hipLaunchKernelGGL((upscale2x_rows_kernel<T>), dim3(rb), dim3(256), 0, hs, (const T*)x, (T*)y, d, h, w, c, sd, sh, sw, gain, (const uint32_t*)mask_bits, mask_slope, nrows)
     SG_DISPATCH(dt, LR(bf16_t), LR(float));
 #undef LR
     SG_LAUNCH_CHECK();
     return SG_OK;
   }
-  const int64_t items = (int64_t)n * d * h * w * 8 * (vec ? c / E : c);
+  const int64_t items = (int64_t)n * (d << sd) * (h << sh) * (w << sw) * (vec ? c / E : c);
   const int blocks = grid_for(items, 256, 4096);
-#define L(T, V) hipLaunchKernelGGL((upscale2x_kernel<T, V>), dim3(blocks), dim3(256), 0, hs, (const T*)x, (T*)y, n, d, h, w, c, gain, (const uint32_t*)mask_bits, mask_slope)
+#define L(T, V) hipLaunchKernelGGL((upscale2x_kernel<T, V>), dim3(blocks), dim3(256), 0, hs, (const T*)x, (T*)y, n, d, h, w, c, sd, sh, sw, gain, (const uint32_t*)mask_bits, mask_slope)
+  if (vec) SG_DISPATCH(dt, L(bf16_t, true), L(float, true));
+  else SG_DISPATCH(dt, L(bf16_t, false), L(float, false));
+#undef L
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_upscale2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
+                            float gain, sg_dtype dt, sg_stream_t st) {
+  return sg_upscale_nn(x, y, nullptr, 0.f, n, d, h, w, c, 2, 2, 2, gain, dt, st);
+}
+
+extern "C" int sg_upscale2x_masked(const void* x, void* y, const void* mask_bits, float mask_slope, int32_t n, int32_t d,
+                                   int32_t h, int32_t w, int32_t c, float gain, sg_dtype dt, sg_stream_t st) {
+  return sg_upscale_nn(x, y, mask_bits, mask_slope, n, d, h, w, c, 2, 2, 2, gain, dt, st);
+}
+
+extern "C" int sg_downscale_sum(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
+                                int32_t fd, int32_t fh, int32_t fw, float gain, sg_dtype dt, sg_stream_t st) {
+  const int sd = sg_factor_shift(fd), sh = sg_factor_shift(fh), sw = sg_factor_shift(fw);
+  if (!x || !y || n < 1 || d < fd || h < fh || w < fw || c < 1 || sd < 0 || sh < 0 || sw < 0) return SG_EINVAL;
+  if ((sd && (d & 1)) || (sh && (h & 1)) || (sw && (w & 1))) return SG_EINVAL;
+  hipStream_t hs = sg_st(st);
+  const int E = dt == SG_BF16 ? 8 : 4;
+  const bool vec = (c % E == 0) && sg_aligned16(x) && sg_aligned16(y);
+  const int64_t items = (int64_t)n * (d >> sd) * (h >> sh) * (w >> sw) * (vec ? c / E : c);
+  const int blocks = grid_for(items, 256, 4096);
+#define L(T, V) hipLaunchKernelGGL((downscale2x_kernel<T, V>), dim3(blocks), dim3(256), 0, hs, (const T*)x, (T*)y, n, d, h, w, c, sd, sh, sw, gain)
   if (vec) SG_DISPATCH(dt, L(bf16_t, true), L(float, true));
   else SG_DISPATCH(dt, L(bf16_t, false), L(float, false));
 #undef L
@@ -826,18 +861,7 @@ extern "C" int sg_upscale2x_masked(const void* x, void* y, const void* mask_bits
 
 extern "C" int sg_downscale2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
                               float gain, sg_dtype dt, sg_stream_t st) {
-  if (!x || !y || n < 1 || d < 2 || h < 2 || w < 2 || c < 1 || ((d | h | w) & 1)) return SG_EINVAL;
-  hipStream_t hs = sg_st(st);
-  const int E = dt == SG_BF16 ? 8 : 4;
-  const bool vec = (c % E == 0) && sg_aligned16(x) && sg_aligned16(y);
-  const int64_t items = (int64_t)n * (d / 2) * (h / 2) * (w / 2) * (vec ? c / E : c);
-  const int blocks = grid_for(items, 256, 4096);
-#define L(T, V) hipLaunchKernelGGL((downscale2x_kernel<T, V>), dim3(blocks), dim3(256), 0, hs, (const T*)x, (T*)y, n, d, h, w, c, gain)
-  if (vec) SG_DISPATCH(dt, L(bf16_t, true), L(float, true));
-  else SG_DISPATCH(dt, L(bf16_t, false), L(float, false));
-#undef L
-  SG_LAUNCH_CHECK();
-  return SG_OK;
+  return sg_downscale_sum(x, y, n, d, h, w, c, 2, 2, 2, gain, dt, st);
 }
 
 extern "C" int sg_axpby(const void* a, const void* b, void* out, float wa, float wb, int64_t numel, sg_dtype dt,

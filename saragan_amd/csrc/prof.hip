@@ -10,6 +10,9 @@ namespace {
 struct Rec { int kind; sg_conv_shape shape; int dtype; hipEvent_t e0, e1; bool ok; const char* name; };
 std::mutex g_mu;
 bool g_on = false;
+bool g_filter = false;
+int g_fkind = 0;
+sg_conv_shape g_fshape;
 std::vector<Rec> g_recs;
 const char* kVersion = "saragan_hip 0.2 (gfx950)";
 }  // namespace
@@ -67,6 +70,7 @@ extern "C" int sg_config_reload(void) {
 
 void sg_prof_begin(int kind, const sg_conv_shape* s, sg_dtype dt, hipStream_t st, int* slot) {
   std::lock_guard<std::mutex> lk(g_mu);
+  if (g_filter && (kind != g_fkind || memcmp(s, &g_fshape, sizeof(sg_conv_shape)) != 0)) { *slot = -1; return; }
   Rec r; r.kind = kind; r.shape = *s; r.dtype = (int)dt; r.ok = false; r.name = "";
   if (hipEventCreate(&r.e0) != hipSuccess) { *slot = -1; return; }
   if (hipEventCreate(&r.e1) != hipSuccess) { (void)hipEventDestroy(r.e0); *slot = -1; return; }
@@ -111,6 +115,13 @@ extern "C" int sg_prof_enable(int on) {
     for (auto& r : g_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     g_recs.clear();
   }
+  return SG_OK;
+}
+
+extern "C" int sg_prof_set_filter(int kind, const sg_conv_shape* s) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  g_filter = s != nullptr;
+  if (s) { g_fkind = kind; g_fshape = *s; }
   return SG_OK;
 }
 

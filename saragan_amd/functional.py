@@ -557,21 +557,23 @@ class _PnActBwd(torch.autograd.Function):
 
 
 class _Up(torch.autograd.Function):
-    """y = gain * nearest_x2(x) (upscale3d / avg_unpool3d, networks/ops.py:250-262,276-289), optionally times the
-    LeakyReLU-backward mask given by `mask_bits`, the sign words of a tensor shaped like y (the gradient of
-    downscale3d(leaky_relu(.)) in one pass)."""
+    """y = gain * nearest-neighbour up-sampling of x by `factors` per dimension ((2,2,2): upscale3d / avg_unpool3d,
+    networks/ops.py:250-262,276-289; (1,2,2): upscale2d of the 2-D tree), optionally times the LeakyReLU-backward mask
+    given by `mask_bits`, the sign words of a tensor shaped like y (the gradient of downscale3d(leaky_relu(.)) in one
+    pass)."""
 
     @staticmethod
-    def forward(ctx, x, gain, mask_bits=None, mask_slope=0.0):
+    def forward(ctx, x, gain, mask_bits=None, mask_slope=0.0, factors=(2, 2, 2)):
         lib = _lib.load()
         _req_cuda(x, mask_bits)
         x = ndhwc(x)
         n, c, d, h, w = _dims(x)
-        y = _empty_like_shape(x, c, (2 * d, 2 * h, 2 * w))
-        _check_signs(mask_bits, 8 * n * d * h * w, c)
-        check(lib.sg_upscale2x_masked(_ptr(x), _ptr(y), _ptr(mask_bits), float(mask_slope), n, d, h, w, c, float(gain),
-                                      _dt(x), _stream()), 'sg_upscale2x_masked')
-        ctx.gain, ctx.mask_slope = gain, mask_slope
+        fd, fh, fw = factors
+        y = _empty_like_shape(x, c, (fd * d, fh * h, fw * w))
+        _check_signs(mask_bits, fd * fh * fw * n * d * h * w, c)
+        check(lib.sg_upscale_nn(_ptr(x), _ptr(y), _ptr(mask_bits), float(mask_slope), n, d, h, w, c, fd, fh, fw,
+                                float(gain), _dt(x), _stream()), 'sg_upscale_nn')
+        ctx.gain, ctx.mask_slope, ctx.factors = gain, mask_slope, tuple(factors)
         ctx.save_for_backward(mask_bits)
         return y
 
@@ -580,28 +582,31 @@ class _Up(torch.autograd.Function):
         (mask_bits,) = ctx.saved_tensors
         if mask_bits is not None:
             gy, _ = _BiasActBwd.apply(gy, mask_bits, ctx.mask_slope, False)
-        return _Down.apply(gy, ctx.gain), None, None, None
+        return _Down.apply(gy, ctx.gain, None, ctx.factors), None, None, None, None
 
 
 class _Down(torch.autograd.Function):
-    """y = gain * sum of each 2x2x2 block (gain 1/8: downscale3d, networks/ops.py:265-273,292-305)."""
+    """y = gain * sum of each block of `factors` voxels (gain 1/8 with (2,2,2): downscale3d, networks/ops.py:265-273,
+    292-305; gain 1/4 with (1,2,2): downscale2d)."""
 
     @staticmethod
-    def forward(ctx, x, gain, in_info=None):
+    def forward(ctx, x, gain, in_info=None, factors=(2, 2, 2)):
         lib = _lib.load()
         _req_cuda(x)
         x = ndhwc(x)
         n, c, d, h, w = _dims(x)
-        y = _empty_like_shape(x, c, (d // 2, h // 2, w // 2))
-        check(lib.sg_downscale2x(_ptr(x), _ptr(y), n, d, h, w, c, float(gain), _dt(x), _stream()), 'sg_downscale2x')
-        ctx.gain, ctx.in_info = gain, in_info
+        fd, fh, fw = factors
+        y = _empty_like_shape(x, c, (d // fd, h // fh, w // fw))
+        check(lib.sg_downscale_sum(_ptr(x), _ptr(y), n, d, h, w, c, fd, fh, fw, float(gain), _dt(x), _stream()),
+              'sg_downscale_sum')
+        ctx.gain, ctx.in_info, ctx.factors = gain, in_info, tuple(factors)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         if _masked_in(ctx.in_info):
-            return _Up.apply(gy, ctx.gain, ctx.in_info.bits, ctx.in_info.slope), None, None
-        return _Up.apply(gy, ctx.gain), None, None
+            return _Up.apply(gy, ctx.gain, ctx.in_info.bits, ctx.in_info.slope, ctx.factors), None, None, None
+        return _Up.apply(gy, ctx.gain, None, 0.0, ctx.factors), None, None, None
 
 
 class _Axpby(torch.autograd.Function):
@@ -691,12 +696,12 @@ def pixel_norm(x, eps=1e-8):
     return _PixelNorm.apply(x, eps)
 
 
-def upscale2x(x, gain=1.0):
-    return _Up.apply(x, gain)
+def upscale2x(x, gain=1.0, factors=(2, 2, 2)):
+    return _Up.apply(x, gain, None, 0.0, factors)
 
 
-def downscale2x(x, gain=0.125, in_info=None):
-    return _Down.apply(x, gain, in_info)
+def downscale2x(x, gain=0.125, in_info=None, factors=(2, 2, 2)):
+    return _Down.apply(x, gain, in_info, factors)
 
 
 def lerp(a, b, wa, wb):

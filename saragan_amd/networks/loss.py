@@ -188,10 +188,14 @@ def forward_simultaneous(generator, discriminator, real_image_input, latent_dim,
         disc_real = discriminator(real_image_input, alpha, phase, is_reuse=True, **net).float()
     gamma = rng.gamma(real_image_input.shape[0], real_image_input.device).to(real_image_input.dtype)
     interpolates = gamma * real_image_input + (1 - gamma) * gen_sample_noisy.detach()
+    # quirk Q1 belongs to the 3-D tree's 5-D tensors; the 2-D tree reduces its 4-D gradient over every non-batch axis
+    keep_w = not getattr(discriminator, 'sg_gp_full_reduction', False)
     slopes = torch.sqrt(_gradient_slopes_sq(discriminator, interpolates, alpha, phase, latent_dim, activation,
-                                            kernel_spec, filter_spec, leakiness, keep_w=True))
+                                            kernel_spec, filter_spec, leakiness, keep_w=keep_w))
     if loss_fn == 'wgan':
         gradient_penalty = (slopes - 1) ** 2
+        if not keep_w:
+            gradient_penalty = gradient_penalty.reshape(-1, 1)     # per sample, next to D's [N,1] logits
         gp_loss = gp_weight * gradient_penalty
         disc_loss = disc_fake_d - disc_real
         drift_loss = 1e-3 * disc_real ** 2

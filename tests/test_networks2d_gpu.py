@@ -1,0 +1,102 @@
+"""The 2-D pgan path (BASELINE config 5; SURFGAN_2D/networks/pgan/*.py with the legacy num_phases / base_dim / size
+signature, SURFGAN_2D/networks/ops.py): images are D == 1 volumes on the same kernels.  The oracle is the 3-D
+restatement on [N,C,1,H,W] with (1,3,3) kernels (oracle.specs_2d) and the 2-D tree's full-reduction gradient penalty."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pgan_oracle as O
+
+pytestmark = pytest.mark.gpu
+BASE = (3, 1, 4, 4)
+
+
+def _to_oracle_names(params2d):
+    """HWIO conv weights of the 2-D variables -> DHWIO with kD = 1."""
+    return {k: (v.unsqueeze(0) if v.dim() == 4 else v) for k, v in params2d.items()}
+
+
+def test_ops_2d_match_oracle():
+    from saragan_amd import functional as F
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(1)
+    for dtype in (torch.float32, torch.bfloat16):
+        x = torch.randn((2, 16, 1, 12, 20), generator=g).to(dtype)
+        xd = x.to(dev).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
+        up = F.upscale2x(xd, 1.0, factors=(1, 2, 2))
+        ref = x.double().repeat_interleave(2, 3).repeat_interleave(2, 4)
+        np.testing.assert_array_equal(up.double().cpu().numpy(), ref.numpy())
+        (gx,) = torch.autograd.grad(up, xd, torch.ones_like(up))
+        assert float(gx.float().min()) == float(gx.float().max()) == 4.0       # gradient = 4 * avg_pool2d
+        dn = F.downscale2x(xd, 0.25, None, factors=(1, 2, 2))
+        refd = torch.nn.functional.avg_pool2d(x.double().squeeze(2), 2).unsqueeze(2)
+        tol = 1e-6 if dtype == torch.float32 else 1e-2
+        np.testing.assert_allclose(dn.double().cpu().numpy(), refd.numpy(), rtol=tol, atol=tol)
+        hp = F.downscale2x(xd, 0.5, None, factors=(1, 2, 1))                    # H-only pooling
+        refh = 0.5 * (x.double()[:, :, :, 0::2] + x.double()[:, :, :, 1::2])
+        np.testing.assert_allclose(hp.double().cpu().numpy(), refh.numpy(), rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize('alpha', [0.0, 0.3])
+def test_pgan_2d_step_matches_oracle(alpha):
+    """One optimisation step of the 2-D pgan (4 phases -> 32x32 RGB, 'xxs' widths 16,8,4,2) through
+    optimize_step with the spec-API adapters, fp32 HIP vs the fp64 oracle on D == 1 volumes."""
+    from tests.cfgutil import assert_adam_close, build_product, pick, rel_l2
+    from saragan_amd.networks2d.ops import num_filters
+    from saragan_amd.networks2d.pgan.variables import legacy_spec, variable_shapes
+    nph, size, phase, n, latent = 4, 'xxs', 4, 4, 32
+    base_dim = num_filters(1, nph, size=size)
+    spec = legacy_spec(nph, base_dim, size)
+    ks, fs = O.specs_2d(nph, size)
+    plan = variable_shapes(phase, BASE, latent, None, spec)
+    want = O.variable_shapes(phase, BASE, latent, ks, fs)
+    assert list(plan.keys()) == list(want.keys())
+    for k_, shp in plan.items():
+        assert tuple(want[k_]) == ((1, *shp) if len(shp) == 4 else tuple(shp)), k_
+    p0 = O.init_params(phase, BASE, latent, ks, fs, seed=9, bias_std=0.05)
+    img = (3, 1, 32, 32)
+    rnd = O.draw_randomness(n, latent, img, 10)
+    real = torch.randn((n, *img), dtype=torch.float64, generator=torch.Generator().manual_seed(11))
+    cfg = dict(phase=phase, base_shape=BASE, latent_dim=latent, kernel_spec=ks, filter_spec=fs, activation='leaky_relu',
+               leakiness=0.2, loss_fn='wgan', gp_weight=10.0, noise_stddev=0.01, gp_full=True)
+    freeze = list(O.variable_shapes(phase - 1, BASE, latent, ks, fs).keys()) if alpha > 0 else None
+    p0_2d = {k_: (v.squeeze(0) if v.dim() == 5 else v) for k_, v in p0.items()}
+    case = dict(p0=p0_2d, rnd=rnd, real=real, alpha=alpha, freeze=freeze, phase=phase, loss_fn='wgan', n=n, latent=latent,
+                base=BASE, img=img, cfg=dict(cfg, kernel_spec=None, filter_spec=spec))
+    store, tup, ph, ema, sess, _ = build_product(case, torch.float32, arch='networks2d.pgan.spec_api')
+    tg, td, gg_h, gv, dg_h, dv, _, _ = pick(tup, freeze is not None)
+    _, _, gl, dl, gs, gg, dg = sess.run([tg, td, tup[2], tup[3], tup[5], gg_h, dg_h], feed_dict={ph: real.float()})
+    p = {k_: v.clone() for k_, v in p0.items()}
+    ref = O.step_simultaneous(p, O.TFAdam(0.0, 0.9), O.TFAdam(0.0, 0.9), None, rnd, real, alpha, cfg, 1e-3, 1e-3, freeze=freeze)
+    np.testing.assert_allclose(float(gl), float(ref['gen_loss']), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(float(dl), float(ref['disc_loss']), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gs.double().cpu().numpy(), ref['gen_sample'].numpy(), rtol=1e-4, atol=1e-5)
+    for hv, grads, refs in ((gv, gg, ref['g_grads']), (dv, dg, ref['d_grads'])):
+        assert [v.key for v in hv] == list(refs.keys())
+        for v, g_ in zip(hv, grads):
+            assert rel_l2(g_, refs[v.key].reshape(g_.shape)) <= 1e-3, v.key
+    for k_, v in store.vars.items():
+        assert_adam_close(v, p[k_].reshape(v.shape), 1e-3, 1e-4, k_)
+
+
+def test_pgan_2d_legacy_signature_1024():
+    """BASELINE config 5 at its own size: the 1024^2 phase (9 phases from 4^2) of the 'xs' 2-D pgan in fp32 through
+    the legacy signature, batch 2: shapes, finiteness, parameter count of the plan."""
+    from saragan_amd.networks2d.ops import num_filters
+    from saragan_amd.networks2d.pgan.discriminator import discriminator
+    from saragan_amd.networks2d.pgan.generator import generator
+    from saragan_amd.networks2d.pgan.variables import legacy_spec, variable_shapes
+    from saragan_amd.varstore import VariableStore, set_compute_dtype, use_store
+    set_compute_dtype(torch.float32)
+    nph, size, latent = 9, 'xs', 512
+    base_dim = num_filters(1, nph, size=size)
+    store = VariableStore('cuda', seed=3)
+    with use_store(store), torch.no_grad():
+        z = torch.randn(2, latent, device='cuda')
+        img = generator(z, 0.5, 9, nph, base_dim, [3, 4, 4], 'leaky_relu', param=0.2, size=size)
+        assert tuple(img.shape) == (2, 3, 1024, 1024) and torch.isfinite(img).all()
+        out = discriminator(img, 0.5, 9, nph, base_dim, latent, 'leaky_relu', param=0.2, size=size)
+        assert tuple(out.shape) == (2, 1) and torch.isfinite(out).all()
+    plan = variable_shapes(9, (3, 1, 4, 4), latent, None, legacy_spec(nph, base_dim, size))
+    assert {k_: tuple(v.shape) for k_, v in store.vars.items()} == {k_: tuple(v) for k_, v in plan.items()}
+    assert plan['generator/generator_block_9/conv_2/weight'] == (3, 3, 4, 4)      # 4 filters at 1024^2 ('xs')

@@ -176,7 +176,7 @@ def test_step_bf16_every_gradient_weight_and_ema(golden_dir, name):
     # These nets are tiny (8-16 channels): bf16 rounding of an activation (0.4 %) flips ~0.5 % of the LeakyReLU masks
     # against the fp64 oracle, so single tensors carry 5-20 % error.  Criteria: every weight gradient within 30 % in
     # relative L2 and cosine >= 0.95 with the oracle's; the whole network's gradient (all tensors concatenated) cosine
-    # >= 0.98 and norm within 5 %.
+    # >= 0.98 and norm within 10 %.
     worst, bad = {}, []
     for net, hv, grads, refs in (('G', gv, gg, fx['gg']), ('D', dv, dg, fx['dg'])):
         assert [v.key for v in hv] == list(refs.keys())
@@ -184,10 +184,13 @@ def test_step_bf16_every_gradient_weight_and_ema(golden_dir, name):
         b = torch.cat([refs[v.key].reshape(-1) for v in hv])
         cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
         worst[f'{net}:all'] = dict(cos=cos, norm_ratio=float(a.norm() / b.norm()))
-        if cos < 0.98 or abs(float(a.norm() / b.norm()) - 1) > 0.05:
+        if cos < 0.98 or abs(float(a.norm() / b.norm()) - 1) > 0.10:
             bad.append((net, worst[f'{net}:all']))
         for v, g in zip(hv, grads):
             r = refs[v.key]
+            if float(r.norm()) == 0.0:       # e.g. to_rgb_{p-1} at alpha = 0: exactly zero in both
+                assert float(g.double().norm()) == 0.0, v.key
+                continue
             e = rel_l2(g, r)
             c = float(torch.dot(g.double().cpu().reshape(-1), r.reshape(-1)) / max(1e-30, float(g.double().norm() * r.norm())))
             worst[v.key] = dict(rel_l2=e, cos=c)

@@ -81,6 +81,12 @@ typedef struct {
   int32_t out_scale;
   int32_t out_off[3];
   int32_t tap_off[3];
+  /* pool = 1: y is NOT the full-resolution output but its mean over 2 (D) x 1 (H) x 2 (W) blocks, [n, d/2, h, w/2, cout]
+   * -- the first stage of downscale3d(act(conv3d(x) + b)) (pgan/discriminator.py:39-44), finished by
+   * sg_downscale_sum(1,2,1, gain 1/2).  sign_out still receives the FULL-resolution sign words (all the backward
+   * needs).  Only the sliding-halo kernel implements it (bf16, 3x3x3, cin <= 32, w % 32 == 0, cout % 32 == 0, even
+   * d and h, no pixel-norm / mask): anything else returns SG_EUNSUPPORTED and the caller runs conv + downscale. */
+  int32_t pool;
 } sg_conv_epilogue;
 
 /* Sign words of an NDHWC tensor t[nvox][c]: uint32 words[nvox][ceil(c/32)], bit j of word (v, k) = (t[v][32k+j] < 0),

@@ -23,7 +23,7 @@ class ConvEpilogue(C.Structure):
                 ('bias', C.c_void_p), ('act', C.c_int32), ('slope', C.c_float), ('pixel_norm', C.c_int32),
                 ('eps', C.c_float), ('pn_scale', C.c_void_p), ('mask_bits', C.c_void_p), ('mask_slope', C.c_float),
                 ('sign_out', C.c_void_p), ('out_scale', C.c_int32), ('out_off', C.c_int32 * 3),
-                ('tap_off', C.c_int32 * 3)]
+                ('tap_off', C.c_int32 * 3), ('pool', C.c_int32)]
 
     def __init__(self, *args, **kw):
         super().__init__(C.sizeof(type(self)), *args, **kw)

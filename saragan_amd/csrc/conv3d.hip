@@ -116,6 +116,7 @@ struct ConvFwdArgs {
   int wres;             // v4: all weight slabs resident in LDS
   int lean;             // v4: input below 2 GiB and no fused up-sampling: buffer addressing for the halo
   int tap_d, tap_h, tap_w;   // added to the tap index when addressing the halo (sub-pixel classes)
+  int pool;                  // 1: y is the D x W mean-pooled output [n, D/2, H, W/2, cout] (sliding-halo kernel only)
   int os, oa, ob, oc;        // output scatter: os == 2 writes voxel (2d+oa, 2h+ob, 2w+oc) of a [n,2D,2H,2W,cout] tensor
   unsigned long long* dbg;  // diagnostic time stamps (NULL in production)
   int dbg_flags;            // diagnostic ablations (0 in production): 1 = no re-staging, 2 = no epilogue
@@ -1398,6 +1399,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
             if (ok) __builtin_amdgcn_raw_buffer_store_b32(sw, rs_, hh == 0 ? svo[mt] : DEAD, ssoff, 0);
           }
           if (use_mask) sg_apply_sign_word(acc[mt], mb[mt], hh, a.mask_slope);
+          if (a.pool) continue;   // uniform: the pooled store below replaces the full-resolution one
           if (wide_store) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {   // 16 contiguous bytes per lane (see sg_store_tile_row_bf16)
@@ -1430,6 +1432,33 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
           }
         }
       }
+      if (closes && a.pool) {
+        // fused downscale3d, first stage (pgan/discriminator.py:44 after conv_2 + bias + LeakyReLU): the tile's two D
+        // planes are this wave's two M tiles (a lane-local add) and W neighbours are adjacent lanes (one DPP quad
+        // permutation), so the mean over the 2 x 1 x 2 block costs 32 VALU ops and the full-resolution activation --
+        // the largest tensor of the network, needed by nobody else: the backward only wants its sign words -- is never
+        // written.  Output [n, D/2, H, W/2, cout]; the H pairs (two different waves) are pooled by sg_downscale_sum(1,2,1).
+        const __amdgpu_buffer_rsrc_t ryp = rsrc_of(a.y, ysb / 4, o.n0);
+        const uint32_t psoff = (uint32_t)((((o.d0 >> 1) * g.H + o.h0) * (g.W >> 1) + (o.w0 >> 1)) * a.cout * ES);
+        const uint32_t pvo = (r & 1) ? DEAD : (uint32_t)(((wave * (g.W >> 1) + (r >> 1)) * a.cout + nt0 * 32) * ES);
+        float sp[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float t = acc[0][i] + acc[1][i];
+          const float u = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));
+          sp[i] = (t + u) * 0.25f;     // quad_perm [1,0,3,2]: lane r <-> r ^ 1
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const uint32_t a0 = sg_pack_bf16(sp[8 * j + 0], sp[8 * j + 1]), a1 = sg_pack_bf16(sp[8 * j + 2], sp[8 * j + 3]);
+          const uint32_t b0 = sg_pack_bf16(sp[8 * j + 4], sp[8 * j + 5]), b1 = sg_pack_bf16(sp[8 * j + 6], sp[8 * j + 7]);
+          const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+          u32x4 out;
+          out[0] = s0[0]; out[1] = s1[0]; out[2] = s0[1]; out[3] = s1[1];
+          if (row_ok) __builtin_amdgcn_raw_buffer_store_b128(out, ryp, pvo + (uint32_t)((16 * j + 8 * hh) * 2), psoff, 0);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (restage) store_planes(on, 2, stg);
     }
@@ -1443,6 +1472,7 @@ static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
   *used = false;
   if (s->upsample_in || s->kd != 3 || s->kh != 3 || s->kw != 3) return SG_OK;
   if (s->d < 4 || (s->w % 32) != 0) return SG_OK;   // needs >= 2 steps per column; full 32-wide rows
+  if (a.pool && (sizeof(T) != 2 || (s->d & 1) || (s->h & 1) || s->cout % 32 != 0 || a.pixel_norm || a.mask_bits)) return SG_OK;
   a.g = sg_make_geom(s, 256, /*prefer_w32=*/true, /*td=*/2, /*th=*/4);
   const sg_tile_geom& g = a.g;
   if (g.TN != 1 || g.TD != 2 || g.TH != 4 || g.TW != 32 || g.HD != 4 || g.HH != 6 || g.HW != 34) return SG_OK;
@@ -2094,6 +2124,8 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
   a.pixel_norm = ep ? ep->pixel_norm : 0;
   a.eps = ep ? ep->eps : 0.f;
   a.tap_d = ep ? ep->tap_off[0] : 0; a.tap_h = ep ? ep->tap_off[1] : 0; a.tap_w = ep ? ep->tap_off[2] : 0;
+  a.pool = ep ? ep->pool : 0;
+  if (a.pool != 0 && a.pool != 1) return SG_EINVAL;
   a.os = (ep && ep->out_scale == 2) ? 2 : 1;
   a.oa = ep ? ep->out_off[0] : 0; a.ob = ep ? ep->out_off[1] : 0; a.oc = ep ? ep->out_off[2] : 0;
   const bool subpixel = a.os == 2 || a.tap_d || a.tap_h || a.tap_w || s->kd == 2;
@@ -2122,7 +2154,9 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     prof.done(rc);
     return rc;
   }
-  if (!sg_cfg().fwd_no_pw) {   // streaming kernels for the 1x1x1 layers with <= 4 channels on one side
+  if (a.pool && (subpixel || dt != SG_BF16 || sg_cfg().fwd_v1 || sg_cfg().fwd_no_v3 || sg_cfg().fwd_no_v3s ||
+                 (s->cin * 2) % 16 != 0 || a.pixel_norm)) return SG_EUNSUPPORTED;
+  if (!sg_cfg().fwd_no_pw && !a.pool) {   // streaming kernels for the 1x1x1 layers with <= 4 channels on one side
     bool used = false;
     rc = dt == SG_BF16 ? launch_pw_fwd<bf16_t>(a, s, hs, &used) : launch_pw_fwd<float>(a, s, hs, &used);
     if (rc != SG_OK || used) { prof.done(rc); return rc; }
@@ -2137,6 +2171,7 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
       else if (a.nchunk == 1) rc = launch_fwd3s<bf16_t, 1>(a, s, hs, &used);
       if (rc != SG_OK || used) { prof.done(rc); return rc; }
     }
+    if (a.pool) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }   // only the sliding-halo kernel pools
     if (dt == SG_BF16) {
       if (k333 && a.nchunk == 2) rc = launch_fwd3r<bf16_t, 2, 2, 3, 3, 3>(a, s, hs, &used);
       else if (k333 && a.nchunk == 1) rc = launch_fwd3r<bf16_t, 2, 1, 3, 3, 3>(a, s, hs, &used);

@@ -186,9 +186,10 @@ def _raw_upconv_subpixel(x, w, coef, bias, act, slope, pixel_norm, eps, want_sca
 
 
 def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel_norm=False, eps=1e-8,
-             want_scale=False, mask_bits=None, mask_slope=0.0, want_signs=False):
+             want_scale=False, mask_bits=None, mask_slope=0.0, want_signs=False, pool=False):
     """y = epilogue(conv3d(x, coef*w)) with w in DHWIO; `flip` selects the data-gradient weights.
-    Returns (y, pixel-norm scale or None, sign words of y or None)."""
+    Returns (y, pixel-norm scale or None, sign words of y or None).  pool: y is the 2 x 1 x 2 (D x H x W) block mean of
+    the output, [n,cout,d/2,h,w/2] (sg_conv_epilogue.pool); returns None if no kernel of the build fuses it here."""
     lib = _lib.load()
     _req_cuda(x, w, bias)
     x = ndhwc(x)
@@ -211,7 +212,9 @@ def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel
     dt = _dt(x)
     st = _stream()
     wp = _packed(w, coef, flip, shp, dt, lib, st)
-    y = _empty_like_shape(x, cout, (d, h, wd))
+    if pool and ((d | wd) & 1 or x.dim() != 5):
+        return None
+    y = _empty_like_shape(x, cout, (d // 2, h, wd // 2) if pool else (d, h, wd))
     _check_signs(mask_bits, n * d * h * wd, cout)
     signs = _empty_signs(x.device, n, d, h, wd, cout) if want_signs else None
     scale = None
@@ -220,7 +223,11 @@ def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel
     b32 = bias.detach().contiguous().float() if bias is not None else None
     ep = ConvEpilogue(_ptr(b32), 1 if act else 0, float(slope), 1 if pixel_norm else 0, float(eps), _ptr(scale),
                       _ptr(mask_bits), float(mask_slope), _ptr(signs))
-    check(lib.sg_conv3d_fwd(_ptr(x), _ptr(wp), _ptr(y), C.byref(shp), C.byref(ep), dt, st), 'sg_conv3d_fwd')
+    ep.pool = 1 if pool else 0
+    rc = lib.sg_conv3d_fwd(_ptr(x), _ptr(wp), _ptr(y), C.byref(shp), C.byref(ep), dt, st)
+    if pool and rc == _lib.SG_EUNSUPPORTED:
+        return None
+    check(rc, 'sg_conv3d_fwd')
     return y, scale, signs
 
 
@@ -440,6 +447,60 @@ class _ConvBiasAct(torch.autograd.Function):
         elif db_from_wgrad:
             _, gb = raw_bias_act_bwd(g, None, 0.0, want_dx=False, want_db=True)
         return gx, gw, (gb if want_db else None), None, None, None, None, None, None, None, None
+
+
+_NO_POOL_FUSION = bool(int(os.environ.get('SARAGAN_NO_POOL_FUSION', '0')))   # diagnostic: conv and downscale3d apart
+
+
+class _ConvBiasActPool(torch.autograd.Function):
+    """downscale3d(leaky_relu(conv3d(x) + b)) (one discriminator block's tail, pgan/discriminator.py:33-44) without the
+    full-resolution activation: the convolution's epilogue writes the 2 x 1 x 2 block means (sg_conv_epilogue.pool) and
+    the sign words, sg_downscale_sum(1,2,1) pools the H pairs.  Backward: the pooled gradient goes up through ONE
+    masked nearest-x2 (gain 1/8, this layer's sign words), then the usual data / weight gradients."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, coef, slope, in_info=None):
+        res = raw_conv(x, w, coef, False, False, bias=b, act=True, slope=slope, want_signs=True, pool=True)
+        if res is None:
+            raise _lib.SgError('pool fusion not available for this layer')
+        ydw, _, signs = res
+        y = _Down.apply(ydw, 0.5, None, (1, 2, 1))
+        ctx.save_for_backward(x, w, signs)
+        ctx.cfg = (coef, slope)
+        ctx.has_b = b is not None
+        ctx.b_ptr = b.data_ptr() if b is not None else 0
+        ctx.in_info = in_info
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, signs = ctx.saved_tensors
+        coef, slope = ctx.cfg
+        g = _Up.apply(gy, 0.125, signs, slope, (2, 2, 2))      # d(downscale3d) * LeakyReLU mask, full resolution
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            if _masked_in(ctx.in_info):
+                gx = _Conv.apply(g, w, coef, True, False, None, ctx.in_info.bits, ctx.in_info.slope)
+            else:
+                gx = _Conv.apply(g, w, coef, True, False)
+        want_db = ctx.has_b and _wants(ctx, 2, ctx.b_ptr)
+        if _wants(ctx, 1, w.data_ptr()):
+            gw, gb = _Wgrad.apply(x, g, tuple(w.shape[:3]), coef, False, want_db)
+            gw = gw.reshape(w.shape)
+        elif want_db:
+            _, gb = raw_bias_act_bwd(g, None, 0.0, want_dx=False, want_db=True)
+        return gx, gw, (gb if want_db else None), None, None, None
+
+
+def pool_fusion_available(x, w, bias, slope):
+    """Whether conv3d + bias + LeakyReLU + downscale3d of this layer runs as _ConvBiasActPool (bf16, 3x3x3, <= 32 input
+    channels, 32-wide rows, whole 32-channel output tiles: sg_conv_epilogue.pool).  Decided from the shape; the library
+    has the last word (SG_EUNSUPPORTED)."""
+    if _NO_POOL_FUSION or x.dim() != 5 or x.dtype != torch.bfloat16 or w.dim() != 5:
+        return False
+    n, cin, d, h, wd = x.shape
+    return (tuple(w.shape[:3]) == (3, 3, 3) and cin <= 32 and cin % 8 == 0 and w.shape[-1] % 32 == 0 and wd % 32 == 0 and
+            d >= 4 and d % 2 == 0 and h % 2 == 0 and n * d * h * wd >= (1 << 20))
 
 
 class _BiasActBwd(torch.autograd.Function):
@@ -686,6 +747,10 @@ def conv3d(x, w, coef=1.0, bias=None, act=False, slope=0.2, pixel_norm=False, ep
     y = _Conv.apply(x, w, coef, False, upsample_in, in_info)
     y = _BiasAct.apply(y, bias, act, slope)
     return _PixelNorm.apply(y, eps) if pixel_norm else y
+
+
+def conv3d_act_pool(x, w, coef, bias, slope, in_info=None):
+    return _ConvBiasActPool.apply(x, w, bias, coef, slope, in_info)
 
 
 def bias_act(x, bias, act=False, slope=0.2):

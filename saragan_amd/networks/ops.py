@@ -288,6 +288,14 @@ def avg_pool3d(x, factor=2, gain=1):
         return x if gain == 1 else F.lerp(x, None, float(gain), 0.0)
     if factor != 2:
         raise NotImplementedError('only factor 2 is used by the pgan path')
+    if (gain == 1 and isinstance(x, _LazyConv) and x._v is None and x.act and not x.pn and not x.ups and
+            F.pool_fusion_available(x.x, x.w, x.bias, x.slope)):
+        # conv3d -> apply_bias -> act -> downscale3d (pgan/discriminator.py:33-44) as ONE fused op: the full-resolution
+        # activation is never written (functional._ConvBiasActPool)
+        try:
+            return F.conv3d_act_pool(x.x, x.w, x.coef, x.bias, x.slope, x.in_info)
+        except F._lib.SgError:
+            pass
     x, in_info = _consume(x, premask=True)     # its gradient (an up-scale) can carry the producer's LeakyReLU mask
     return F.downscale2x(x, float(gain) / 8.0, in_info)
 

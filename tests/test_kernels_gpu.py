@@ -450,3 +450,55 @@ def test_adam_ema_matches_tf_rule():
         F.adam_ema_(p, gr.float().to(dev()), m, v, ema, 1e-3, 0.0, 0.9, step)
     np.testing.assert_allclose(p.double().cpu().numpy(), params['w'].numpy(), rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(ema.double().cpu().numpy(), shadow['w'].numpy(), rtol=1e-5, atol=1e-6)
+
+
+def _mostly_close(got, ref, rt, at_scale, what, max_bad=1e-3):
+    """assert_allclose for tensors behind a LeakyReLU mask: a handful of activations within rounding of zero take the
+    other sign than the fp64 oracle's and disturb their 27-tap neighbourhood; at most `max_bad` of the elements may miss
+    the tolerance, none by more than 20x."""
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    scale = max(1e-30, float(ref.abs().max()))
+    err = (got - ref).abs() - rt * ref.abs()
+    bad = float((err > at_scale * scale).double().mean())
+    assert bad <= max_bad, (what, bad)
+    assert float(err.max()) <= 20 * at_scale * scale + 1e-12, (what, float(err.max()), scale)
+
+
+def test_conv_epilogue_fused_downscale():
+    """downscale3d(leaky_relu(conv3d(x) + b)) with the pooling fused into the sliding-halo kernel's epilogue
+    (sg_conv_epilogue.pool + sg_downscale_sum(1,2,1)) against O.downscale3d(O.act(...)): forward, first-order gradients
+    and the gradient-penalty style second-order gradient (pgan/discriminator.py:33-44, loss.py:133-140)."""
+    from saragan_amd import functional as F
+    dtype = torch.bfloat16
+    n, cin, cout, sp = 2, 32, 64, (6, 128, 256)
+    x = rnd((n, cin, *sp), 61, dtype)
+    w = rnd((3, 3, 3, cin, cout), 62, dtype)
+    b = rnd((cout,), 63, torch.float32) * 0.3
+    coef = O.runtime_coef(w.shape, 'leaky_relu', 0.2)
+    wq = (w * coef).to(dtype).double() / coef
+    xr = x.clone().requires_grad_(True)
+    wr = wq.clone().requires_grad_(True)
+    br = b.double().clone().requires_grad_(True)
+    yr = O.downscale3d(O.act(O.apply_bias(O.conv3d(xr, wr, 'leaky_relu', 0.2), br), 'leaky_relu', 0.2))
+    xg = cl(x, dtype).requires_grad_(True)
+    wg = w.float().to(dev()).requires_grad_(True)
+    bg = b.float().to(dev()).requires_grad_(True)
+    yg = F.conv3d_act_pool(xg, wg, coef, bg, 0.2)
+    assert tuple(yg.shape) == (n, cout, 3, 64, 128)
+    close(yg, yr, dtype, 'fused conv + bias + lrelu + downscale')
+    # the unfused product path on the same inputs agrees too (same kernels, one more bf16 rounding of the full tensor)
+    yu = F.downscale2x(F.conv3d(xg, wg, coef, bias=bg, act=True, slope=0.2), 0.125)
+    close(yu, yr, dtype, 'unfused conv, downscale')
+    gy = rnd(tuple(yr.shape), 64, dtype)
+    gxr, gwr, gbr = torch.autograd.grad(yr, [xr, wr, br], gy, create_graph=True)
+    gxg, gwg, gbg = torch.autograd.grad(yg, [xg, wg, bg], cl(gy, dtype), create_graph=True)
+    _mostly_close(gxg, gxr, 1e-2, 1e-2, 'dx')
+    _mostly_close(gwg, gwr, 2e-3, 4e-3, 'dw')
+    _mostly_close(gbg, gbr, 2e-3, 4e-3, 'db')
+    # second order: d/dw of sum(dx^2)
+    (g2r,) = torch.autograd.grad((gxr * gxr).sum(), wr)
+    (g2g,) = torch.autograd.grad((gxg.float() * gxg.float()).sum(), wg)
+    _mostly_close(g2g, g2r, 2e-2, 2e-2, 'second-order dw', max_bad=5e-3)
+    # requests no kernel fuses (f32 storage) are refused, not mis-computed
+    assert F.raw_conv(xg.float(), wg, coef, False, bias=bg, act=True, want_signs=True, pool=True) is None

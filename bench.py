@@ -140,6 +140,7 @@ def build(args, device, dtype):
     og, od = opt.AdamOptimizer(g_lr, 0.0, 0.9), opt.AdamOptimizer(d_lr, 0.0, 0.9)
     if parallel.size() > 1:
         og, od = parallel.DistributedOptimizer(og), parallel.DistributedOptimizer(od)
+        og.distributed.timing = od.distributed.timing = True
     sp = [s * 2 ** (args.phase - 1) for s in base_shape[1:]]
     ph = opt.Placeholder([args.batch, base_shape[0], *sp])
     freeze = None
@@ -156,7 +157,7 @@ def build(args, device, dtype):
     sess = opt.Session(device)
     tg, td = (tup[12], tup[16]) if freeze is not None else (tup[0], tup[1])
     return dict(store=store, sess=sess, ph=ph, train=[tg, td], ema_op=ema.apply(), ks=ks, fs=fs,
-                base_shape=base_shape, shape=ph.shape, losses=[tup[3], tup[2]], graph=graph)
+                base_shape=base_shape, shape=ph.shape, losses=[tup[3], tup[2]], graph=graph, optimizers=(og, od))
 
 
 def synthetic_volume(shape, idx):
@@ -221,7 +222,7 @@ def cpu_baseline(args, cfg, budget_s):
                 activation='leaky_relu', leakiness=0.2, loss_fn=args.loss, gp_weight=10.0 if args.loss == 'wgan' else 1.0,
                 noise_stddev=0.01)
     if args.dims == 2:
-        ocfg['gp_full'] = True
+        ocfg['two_d'] = True
     nb = 1 if args.config != 1 else args.batch
     freeze = None
     if args.alpha > 0 and args.phase > 1:
@@ -362,12 +363,18 @@ def main():
     if table:
         lib.sg_prof_set_filter(table[0].kind, C.byref(table[0].shape))
     barrier()
+    if world > 1:
+        for o_ in cfg['optimizers']:
+            o_.distributed.exposed_ms()       # forget the warm-up steps
     lib.sg_prof_enable(1)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + ncal + i)
     barrier()
     dt = time.perf_counter() - t0
+    if world > 1:      # all-reduce time left exposed behind backward, per step (G + D), this rank
+        comm['exposed_allreduce_ms_per_step'] = round(sum(sum(o_.distributed.exposed_ms()) for o_ in cfg['optimizers']) / args.steps, 3)
+        comm['bucket_mib'] = cfg['optimizers'][0].distributed.bucket_elems * 4 >> 20
     timed = collect()
     lib.sg_prof_enable(0)
     lib.sg_prof_set_filter(0, None)

@@ -136,18 +136,25 @@ def pixel_norm(x: torch.Tensor, epsilon: float = 1e-8) -> torch.Tensor:
     return x * torch.rsqrt(torch.mean(x * x, dim=1, keepdim=True) + epsilon)
 
 
+_TWO_D = {'on': False}      # set by the loss builders for the 2-D tree (SURFGAN_2D/networks/ops.py:176-231)
+
+
 def upscale3d(x: torch.Tensor, factor: int = 2) -> torch.Tensor:
     """networks/ops.py:250-262,276-289: nearest-neighbour x2 (tile + batch_to_space); the custom
-    gradient (8 * avg-pool = sum-pool) is what autograd derives for repeat_interleave."""
+    gradient (8 * avg-pool = sum-pool) is what autograd derives for repeat_interleave.  2-D tree: upscale2d (H, W only)."""
     if factor == 1:
         return x
+    if _TWO_D['on']:
+        return x.repeat_interleave(factor, 3).repeat_interleave(factor, 4)
     return x.repeat_interleave(factor, 2).repeat_interleave(factor, 3).repeat_interleave(factor, 4)
 
 
 def downscale3d(x: torch.Tensor, factor: int = 2) -> torch.Tensor:
-    """networks/ops.py:265-273,292-305: avg_pool3d k=s=2 VALID."""
+    """networks/ops.py:265-273,292-305: avg_pool3d k=s=2 VALID.  2-D tree: downscale2d (avg_pool2d)."""
     if factor == 1:
         return x
+    if _TWO_D['on']:
+        return F.avg_pool3d(x, (1, factor, factor))
     return F.avg_pool3d(x, factor)
 
 
@@ -465,14 +472,15 @@ def _softplus(x):
 
 def forward_simultaneous(p: Params, real, z, noise_real, noise_fake, gamma, alpha, phase, base_shape,
                          latent_dim, kernel_spec, filter_spec, activation, leakiness, loss_fn,
-                         gp_weight, noise_stddev, arch='pgan', gp_full=False):
+                         gp_weight, noise_stddev, arch='pgan', two_d=False):
     """networks/loss.py:101-165, including quirk Q1: slopes reduce over axes (1,2,3) of the 5-D
-    gradient, so slopes has shape [N, W] (loss.py:140).  gp_full: the 2-D tree's version of this function reduces
-    its 4-D gradient over (1,2,3) = every non-batch axis (SURFGAN_2D/networks/loss.py:130-137); on the D == 1
-    volumes used here that is axes (1,2,3,4), slopes [N] -> [N,1]."""
+    gradient, so slopes has shape [N, W] (loss.py:140).  two_d: the 2-D tree on D == 1 volumes -- its version of this
+    function reduces the 4-D gradient over (1,2,3) = every non-batch axis (SURFGAN_2D/networks/loss.py:130-137), here
+    axes (1,2,3,4) with slopes [N] -> [N,1], and its up/down-sampling leaves D alone (upscale2d / downscale2d)."""
     net = dict(phase=phase, activation=activation, kernel_spec=kernel_spec, filter_spec=filter_spec,
                param=leakiness)
     generator, discriminator = ARCHS[arch][:2]      # networks.<arch> (optuna_objective.py:64-65)
+    _TWO_D['on'] = bool(two_d)
     gen_sample = generator(p, z, alpha, base_shape=base_shape, **net)
     real_n = real + noise_real * noise_stddev
     fake_n = gen_sample + noise_fake * noise_stddev
@@ -481,7 +489,7 @@ def forward_simultaneous(p: Params, real, z, noise_real, noise_fake, gamma, alph
     interpolates = (gamma * real_n + (1 - gamma) * fake_n.detach()).requires_grad_(True)
     d_int = discriminator(p, interpolates, alpha, latent_dim=latent_dim, **net)
     (gradients,) = torch.autograd.grad(d_int.sum(), interpolates, create_graph=True)
-    if gp_full:
+    if two_d:
         slopes = torch.sqrt(torch.sum(gradients * gradients, dim=(1, 2, 3, 4))).reshape(-1, 1)
     else:
         slopes = torch.sqrt(torch.sum(gradients * gradients, dim=(1, 2, 3)))
@@ -499,6 +507,7 @@ def forward_simultaneous(p: Params, real, z, noise_real, noise_fake, gamma, alph
         gen_loss = torch.mean(_softplus(-disc_fake_g))
     else:
         raise ValueError(f"Unknown loss function: {loss_fn}")
+    _TWO_D['on'] = False
     return gen_loss, disc_loss, gp_loss, gen_sample
 
 

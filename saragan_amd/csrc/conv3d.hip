@@ -1922,38 +1922,51 @@ __global__ __launch_bounds__(256) void pw_fwd_small_cin_kernel(ConvFwdArgs a, in
   const int rows = 256 / P;
   const int tpw = P < 32 / E ? P : 32 / E;      // threads per 32-channel sign word (adjacent lanes; powers of two)
   const int64_t nv_pad = (nvox + rows - 1) / rows * rows;   // whole waves stay in the loop for the shuffles
-  for (int64_t v = (int64_t)blockIdx.x * rows + threadIdx.x / P; v < nv_pad; v += (int64_t)gridDim.x * rows) {
-    const bool live = v < nvox;
-    float xv[4];
+  constexpr int U = 4;     // voxels per thread and trip: their input loads (and mask words) are issued together
+  const int64_t vstride = (int64_t)gridDim.x * rows;
+  for (int64_t v0 = (int64_t)blockIdx.x * rows + threadIdx.x / P; v0 < nv_pad; v0 += vstride * U) {
+    float xv[U][4];
+    uint32_t mwv[U];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xv[j] = (live && j < a.cin) ? sg_traits<T>::to_f(x[v * a.cin + j]) : 0.f;
-    float o[E];
-    uint32_t neg = 0u;
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * vstride;
+      const bool live = v < nvox;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      float t = b[e];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) t = fmaf(xv[j], w[j][e], t);
-      if (a.act) t = fmaxf(t, t * a.slope);
-      neg |= (t < 0.f ? 1u : 0u) << e;
-      o[e] = t;
+      for (int j = 0; j < 4; ++j) xv[u][j] = (live && j < a.cin) ? sg_traits<T>::to_f(x[v * a.cin + j]) : 0.f;
+      mwv[u] = (live && a.mask_bits != nullptr) ? a.mask_bits[v * a.ntile + (c0 >> 5)] >> (c0 & 31) : 0u;
     }
-    if (a.sign_out != nullptr) {                // the TPW threads of a word are adjacent lanes
-      uint32_t wbits = neg << ((p % tpw) * E);
-      for (int sh = 1; sh < tpw; sh <<= 1) wbits |= (uint32_t)__shfl_xor((int)wbits, sh);
-      if (live && p % tpw == 0) a.sign_out[v * a.ntile + (c0 >> 5)] = wbits;
-    }
-    if (!live) continue;
-    if (a.mask_bits != nullptr) {
-      const uint32_t mw = a.mask_bits[v * a.ntile + (c0 >> 5)] >> (c0 & 31);
 #pragma unroll
-      for (int e = 0; e < E; ++e) o[e] = ((mw >> e) & 1u) ? o[e] * a.mask_slope : o[e];
-    }
-    u32x4 raw;
-    T* t = reinterpret_cast<T*>(&raw);
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * vstride;
+      if (v >= nv_pad) break;                   // uniform per wave: nv_pad and the strides are multiples of `rows`
+      const bool live = v < nvox;
+      float o[E];
+      uint32_t neg = 0u;
 #pragma unroll
-    for (int e = 0; e < E; ++e) t[e] = sg_traits<T>::from_f(o[e]);
-    *reinterpret_cast<u32x4*>(y + v * a.cout + c0) = raw;
+      for (int e = 0; e < E; ++e) {
+        float t = b[e];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t = fmaf(xv[u][j], w[j][e], t);
+        if (a.act) t = fmaxf(t, t * a.slope);
+        neg |= (t < 0.f ? 1u : 0u) << e;
+        o[e] = t;
+      }
+      if (a.sign_out != nullptr) {                // the TPW threads of a word are adjacent lanes
+        uint32_t wbits = neg << ((p % tpw) * E);
+        for (int sh = 1; sh < tpw; sh <<= 1) wbits |= (uint32_t)__shfl_xor((int)wbits, sh);
+        if (live && p % tpw == 0) a.sign_out[v * a.ntile + (c0 >> 5)] = wbits;
+      }
+      if (!live) continue;
+      if (a.mask_bits != nullptr) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = ((mwv[u] >> e) & 1u) ? o[e] * a.mask_slope : o[e];
+      }
+      u32x4 raw;
+      T* t = reinterpret_cast<T*>(&raw);
+#pragma unroll
+      for (int e = 0; e < E; ++e) t[e] = sg_traits<T>::from_f(o[e]);
+      *reinterpret_cast<u32x4*>(y + v * a.cout + c0) = raw;
+    }
   }
 }
 

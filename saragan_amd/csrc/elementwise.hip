@@ -222,8 +222,10 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------------------
-// pixel norm: a team of TP lanes (power of two <= 64) owns one voxel; up to 4 pieces per lane.
-template <typename T, bool BWD>
+// pixel norm: a team of TP lanes (power of two <= 64) owns one voxel; KP pieces per lane (1 up to 512 bf16 channels,
+// else 4) and U voxels per loop trip: the loads of all U voxels are issued before the first reduction, which is what
+// the kernel needs to keep enough bytes in flight (one voxel per trip reached 2.8 of 6.3 TB/s).
+template <typename T, bool BWD, int KP, int U>
 __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a, const T* __restrict__ yv,
                                                          const float* __restrict__ scale_in, T* __restrict__ out,
                                                          float* __restrict__ scale_out, int64_t nvox, int c, int tp,
@@ -237,68 +239,91 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a
   const int lane_t = threadIdx.x % tp;
   const int teams = blockDim.x / tp;
   const float inv_c = 1.f / (float)c;
-  float cs[4][E];
+  const int nw = (c + 31) >> 5;
+  float cs[KP][E];
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < KP; ++k)
 #pragma unroll
     for (int e = 0; e < E; ++e) cs[k][e] = 0.f;
-  for (int64_t v = (int64_t)blockIdx.x * teams + threadIdx.x / tp; v < nvox; v += (int64_t)gridDim.x * teams) {
-    Piece<T> pa[4], py[4];
-    float s = 0.f;
+  const int64_t vstride = (int64_t)gridDim.x * teams;
+  for (int64_t v0 = (int64_t)blockIdx.x * teams + threadIdx.x / tp; v0 < nvox; v0 += vstride * U) {
+    Piece<T> pa[U][KP], py[U][KP];
+    float s[U], scv[U];
+    uint32_t sw[U][KP];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int p = lane_t + k * tp;
-      if (p < P) {
-        pa[k].load(a + v * c + (int64_t)p * E);
-        if (BWD) {
-          py[k].load(yv + v * c + (int64_t)p * E);
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * vstride;
+      s[u] = 0.f;
+      scv[u] = 0.f;
 #pragma unroll
-          for (int e = 0; e < E; ++e) s += pa[k].v[e] * py[k].v[e];
-        } else {
-#pragma unroll
-          for (int e = 0; e < E; ++e) s += pa[k].v[e] * pa[k].v[e];
+      for (int k = 0; k < KP; ++k) {
+        const int p = lane_t + k * tp;
+        sw[u][k] = 0u;
+        if (v < nvox && p < P) {
+          pa[u][k].load(a + v * c + (int64_t)p * E);
+          if (BWD) {
+            py[u][k].load(yv + v * c + (int64_t)p * E);
+            if (words) sw[u][k] = piece_signs(words, v, nw, p * E);
+          }
         }
       }
+      if (BWD && v < nvox) scv[u] = scale_in[v];
     }
-    for (int m = tp >> 1; m >= 1; m >>= 1) s += __shfl_xor(s, m);
-    if (BWD) {
-      const float sc = scale_in[v];
-      const float mean = s * inv_c;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * vstride;
+#pragma unroll
+      for (int k = 0; k < KP; ++k) {
         const int p = lane_t + k * tp;
-        if (p < P) {
+        if (v < nvox && p < P) {
 #pragma unroll
-          for (int e = 0; e < E; ++e) pa[k].v[e] = sc * (pa[k].v[e] - py[k].v[e] * mean);
-          if (words) {
-            const uint32_t sw = piece_signs(words, v, (c + 31) >> 5, p * E);
-#pragma unroll
-            for (int e = 0; e < E; ++e) pa[k].v[e] = ((sw >> e) & 1u) ? pa[k].v[e] * slope : pa[k].v[e];
-          }
-          if (part) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) cs[k][e] += pa[k].v[e];
-          }
-          pa[k].store(out + v * c + (int64_t)p * E);
+          for (int e = 0; e < E; ++e) s[u] += pa[u][k].v[e] * (BWD ? py[u][k].v[e] : pa[u][k].v[e]);
         }
       }
-    } else {
-      const float sc = rsqrtf(s * inv_c + eps);
-      if (scale_out && lane_t == 0) scale_out[v] = sc;
+      for (int m = tp >> 1; m >= 1; m >>= 1) s[u] += __shfl_xor(s[u], m);
+    }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int p = lane_t + k * tp;
-        if (p < P) {
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = v0 + u * vstride;
+      if (v >= nvox) continue;
+      if (BWD) {
+        const float sc = scv[u];
+        const float mean = s[u] * inv_c;
 #pragma unroll
-          for (int e = 0; e < E; ++e) pa[k].v[e] *= sc;
-          pa[k].store(out + v * c + (int64_t)p * E);
+        for (int k = 0; k < KP; ++k) {
+          const int p = lane_t + k * tp;
+          if (p < P) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) pa[u][k].v[e] = sc * (pa[u][k].v[e] - py[u][k].v[e] * mean);
+            if (words) {
+#pragma unroll
+              for (int e = 0; e < E; ++e) pa[u][k].v[e] = ((sw[u][k] >> e) & 1u) ? pa[u][k].v[e] * slope : pa[u][k].v[e];
+            }
+            if (part) {
+#pragma unroll
+              for (int e = 0; e < E; ++e) cs[k][e] += pa[u][k].v[e];
+            }
+            pa[u][k].store(out + v * c + (int64_t)p * E);
+          }
+        }
+      } else {
+        const float sc = rsqrtf(s[u] * inv_c + eps);
+        if (scale_out && lane_t == 0) scale_out[v] = sc;
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+          const int p = lane_t + k * tp;
+          if (p < P) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) pa[u][k].v[e] *= sc;
+            pa[u][k].store(out + v * c + (int64_t)p * E);
+          }
         }
       }
     }
   }
   if (BWD && part) {   // channel sums of this block: teams hold the same pieces, one LDS pass per piece slot
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < KP; ++k) {
       if (k * tp < P) {
         __syncthreads();
 #pragma unroll
@@ -401,20 +426,33 @@ __global__ __launch_bounds__(256) void upscale2x_rows_kernel(const T* __restrict
     const T* xrow = x + (((nn * d + (od >> sd)) * h + (oh >> sh)) * (int64_t)w) * c;
     T* yrow = y + row * (int64_t)OW * c;
     const uint32_t* mrow = mask_bits ? mask_bits + row * (int64_t)OW * nw : nullptr;
-    for (int i = threadIdx.x; i < per_row; i += 256) {
-      const int ow = i / P, p = i - ow * P;
-      Piece<T> pc;
-      pc.load(xrow + (int64_t)(ow >> sw) * c + p * E);
-      if (gain != 1.f) {
+    // four pieces per thread and trip, every load issued before the first store (a 128-voxel row of 64 channels is
+    // exactly one trip): one piece per trip left the kernel at 3.7 of 6.3 TB/s
+    for (int i0 = threadIdx.x; i0 < per_row; i0 += 256 * 4) {
+      Piece<T> pc[4];
+      uint32_t sg[4];
 #pragma unroll
-        for (int e = 0; e < E; ++e) pc.v[e] *= gain;
+      for (int j = 0; j < 4; ++j) {
+        const int i = i0 + 256 * j;
+        sg[j] = 0u;
+        if (i < per_row) {
+          const int ow = i / P, p = i - ow * P;
+          pc[j].load(xrow + (int64_t)(ow >> sw) * c + p * E);
+          if (mrow) sg[j] = mrow[ow * nw + ((p * E) >> 5)] >> ((p * E) & 31);
+        }
       }
-      if (mrow) {
-        const uint32_t sw_ = mrow[ow * nw + ((p * E) >> 5)] >> ((p * E) & 31);
 #pragma unroll
-        for (int e = 0; e < E; ++e) pc.v[e] = ((sw_ >> e) & 1u) ? pc.v[e] * mask_slope : pc.v[e];
+      for (int j = 0; j < 4; ++j) {
+        const int i = i0 + 256 * j;
+        if (i < per_row) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const float v = pc[j].v[e] * gain;
+            pc[j].v[e] = ((sg[j] >> e) & 1u) ? v * mask_slope : v;
+          }
+          pc[j].store(yrow + (int64_t)i * E);
+        }
       }
-      pc.store(yrow + (int64_t)i * E);
     }
   }
 }
@@ -748,7 +786,8 @@ static int pixel_norm_launch(const void* a, const void* yv, const float* scale_i
     const int tp = team_size(P);
     const int teams = 256 / tp;
     const int blocks = grid_for(nvox, teams, 4096);
-#define L(T) hipLaunchKernelGGL((pixel_norm_kernel<T, BWD>), dim3(blocks), dim3(256), 0, hs, (const T*)a, (const T*)yv, scale_in, (T*)out, scale_out, nvox, c, tp, eps)
+#define L(T) do { if (P <= tp) hipLaunchKernelGGL((pixel_norm_kernel<T, BWD, 1, 2>), dim3(blocks), dim3(256), 0, hs, (const T*)a, (const T*)yv, scale_in, (T*)out, scale_out, nvox, c, tp, eps); \
+                  else hipLaunchKernelGGL((pixel_norm_kernel<T, BWD, 4, 1>), dim3(blocks), dim3(256), 0, hs, (const T*)a, (const T*)yv, scale_in, (T*)out, scale_out, nvox, c, tp, eps); } while (0)
     SG_DISPATCH(dt, L(bf16_t), L(float));
 #undef L
   } else {
@@ -791,7 +830,8 @@ extern "C" int sg_pixel_norm_act_bwd(const void* dy, const void* y, const float*
   const int teams = 256 / tp;
   const int blocks = grid_for(nvox, teams, kBwdBlocks);
   float* part = dbias ? reinterpret_cast<float*>(workspace) : nullptr;
-#define L(T) hipLaunchKernelGGL((pixel_norm_kernel<T, true>), dim3(blocks), dim3(256), 0, hs, (const T*)dy, (const T*)y, scale, (T*)dz, (float*)nullptr, nvox, c, tp, 0.f, (const uint32_t*)y_sign_words, slope, part)
+#define L(T) do { if (P <= tp) hipLaunchKernelGGL((pixel_norm_kernel<T, true, 1, 2>), dim3(blocks), dim3(256), 0, hs, (const T*)dy, (const T*)y, scale, (T*)dz, (float*)nullptr, nvox, c, tp, 0.f, (const uint32_t*)y_sign_words, slope, part); \
+                  else hipLaunchKernelGGL((pixel_norm_kernel<T, true, 4, 1>), dim3(blocks), dim3(256), 0, hs, (const T*)dy, (const T*)y, scale, (T*)dz, (float*)nullptr, nvox, c, tp, 0.f, (const uint32_t*)y_sign_words, slope, part); } while (0)
   SG_DISPATCH(dt, L(bf16_t), L(float));
 #undef L
   SG_LAUNCH_CHECK();

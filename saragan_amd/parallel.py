@@ -56,6 +56,8 @@ class GradientAllReducer:
         self._buckets = []
         self._handles = []
         self._armed = False
+        self.timing = bool(int(os.environ.get('SARAGAN_DP_TIMING', '0')))
+        self._spans = []       # (event before the waits, event after): GPU time the compute stream sat in finish()
 
     def _plan(self, flat_grad, ranges, params):
         key = (flat_grad.data_ptr(), tuple(ranges), len(params))
@@ -110,9 +112,28 @@ class GradientAllReducer:
         for b in self._buckets:
             if not b['launched']:
                 self._launch(b)
+        span = None
+        if self.timing and self._handles and torch.cuda.is_available() and self._flat.is_cuda:
+            span = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            span[0].record()
         for h in self._handles:
-            h.wait()
+            h.wait()           # NCCL/RCCL: the current stream waits for the collective's stream; gloo: the host does
+        if span is not None:
+            span[1].record()
+            self._spans.append(span)
         self._handles = []
+
+    def exposed_ms(self, reset=True):
+        """Per finish() call: milliseconds the compute stream spent between "backward enqueued" and "last bucket
+        reduced", i.e. the all-reduce time NOT hidden behind backward (enable with .timing / SARAGAN_DP_TIMING=1;
+        synchronises).  The buckets launched from the autograd hooks overlap; what is left here is the tail."""
+        out = []
+        for e0, e1 in self._spans:
+            e1.synchronize()
+            out.append(e0.elapsed_time(e1))
+        if reset:
+            self._spans = []
+        return out
 
 
 def DistributedOptimizer(optimizer, group=None, bucket_bytes=None, op=None):

@@ -94,3 +94,32 @@ def assert_adam_close(got, ref, lr, rtol, what, max_flip_frac=2e-4):
     if nbad:
         assert float(diff.max()) <= 2.2 * lr + 2e-5, (what, float(diff.max()))
         assert nbad <= max(1, int(max_flip_frac * g.numel())), (what, nbad, g.numel())
+
+
+def bf16_gradient_report(groups, w_rel=0.30, w_cos=0.95, net_cos=0.98, net_norm=0.10):
+    """bf16 gradients against the fp64 oracle's.  groups: [(tag, handle_vars, grads, {name: ref})].  bf16 rounding of an
+    activation (0.4 %) flips a fraction of a percent of the LeakyReLU masks against the oracle, so single tensors carry
+    5-20 % error and bias gradients (sums with cancellation) more.  Criteria: every WEIGHT gradient within `w_rel` in
+    relative L2 and cosine >= `w_cos`; each network's whole gradient (all tensors concatenated) cosine >= `net_cos`
+    and norm within `net_norm`.  Returns (report, violations)."""
+    report, bad = {}, []
+    for tag, hv, grads, refs in groups:
+        assert [v.key for v in hv] == list(refs.keys())
+        a = torch.cat([g.detach().double().cpu().reshape(-1) for g in grads])
+        b = torch.cat([refs[v.key].double().reshape(-1) for v in hv])
+        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
+        report[f'{tag}:all'] = dict(cos=cos, norm_ratio=float(a.norm() / b.norm()))
+        if cos < net_cos or abs(float(a.norm() / b.norm()) - 1) > net_norm:
+            bad.append((tag, report[f'{tag}:all']))
+        for v, g in zip(hv, grads):
+            r = refs[v.key].double()
+            gd = g.detach().double().cpu()
+            if float(r.norm()) == 0.0:       # e.g. to_rgb_{p-1} at alpha = 0: exactly zero in both
+                assert float(gd.norm()) == 0.0, v.key
+                continue
+            e = rel_l2(gd, r)
+            c = float(torch.dot(gd.reshape(-1), r.reshape(-1)) / max(1e-30, float(gd.norm() * r.norm())))
+            report[v.key] = dict(rel_l2=e, cos=c)
+            if v.key.endswith('weight') and (e > w_rel or c < w_cos):
+                bad.append((v.key, report[v.key]))
+    return report, bad

@@ -23,9 +23,11 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, golden, q):
+def _worker(rank, world, port, golden, q, backend='gloo'):
+    # gloo: both ranks share cuda:0 (one GPU suffices); nccl (= RCCL): one device per rank
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK='0', SARAGAN_DIST_BACKEND='gloo')
+                      LOCAL_RANK=str(rank) if backend == 'nccl' else '0', SARAGAN_DIST_BACKEND=backend,
+                      HSA_ENABLE_IPC_MODE_LEGACY='0', SARAGAN_DP_TIMING='1')
     import saragan_amd.optimization as opt
     from saragan_amd import parallel
     from saragan_amd.ExtendedEMA import ExtendedEMA
@@ -61,18 +63,25 @@ def _worker(rank, world, port, golden, q):
     sess.run([tup[0], tup[1]], feed_dict={ph: fx['real'][sl].float()})
     sess.run(ema.apply())
     torch.cuda.synchronize()
+    if backend == 'nccl':
+        assert torch.distributed.get_backend() == 'nccl' and torch.cuda.current_device() == rank
+    exposed = og.distributed.exposed_ms() + od.distributed.exposed_ms()
+    assert len(exposed) == 2 and all(e >= 0 for e in exposed)
     q.put((rank, {k: v.detach().cpu().numpy() for k, v in store.vars.items()}))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_step_equals_full_batch_oracle(golden_dir):
+@pytest.mark.parametrize('backend', ['gloo', 'nccl'])
+def test_two_rank_step_equals_full_batch_oracle(golden_dir, backend):
     from tests.stepfix import load_step_fixture
     world = 2
+    if backend == 'nccl' and torch.cuda.device_count() < 2:
+        pytest.skip('RCCL needs one device per rank: fewer than 2 GPUs here (the 8-GPU node runs this variant)')
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, golden_dir, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, golden_dir, q, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=300) for _ in range(world))

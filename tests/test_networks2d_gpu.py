@@ -25,16 +25,16 @@ def test_ops_2d_match_oracle():
         xd = x.to(dev).contiguous(memory_format=torch.channels_last_3d).requires_grad_(True)
         up = F.upscale2x(xd, 1.0, factors=(1, 2, 2))
         ref = x.double().repeat_interleave(2, 3).repeat_interleave(2, 4)
-        np.testing.assert_array_equal(up.double().cpu().numpy(), ref.numpy())
+        np.testing.assert_array_equal(up.detach().double().cpu().numpy(), ref.numpy())
         (gx,) = torch.autograd.grad(up, xd, torch.ones_like(up))
         assert float(gx.float().min()) == float(gx.float().max()) == 4.0       # gradient = 4 * avg_pool2d
         dn = F.downscale2x(xd, 0.25, None, factors=(1, 2, 2))
         refd = torch.nn.functional.avg_pool2d(x.double().squeeze(2), 2).unsqueeze(2)
         tol = 1e-6 if dtype == torch.float32 else 1e-2
-        np.testing.assert_allclose(dn.double().cpu().numpy(), refd.numpy(), rtol=tol, atol=tol)
+        np.testing.assert_allclose(dn.detach().double().cpu().numpy(), refd.numpy(), rtol=tol, atol=tol)
         hp = F.downscale2x(xd, 0.5, None, factors=(1, 2, 1))                    # H-only pooling
         refh = 0.5 * (x.double()[:, :, :, 0::2] + x.double()[:, :, :, 1::2])
-        np.testing.assert_allclose(hp.double().cpu().numpy(), refh.numpy(), rtol=tol, atol=tol)
+        np.testing.assert_allclose(hp.detach().double().cpu().numpy(), refh.numpy(), rtol=tol, atol=tol)
 
 
 @pytest.mark.parametrize('alpha', [0.0, 0.3])
@@ -58,7 +58,7 @@ def test_pgan_2d_step_matches_oracle(alpha):
     rnd = O.draw_randomness(n, latent, img, 10)
     real = torch.randn((n, *img), dtype=torch.float64, generator=torch.Generator().manual_seed(11))
     cfg = dict(phase=phase, base_shape=BASE, latent_dim=latent, kernel_spec=ks, filter_spec=fs, activation='leaky_relu',
-               leakiness=0.2, loss_fn='wgan', gp_weight=10.0, noise_stddev=0.01, gp_full=True)
+               leakiness=0.2, loss_fn='wgan', gp_weight=10.0, noise_stddev=0.01, two_d=True)
     freeze = list(O.variable_shapes(phase - 1, BASE, latent, ks, fs).keys()) if alpha > 0 else None
     p0_2d = {k_: (v.squeeze(0) if v.dim() == 5 else v) for k_, v in p0.items()}
     case = dict(p0=p0_2d, rnd=rnd, real=real, alpha=alpha, freeze=freeze, phase=phase, loss_fn='wgan', n=n, latent=latent,

@@ -164,7 +164,7 @@ def test_step_bf16_every_gradient_weight_and_ema(golden_dir, name):
     (relative L2 per tensor; they pass through the GP double backward), the post-Adam weights and the EMA shadows after
     one and two steps.  With beta1 = 0 a first update is -lr * sign(g): elements whose gradient is below bf16 noise may
     land 2 lr away, at most 5 % of a tensor."""
-    from tests.cfgutil import assert_adam_close, rel_l2
+    from tests.cfgutil import bf16_gradient_report
     fx = load_step_fixture(os.path.join(golden_dir, name), torch.float64)
     store, tup, ph, ema, sess = _build(fx, torch.bfloat16)
     mixing = fx['freeze'] is not None
@@ -173,31 +173,9 @@ def test_step_bf16_every_gradient_weight_and_ema(golden_dir, name):
     feed = {ph: fx['real'].float()}
     _, _, gg, dg = sess.run([tg, td, gg_h, dg_h], feed_dict=feed)
     sess.run(ema.apply())
-    # These nets are tiny (8-16 channels): bf16 rounding of an activation (0.4 %) flips ~0.5 % of the LeakyReLU masks
-    # against the fp64 oracle, so single tensors carry 5-20 % error.  Criteria: every weight gradient within 30 % in
-    # relative L2 and cosine >= 0.95 with the oracle's; the whole network's gradient (all tensors concatenated) cosine
-    # >= 0.98 and norm within 10 %.
-    worst, bad = {}, []
-    for net, hv, grads, refs in (('G', gv, gg, fx['gg']), ('D', dv, dg, fx['dg'])):
-        assert [v.key for v in hv] == list(refs.keys())
-        a = torch.cat([g.double().cpu().reshape(-1) for g in grads])
-        b = torch.cat([refs[v.key].reshape(-1) for v in hv])
-        cos = float(torch.dot(a, b) / (a.norm() * b.norm()))
-        worst[f'{net}:all'] = dict(cos=cos, norm_ratio=float(a.norm() / b.norm()))
-        if cos < 0.98 or abs(float(a.norm() / b.norm()) - 1) > 0.10:
-            bad.append((net, worst[f'{net}:all']))
-        for v, g in zip(hv, grads):
-            r = refs[v.key]
-            if float(r.norm()) == 0.0:       # e.g. to_rgb_{p-1} at alpha = 0: exactly zero in both
-                assert float(g.double().norm()) == 0.0, v.key
-                continue
-            e = rel_l2(g, r)
-            c = float(torch.dot(g.double().cpu().reshape(-1), r.reshape(-1)) / max(1e-30, float(g.double().norm() * r.norm())))
-            worst[v.key] = dict(rel_l2=e, cos=c)
-            if v.key.endswith('weight') and (e > 0.30 or c < 0.95):
-                bad.append((v.key, worst[v.key]))
-    print(name, {k: v for k, v in worst.items() if k.endswith(':all')})
-    assert not bad, (bad, worst)
+    report, bad = bf16_gradient_report([('G', gv, gg, fx['gg']), ('D', dv, dg, fx['dg'])])
+    print(name, {k: v for k, v in report.items() if k.endswith(':all')})
+    assert not bad, (bad, report)
     flips = {}
     for k, p in store.vars.items():
         d = (p.detach().double().cpu() - fx['p1'][k]).abs()
@@ -209,7 +187,8 @@ def test_step_bf16_every_gradient_weight_and_ema(golden_dir, name):
     sess.run(ema.apply())
     for k, p in store.vars.items():   # second step: both arithmetic's weights have moved, differences add up
         d = (p.detach().double().cpu() - fx['p2'][k]).abs().max()
-        assert float(d) <= 4.4e-3 + 1e-3 * float(fx['p2'][k].abs().max()), (k, float(d))
+        # (a second Adam step moves an element by up to 1.38 lr: 2 lr + 2 * 1.38 lr when both steps went opposite ways)
+        assert float(d) <= 5e-3 + 1e-3 * float(fx['p2'][k].abs().max()), (k, float(d))
     from saragan_amd.varstore import set_compute_dtype
     set_compute_dtype(torch.float32)
 

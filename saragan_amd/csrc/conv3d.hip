@@ -608,16 +608,17 @@ static int launch_fwd2(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st) {
 
 // Fully unrolled, software-pipelined K loop of the weight-stationary kernel (see the call site).  Template
 // recursion keeps every LDS offset and wait count an immediate.
-// Address-table index of operand fragment (tap, M tile).  With HS ("H shift") the wave's two M tiles are consecutive
-// H rows of the tile, so the fragment of (kd, kh, kw) for M tile 1 IS the fragment of (kd, kh + 1, kw) for M tile 0:
-// the table holds KD x (KH + 1) x KW addresses instead of KD x KH x KW x 2 (36 instead of 54 registers at 3x3x3,
-// which is what kept <2,2,3,3,3> from fitting 256 VGPRs next to its 64 accumulators).
+// Address-table index of operand fragment (tap, M tile).  With HS ("H shift") the wave's MTW M tiles are consecutive
+// H rows of the tile, so the fragment of (kd, kh, kw) for M tile mt IS the fragment of (kd, kh + mt, kw) for M tile 0:
+// the table holds KD x (KH + MTW - 1) x KW addresses instead of KD x KH x KW x MTW (36 instead of 54 registers at 3x3x3
+// with two M tiles, which is what kept <2,2,3,3,3> from fitting 256 VGPRs next to its 64 accumulators; 54 instead of
+// 108 with four).
 template <int MTW, int KH, int KW, bool HS>
 __host__ __device__ constexpr int sg_xa_index(int tap, int mt) {
-  return HS ? ((tap / (KH * KW)) * (KH + 1) + (tap / KW) % KH + mt) * KW + tap % KW : tap * MTW + mt;
+  return HS ? ((tap / (KH * KW)) * (KH + MTW - 1) + (tap / KW) % KH + mt) * KW + tap % KW : tap * MTW + mt;
 }
 template <int MTW, int KD, int KH, int KW, bool HS>
-struct sg_xa_size { static constexpr int value = HS ? KD * (KH + 1) * KW : KD * KH * KW * MTW; };
+struct sg_xa_size { static constexpr int value = HS ? KD * (KH + MTW - 1) * KW : KD * KH * KW * MTW; };
 
 template <typename T, int MTW, int GC, int TAPS, int RING, int KH, int KW, bool HS, int NA>
 struct sg_unrolled_k {
@@ -781,11 +782,11 @@ __global__ __launch_bounds__(512) void conv_fwd3r_kernel(ConvFwdArgs a) {
 #pragma unroll
     for (int kd = 0; kd < KD; ++kd)
 #pragma unroll
-      for (int kh = 0; kh < KH + (HS ? 1 : 0); ++kh)
+      for (int kh = 0; kh < KH + (HS ? MTW - 1 : 0); ++kh)
 #pragma unroll
         for (int kw = 0; kw < KW; ++kw) {
           const int row = lrow + (kd * g.HH + kh) * g.HW + kw;
-          const int idx = HS ? (kd * (KH + 1) + kh) * KW + kw : ((kd * KH + kh) * KW + kw) * MTW + mt;
+          const int idx = HS ? (kd * (KH + MTW - 1) + kh) * KW + kw : ((kd * KH + kh) * KW + kw) * MTW + mt;
           xaddr[idx] = grp * a.xbytes + row * rb + (((hh) ^ ((row >> rshift) & (S - 1))) << 4);
         }
   }
@@ -1434,8 +1435,8 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
       }
       if (closes && a.pool) {
         // fused downscale3d, first stage (pgan/discriminator.py:44 after conv_2 + bias + LeakyReLU): the tile's two D
-        // planes are this wave's two M tiles (a lane-local add) and W neighbours are adjacent lanes (one DPP quad
-        // permutation), so the mean over the 2 x 1 x 2 block costs 32 VALU ops and the full-resolution activation --
+        // planes are this wave's two M tiles (a lane-local add) and W neighbours are adjacent lanes (one cross-lane
+        // exchange), so the mean over the 2 x 1 x 2 block costs 32 VALU ops and the full-resolution activation --
         // the largest tensor of the network, needed by nobody else: the backward only wants its sign words -- is never
         // written.  Output [n, D/2, H, W/2, cout]; the H pairs (two different waves) are pooled by sg_downscale_sum(1,2,1).
         const __amdgpu_buffer_rsrc_t ryp = rsrc_of(a.y, ysb / 4, o.n0);
@@ -1445,8 +1446,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const float t = acc[0][i] + acc[1][i];
-          const float u = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t), 0xB1, 0xF, 0xF, true));
-          sp[i] = (t + u) * 0.25f;     // quad_perm [1,0,3,2]: lane r <-> r ^ 1
+          sp[i] = (t + __shfl_xor(t, 1)) * 0.25f;     // lane r <-> r ^ 1: the W neighbour
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -1546,9 +1546,9 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
   const int items_mine = kmine * ncg;
   const int items_max = ((K + 1) >> 1) * ncg;                               // group 0 has the most
 
-  // HS (two output-channel tiles per wave: 64 accumulators): the address table is shared between the wave's two
-  // M tiles (sg_xa_index); the host launches it only where M tile 1 is M tile 0 moved by one H row
-  constexpr bool HS = (MTW == 2 && NTB == 2);
+  // HS (64 accumulators per lane: two M x two N tiles, or four M tiles): the address table is shared between the
+  // wave's M tiles (sg_xa_index); the host launches it only where M tile mt is M tile 0 moved by mt H rows
+  constexpr bool HS = (MTW * NTB >= 4);
   constexpr int NA = sg_xa_size<MTW, KD, KH, KW, HS>::value;
   int xaddr[NA];
   int tcoord[MTW];
@@ -1568,17 +1568,17 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
 #pragma unroll
     for (int kd = 0; kd < KD; ++kd)
 #pragma unroll
-      for (int kh = 0; kh < KH + (HS ? 1 : 0); ++kh)
+      for (int kh = 0; kh < KH + (HS ? MTW - 1 : 0); ++kh)
 #pragma unroll
         for (int kw = 0; kw < KW; ++kw) {
           const int row = lrow + ((kd + a.tap_d) * g.HH + (kh + a.tap_h)) * g.HW + (kw + a.tap_w);
-          const int idx = HS ? (kd * (KH + 1) + kh) * KW + kw : ((kd * KH + kh) * KW + kw) * MTW + mt;
+          const int idx = HS ? (kd * (KH + MTW - 1) + kh) * KW + kw : ((kd * KH + kh) * KW + kw) * MTW + mt;
           xaddr[idx] = grp * a.xbytes + row * rb + ((hh ^ ((row >> 3) & 1)) << 4);
         }
   }
   const int hv = g.TN * g.HD * g.HH * g.HW;
   const int items = hv * 2;
-  constexpr int MAXIT = 8;
+  constexpr int MAXIT = MTW > 2 ? 10 : 8;   // LDS-DMA pieces per wave per halo chunk (host-checked)
   int it_rel[MAXIT];   // element offset (chunk 0) relative to the tile's first halo voxel, -1 dead
   int it_crd[MAXIT];
   const int Di = g.ups ? (g.D >> 1) : g.D, Hi = g.ups ? (g.H >> 1) : g.H, Wi = g.ups ? (g.W >> 1) : g.W;
@@ -1644,10 +1644,12 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
 #pragma unroll
       for (int k = 0; k < MAXIT; ++k) {
         if ((wave + 4 * k) * 64 < items && it_crd[k] != 0x7F7F7F7F) {   // idle lanes: beyond the halo image
-          const uint32_t c_ = (uint32_t)it_crd[k] & 0x7FFFFFFFu;
+          uint32_t craw = (uint32_t)it_crd[k];
+          asm volatile("" : "+v"(craw));   // opaque: or the compiler keeps three derived copies of the table in registers
+          const uint32_t c_ = craw & 0x7FFFFFFFu;
           const uint32_t t1 = (c_ | 0x80808080u) - lo, t2 = hi - c_;
           bool ok = (t1 & t2 & 0x80808080u) == 0x80808080u;
-          if (tail) ok = ok && (c0 + (int)((uint32_t)it_crd[k] >> 31) * EPP < a.cin);
+          if (tail) ok = ok && (c0 + (int)(craw >> 31) * EPP < a.cin);
           const uint32_t vo = ok ? (uint32_t)(it_rel[k] * (int)sizeof(T) + tile_off) : DEAD;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xmine + (size_t)(wave + 4 * k) * 1024), 16, vo, 0, 0, 0);
         }
@@ -1745,7 +1747,8 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
 #pragma unroll
               for (int i = 0; i < 16; ++i) acc[mt][nt][i] = bias_lds[nt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];
         }
-        sg_unrolled_k4<T, MTW, NTB, TAPS, 3, KH, KW, HS, NA>::run(acc, xaddr, (int)(wl - smem) + (a.wres ? (q % ncg) : (q & 1)) * a.wbytes);
+        // (four M tiles: a step already carries 4 MFMAs = 128 cycles, one step of fragment prefetch covers the LDS latency)
+        sg_unrolled_k4<T, MTW, NTB, TAPS, (MTW > 2 ? 2 : 3), KH, KW, HS, NA>::run(acc, xaddr, (int)(wl - smem) + (a.wres ? (q % ncg) : (q & 1)) * a.wbytes);
       }
     } else {
       // my next item is q' = (p + 1) >> 1; my previous one q' - 1 (ran in phase p - 1)
@@ -1870,8 +1873,8 @@ static int launch_fwd4(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, b
   a.lean = ((!s->upsample_in || (g.TD % 2 == 0 && g.TH % 2 == 0 && g.TW % 2 == 0 && g.TN == 1)) &&
             !sg_cfg().fwd4_no_lean) ? 1 : 0;
   a.wbytes = a.taps * NTB * 1024;
-  if (sg_cdiv(hv * 2, 64) > 32) return SG_OK;
-  if (MTW == 2 && NTB == 2 && !(g.TW == 32 && (g.TH & 1) == 0)) return SG_OK;   // shared address table (sg_xa_index)
+  if (sg_cdiv(hv * 2, 64) > (MTW > 2 ? 40 : 32)) return SG_OK;
+  if (MTW * NTB >= 4 && !(g.TW == 32 && g.TH % MTW == 0)) return SG_OK;   // shared address table (sg_xa_index)
   size_t lds = 2ull * a.xbytes + (size_t)a.nchunk * a.wbytes + NTB * 128;
   a.wres = (lds <= 160 * 1024 && !sg_cfg().fwd4_no_wres) ? 1 : 0;
   if (!a.wres) lds = 2ull * a.xbytes + 2ull * a.wbytes + NTB * 128;
@@ -1922,51 +1925,38 @@ __global__ __launch_bounds__(256) void pw_fwd_small_cin_kernel(ConvFwdArgs a, in
   const int rows = 256 / P;
   const int tpw = P < 32 / E ? P : 32 / E;      // threads per 32-channel sign word (adjacent lanes; powers of two)
   const int64_t nv_pad = (nvox + rows - 1) / rows * rows;   // whole waves stay in the loop for the shuffles
-  constexpr int U = 4;     // voxels per thread and trip: their input loads (and mask words) are issued together
-  const int64_t vstride = (int64_t)gridDim.x * rows;
-  for (int64_t v0 = (int64_t)blockIdx.x * rows + threadIdx.x / P; v0 < nv_pad; v0 += vstride * U) {
-    float xv[U][4];
-    uint32_t mwv[U];
+  for (int64_t v = (int64_t)blockIdx.x * rows + threadIdx.x / P; v < nv_pad; v += (int64_t)gridDim.x * rows) {
+    const bool live = v < nvox;
+    float xv[4];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t v = v0 + u * vstride;
-      const bool live = v < nvox;
+    for (int j = 0; j < 4; ++j) xv[j] = (live && j < a.cin) ? sg_traits<T>::to_f(x[v * a.cin + j]) : 0.f;
+    float o[E];
+    uint32_t neg = 0u;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xv[u][j] = (live && j < a.cin) ? sg_traits<T>::to_f(x[v * a.cin + j]) : 0.f;
-      mwv[u] = (live && a.mask_bits != nullptr) ? a.mask_bits[v * a.ntile + (c0 >> 5)] >> (c0 & 31) : 0u;
+    for (int e = 0; e < E; ++e) {
+      float t = b[e];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) t = fmaf(xv[j], w[j][e], t);
+      if (a.act) t = fmaxf(t, t * a.slope);
+      neg |= (t < 0.f ? 1u : 0u) << e;
+      o[e] = t;
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t v = v0 + u * vstride;
-      if (v >= nv_pad) break;                   // uniform per wave: nv_pad and the strides are multiples of `rows`
-      const bool live = v < nvox;
-      float o[E];
-      uint32_t neg = 0u;
-#pragma unroll
-      for (int e = 0; e < E; ++e) {
-        float t = b[e];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) t = fmaf(xv[u][j], w[j][e], t);
-        if (a.act) t = fmaxf(t, t * a.slope);
-        neg |= (t < 0.f ? 1u : 0u) << e;
-        o[e] = t;
-      }
-      if (a.sign_out != nullptr) {                // the TPW threads of a word are adjacent lanes
-        uint32_t wbits = neg << ((p % tpw) * E);
-        for (int sh = 1; sh < tpw; sh <<= 1) wbits |= (uint32_t)__shfl_xor((int)wbits, sh);
-        if (live && p % tpw == 0) a.sign_out[v * a.ntile + (c0 >> 5)] = wbits;
-      }
-      if (!live) continue;
-      if (a.mask_bits != nullptr) {
-#pragma unroll
-        for (int e = 0; e < E; ++e) o[e] = ((mwv[u] >> e) & 1u) ? o[e] * a.mask_slope : o[e];
-      }
-      u32x4 raw;
-      T* t = reinterpret_cast<T*>(&raw);
-#pragma unroll
-      for (int e = 0; e < E; ++e) t[e] = sg_traits<T>::from_f(o[e]);
-      *reinterpret_cast<u32x4*>(y + v * a.cout + c0) = raw;
+    if (a.sign_out != nullptr) {                // the TPW threads of a word are adjacent lanes
+      uint32_t wbits = neg << ((p % tpw) * E);
+      for (int sh = 1; sh < tpw; sh <<= 1) wbits |= (uint32_t)__shfl_xor((int)wbits, sh);
+      if (live && p % tpw == 0) a.sign_out[v * a.ntile + (c0 >> 5)] = wbits;
     }
+    if (!live) continue;
+    if (a.mask_bits != nullptr) {
+      const uint32_t mw = a.mask_bits[v * a.ntile + (c0 >> 5)] >> (c0 & 31);
+#pragma unroll
+      for (int e = 0; e < E; ++e) o[e] = ((mw >> e) & 1u) ? o[e] * a.mask_slope : o[e];
+    }
+    u32x4 raw;
+    T* t = reinterpret_cast<T*>(&raw);
+#pragma unroll
+    for (int e = 0; e < E; ++e) t[e] = sg_traits<T>::from_f(o[e]);
+    *reinterpret_cast<u32x4*>(y + v * a.cout + c0) = raw;
   }
 }
 
@@ -2206,6 +2196,11 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     // 32-channel slice per block (pixel-norm over 64 channels then falls through to the v2 kernels)
     const sg_tile_geom g4 = sg_make_geom(s, 256, /*prefer_w32=*/true);
     const bool n1 = a.ntile == 1 || (!(g4.TW == 32 && (g4.TH & 1) == 0) && !a.pixel_norm);
+    // (A 4 x 4 x 32 tile with four M tiles per wave was measured for the one-slice deep-K layers, 64 -> 32 at 128^2:
+    // 682 against 732 TFLOP/s.  It doubles the MFMAs per staged halo chunk but no longer fits next to resident weights,
+    // so the streamed slab halves put back the bytes per phase it saved: those layers are bound by the LDS-DMA issue ->
+    // landed latency of one phase's staging, which only a two-phase-deep halo pipeline -- LDS the kernel does not have
+    // -- would hide.)
     if (dt == SG_BF16) {
       if (k333) rc = n1 ? launch_fwd4<bf16_t, 2, 1, 3, 3, 3>(a, s, hs, &used) : launch_fwd4<bf16_t, 2, 2, 3, 3, 3>(a, s, hs, &used);
       else if (k133) rc = n1 ? launch_fwd4<bf16_t, 2, 1, 1, 3, 3>(a, s, hs, &used) : launch_fwd4<bf16_t, 2, 2, 1, 3, 3>(a, s, hs, &used);

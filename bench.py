@@ -258,7 +258,7 @@ def pmc_traffic(entry, dtype):
         key = dict(n=s.n, d=s.d, h=s.h, w=s.w, cin=s.cin, cout=s.cout, k=[s.kd, s.kh, s.kw])
         kind = 'fwd' if entry.kind == 0 else 'wgrad'
         hits = [e['traffic_bytes'] for e in tab['entries'] if e['kind'] == kind and e['shape'] == key and
-                (not e.get('kernel') or e['kernel'] == entry.kernel.decode())]
+                e.get('variant', '').startswith(('fwd bias', 'wgrad', 'bias', 'with'))]
         if hits and not s.upsample_in:
             return round(sum(hits) / len(hits))
     return None

@@ -1,27 +1,31 @@
-"""Launches each hot conv kernel of the pgan 's' phase-6 step a few times, preceded by a streaming kernel of known
-byte count (calibration), for the HBM-traffic counter passes:
+"""Launches the hot kernels of the pgan 's' phase-6 step (bench default: batch 32 per GPU) at their in-step shapes, each
+twice, after a streaming kernel of known byte count (calibration), for the rocprofv3 counter passes -- one counter
+group per pass, as MI355X_MICROARCH.md prescribes (FETCH_SIZE and WRITE_SIZE do not fit one pass):
 
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_rd -o rd -- python tools/pmc_probe.py
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_wr -o wr -- python tools/pmc_probe.py
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_rd -o rd -- python3 tools/pmc_probe.py
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_wr -o wr -- python3 tools/pmc_probe.py
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv \
+            -d gpurun_out/pmc_mfma -o mf -- python3 tools/pmc_probe.py
 
-tools/pmc_summary.py turns the two counter CSVs into profiles/r01_pmc_traffic.json."""
+The probe writes gpurun_out/pmc_manifest.json: one record per measured launch (kernel-name substring to look for,
+algorithmic bytes, FLOPs); tools/pmc_summary.py joins it with the counter CSVs into profiles/r02_pmc_*.json."""
 import ctypes as C
+import json
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 from saragan_amd import _lib  # noqa: E402
 from saragan_amd._lib import ConvEpilogue, ConvShape  # noqa: E402
 
-SHAPES = [  # n, (d,h,w), cin, cout  (all 3x3x3): the >= 1 ms/step entries of `bench.py --dump-prof` at the default
-    # per-GPU batch 32; n = 64 is the concatenated real+fake batch of the discriminator, n = 32 the generator /
-    # gradient-penalty passes
+CONVS = [  # n, (d,h,w), cin, cout (all 3x3x3): the >= 1 ms/step entries of `bench.py --dump-prof`; n = 64 is the
+    # concatenated real+fake batch of the discriminator, n = 32 the generator / gradient-penalty passes
     (64, (32, 128, 128), 64, 32),
     (64, (32, 128, 128), 32, 32),
     (64, (32, 128, 128), 32, 64),
-    (32, (32, 128, 128), 32, 32),
     (32, (32, 128, 128), 32, 64),
     (32, (32, 128, 128), 64, 32),
     (64, (16, 64, 64), 64, 64),
@@ -36,17 +40,26 @@ def main():
     dt = _lib.SG_BF16
     dev = torch.device('cuda:0')
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    # calibration: out = 1*a + 0*b over 2^28 bf16 elements: reads 2 x 512 MiB, writes 512 MiB, 16 B per lane
+    manifest = []
+
+    def twice(tag, match, alg_bytes, flops, fn):
+        for rep in range(2):
+            fn()
+        torch.cuda.synchronize()
+        manifest.append(dict(tag=tag, match=match, algorithmic_bytes=int(alg_bytes), flops=float(flops), repeats=2))
+        print(tag, 'done', flush=True)
+
+    # calibration: out = 1*a + 0.5*b over 2^28 bf16 elements: reads 2 x 512 MiB, writes 512 MiB, 16 B per lane
     numel = 1 << 28
     a = torch.randn(numel, device=dev).to(torch.bfloat16)
     b = torch.randn(numel, device=dev).to(torch.bfloat16)
     o = torch.empty_like(a)
-    for _ in range(2):
-        _lib.check(lib.sg_axpby(a.data_ptr(), b.data_ptr(), o.data_ptr(), 1.0, 0.5, numel, dt, st))
-    torch.cuda.synchronize()
+    twice('calibration axpby 2^28', 'axpby', 3 * numel * 2, 0,
+          lambda: _lib.check(lib.sg_axpby(a.data_ptr(), b.data_ptr(), o.data_ptr(), 1.0, 0.5, numel, dt, st)))
     del a, b, o
-    for n, (d, h, w), cin, cout in SHAPES:
+    for n, (d, h, w), cin, cout in CONVS:
         shp = ConvShape(n, d, h, w, cin, cout, 3, 3, 3, 0)
+        vox = n * d * h * w
         x = torch.randn(n, d, h, w, cin, device=dev).to(torch.bfloat16)
         dy = torch.randn(n, d, h, w, cout, device=dev).to(torch.bfloat16)
         wt = torch.randn(3, 3, 3, cin, cout, device=dev)
@@ -63,13 +76,47 @@ def main():
         ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
         dw = torch.empty(3, 3, 3, cin, cout, device=dev)
         db = torch.empty(cout, device=dev)
-        for _ in range(2):
-            _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep_plain), dt, st))
-            _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep_mask), dt, st))
-            _lib.check(lib.sg_conv3d_wgrad_bias(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), 1.0,
-                                                ws.data_ptr(), wsb, C.byref(shp), dt, st))
-        torch.cuda.synchronize()
-        print(f'{d}x{h}x{w} {cin}->{cout} n={n} done', flush=True)
+        flops = 2.0 * vox * cin * cout * 27
+        name = f'n{n} {d}x{h}x{w} {cin}->{cout}'
+        twice(f'fwd bias+lrelu+sign_out {name}', 'conv_fwd', vox * (cin + cout) * 2 + vox * nw * 4 + 27 * cin * cout * 2, flops,
+              lambda: _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep_plain), dt, st)))
+        twice(f'fwd mask_bits {name}', 'conv_fwd', vox * (cin + cout) * 2 + vox * nw * 4 + 27 * cin * cout * 2, flops,
+              lambda: _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep_mask), dt, st)))
+        twice(f'wgrad+dbias {name}', 'conv_wgrad', vox * (cin + cout) * 2 + 27 * cin * cout * 4, flops,
+              lambda: _lib.check(lib.sg_conv3d_wgrad_bias(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), 1.0,
+                                                          ws.data_ptr(), wsb, C.byref(shp), dt, st)))
+        if cin <= 32 and cout % 32 == 0:      # the fused first stage of downscale3d (sg_conv_epilogue.pool)
+            yp = torch.empty(n, d // 2, h, w // 2, cout, device=dev, dtype=torch.bfloat16)
+            ep_pool = ConvEpilogue(bias.data_ptr(), 1, 0.2, 0, 1e-8, None, None, 0.0, sout.data_ptr())
+            ep_pool.pool = 1
+            twice(f'fwd pooled (D x W mean) {name}', 'conv_fwd3s', vox * (cin + cout / 4) * 2 + vox * nw * 4 + 27 * cin * cout * 2, flops,
+                  lambda: _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), yp.data_ptr(), C.byref(shp), C.byref(ep_pool), dt, st)))
+        del x, dy, y, bits, sout, ws
+    # non-convolution kernels at the top level
+    for (n, d, h, w, c) in ((64, 32, 128, 128, 64), (32, 32, 128, 128, 32)):
+        vox = n * d * h * w
+        nw = (c + 31) // 32
+        x = torch.randn(n, d, h, w, c, device=dev).to(torch.bfloat16)
+        y = torch.randn_like(x)
+        z = torch.empty_like(x)
+        half = torch.empty(n, d // 2, h // 2, w // 2, c, device=dev, dtype=torch.bfloat16)
+        bits = torch.randint(-2 ** 31, 2 ** 31 - 1, (n, d, h, w, nw), device=dev, dtype=torch.int32)
+        db = torch.empty(c, device=dev)
+        ws = torch.empty(lib.sg_bias_act_bwd_workspace(c), device=dev, dtype=torch.uint8)
+        scale = torch.rand(vox, device=dev) + 0.5
+        name = f'n{n} {d}x{h}x{w} c{c}'
+        twice(f'downscale2x {name}', 'downscale2x', vox * c * 2 * (1 + 1 / 8), 0,
+              lambda: _lib.check(lib.sg_downscale2x(x.data_ptr(), half.data_ptr(), n, d, h, w, c, 0.125, dt, st)))
+        twice(f'upscale2x_masked {name}', 'upscale2x', vox * c * 2 * (1 + 1 / 8) + vox * nw * 4, 0,
+              lambda: _lib.check(lib.sg_upscale2x_masked(half.data_ptr(), z.data_ptr(), bits.data_ptr(), 0.2, n, d // 2, h // 2, w // 2, c, 0.125, dt, st)))
+        twice(f'bias_act_bwd_bits+db {name}', 'bias_act_bwd', vox * c * 2 * 2 + vox * nw * 4, 0,
+              lambda: _lib.check(lib.sg_bias_act_bwd_bits(x.data_ptr(), bits.data_ptr(), z.data_ptr(), db.data_ptr(), ws.data_ptr(), vox, c, 0.2, dt, st)))
+        twice(f'pixel_norm_act_bwd {name}', 'pixel_norm', vox * c * 2 * 3 + vox * (4 + nw * 4), 0,
+              lambda: _lib.check(lib.sg_pixel_norm_act_bwd(x.data_ptr(), y.data_ptr(), scale.data_ptr(), bits.data_ptr(), 0.2, z.data_ptr(), db.data_ptr(), ws.data_ptr(), vox, c, dt, st)))
+        del x, y, z, half, bits
+    out = os.path.join(ROOT, 'gpurun_out')
+    os.makedirs(out, exist_ok=True)
+    json.dump(manifest, open(os.path.join(out, 'pmc_manifest.json'), 'w'), indent=1)
 
 
 if __name__ == '__main__':

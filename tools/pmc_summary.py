@@ -1,60 +1,83 @@
-"""Turns the two rocprofv3 counter passes of tools/pmc_probe.py into profiles/<round>_pmc_traffic.json.
+"""Joins tools/pmc_probe.py's manifest with the rocprofv3 counter CSVs of its three passes.
 
-usage: python tools/pmc_summary.py gpurun_out/pmc_rd/rd_counter_collection.csv gpurun_out/pmc_wr/wr_counter_collection.csv \
-           profiles/r01_pmc_traffic.json
+usage: python tools/pmc_summary.py gpurun_out/pmc_manifest.json gpurun_out/pmc_rd/rd_counter_collection.csv \
+           gpurun_out/pmc_wr/wr_counter_collection.csv gpurun_out/pmc_mfma/mf_counter_collection.csv profiles/r02_pmc_traffic.json
 
 Corrections (MI355X_MICROARCH.md, HBM): FETCH_SIZE is in KiB and reports half of the bytes of wide coalesced reads on
-gfx950 -> doubled; WRITE_SIZE (KiB) is exact.  The calibration kernel in the probe (sg_axpby over 2^28 bf16: 1 GiB
-read, 0.5 GiB written) is checked against both before anything else is trusted."""
+gfx950 -> doubled; WRITE_SIZE (KiB) is exact.  The calibration launch of the probe (sg_axpby over 2^28 bf16: 1 GiB read,
+0.5 GiB written) is checked against both before anything else is trusted.  (What FETCH_SIZE reports for 32-byte sliver
+reads is calibrated separately: tools/probe/sliver_probe.hip.)  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel
+cycles), kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs; for v_mfma_f32_32x32x16_bf16 the busy cycles are 32 per instruction,
+which the summary cross-checks against FLOPs / 32768 per instruction."""
 import csv
 import json
 import sys
 
-from pmc_probe import SHAPES
 
-
-def load(path, counter):
-    rows = [r for r in csv.DictReader(open(path)) if r['Counter_Name'] == counter]
+def load(path):
+    rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     return rows
 
 
-def main():
-    rd, wr, out = sys.argv[1:4]
-    R, W = load(rd, 'FETCH_SIZE'), load(wr, 'WRITE_SIZE')
-    cal_r = [float(r['Counter_Value']) for r in R if 'axpby' in r['Kernel_Name']]
-    cal_w = [float(r['Counter_Value']) for r in W if 'axpby' in r['Kernel_Name']]
-    assert cal_r and abs(2 * cal_r[-1] / (1 << 20) - 1.0) < 0.02, ('FETCH_SIZE calibration', cal_r)
-    assert cal_w and abs(cal_w[-1] / (1 << 19) - 1.0) < 0.02, ('WRITE_SIZE calibration', cal_w)
+def per_dispatch(rows, counter):
+    out = {}
+    for r in rows:
+        if r['Counter_Name'] == counter:
+            out[int(r['Dispatch_Id'])] = (r['Kernel_Name'], float(r['Counter_Value']))
+    return [(k, *out[k]) for k in sorted(out)]
 
-    def convs(rows):
-        return [r for r in rows if any(k in r['Kernel_Name'] for k in ('conv_fwd', 'conv_wgrad'))]
-    cr, cw = convs(R), convs(W)
-    assert len(cr) == len(cw) == 6 * len(SHAPES), (len(cr), len(cw))
+
+def match(manifest, disp):
+    """For every manifest entry the LAST of its `repeats` matching dispatches, in order (first-touch effects gone)."""
+    res, pos = [], 0
+    for m in manifest:
+        found = []
+        while pos < len(disp) and len(found) < m['repeats']:
+            if m['match'] in disp[pos][1]:
+                found.append(disp[pos])
+            pos += 1
+        assert len(found) == m['repeats'], (m['tag'], len(found))
+        res.append(found[-1])
+    return res
+
+
+def main():
+    man_p, rd_p, wr_p, mf_p, out_p = sys.argv[1:6]
+    manifest = json.load(open(man_p))
+    R = match(manifest, per_dispatch(load(rd_p), 'FETCH_SIZE'))
+    W = match(manifest, per_dispatch(load(wr_p), 'WRITE_SIZE'))
+    mf = load(mf_p)
+    MB = match(manifest, per_dispatch(mf, 'SQ_VALU_MFMA_BUSY_CYCLES'))
+    GA = match(manifest, per_dispatch(mf, 'GRBM_GUI_ACTIVE'))
+    cal_r, cal_w = 2 * R[0][2] / (1 << 20), W[0][2] / (1 << 20)
+    assert abs(cal_r - 1.0) < 0.02 and abs(cal_w - 0.5) < 0.02, ('calibration', cal_r, cal_w)
     res = {'unit': 'bytes per launch', 'dtype': 'bf16',
            'correction': 'FETCH_SIZE KiB x 2 (gfx950 wide reads), WRITE_SIZE KiB x 1',
-           'calibration': {'axpby_read_GiB': 2 * cal_r[-1] / (1 << 20), 'axpby_write_GiB': cal_w[-1] / (1 << 20)},
-           'entries': []}
-    for i, (n, (d, h, w), cin, cout) in enumerate(SHAPES):
-        blk_r, blk_w = cr[6 * i:6 * i + 6], cw[6 * i:6 * i + 6]
-        vox = n * d * h * w
-        for j, (kind, variant) in enumerate((('fwd', 'bias+lrelu+sign_out'), ('fwd', 'mask_bits'), ('wgrad', 'with dbias'))):
-            # second repetition of each (index 3 + j): first touch effects gone
-            fr = 2.0 * float(blk_r[3 + j]['Counter_Value']) * 1024
-            fw = float(blk_w[3 + j]['Counter_Value']) * 1024
-            if kind == 'fwd':
-                alg = vox * (cin + cout) * 2 + 27 * cin * cout * 2
-            else:
-                alg = vox * (cin + cout) * 2 + 27 * cin * cout * 4
-            res['entries'].append({'kind': kind, 'variant': variant, 'kernel': blk_r[3 + j]['Kernel_Name'].split('(')[0][:60],
-                                   'shape': {'n': n, 'd': d, 'h': h, 'w': w, 'cin': cin, 'cout': cout, 'k': [3, 3, 3]},
-                                   'read_bytes': fr, 'write_bytes': fw, 'traffic_bytes': fr + fw,
-                                   'algorithmic_bytes': alg, 'traffic_over_algorithmic': (fr + fw) / alg})
-    json.dump(res, open(out, 'w'), indent=1)
+           'calibration': {'axpby_read_GiB': cal_r, 'axpby_write_GiB': cal_w}, 'entries': []}
+    for m, r, w, b, g in zip(manifest[1:], R[1:], W[1:], MB[1:], GA[1:]):
+        fr, fw = 2.0 * r[2] * 1024, w[2] * 1024
+        e = {'tag': m['tag'], 'kernel': r[1].split('(')[0][:70], 'read_bytes': fr, 'write_bytes': fw, 'traffic_bytes': fr + fw,
+             'algorithmic_bytes': m['algorithmic_bytes'], 'traffic_over_algorithmic': (fr + fw) / m['algorithmic_bytes']}
+        kind = 'fwd' if m['tag'].startswith('fwd') else ('wgrad' if m['tag'].startswith('wgrad') else 'elementwise')
+        e['kind'] = kind
+        if kind != 'elementwise':
+            import re
+            mm = re.search(r'n(\d+) (\d+)x(\d+)x(\d+) (\d+)->(\d+)', m['tag'])
+            n, d, h, w_, ci, co = (int(v) for v in mm.groups())
+            e['shape'] = {'n': n, 'd': d, 'h': h, 'w': w_, 'cin': ci, 'cout': co, 'k': [3, 3, 3]}
+            e['variant'] = m['tag'].split(' n')[0]
+            cycles = g[2] / 8.0
+            e['kernel_cycles'] = cycles
+            e['mfma_busy_cycles'] = b[2]
+            e['mfma_busy_frac'] = b[2] / (1024.0 * cycles) if cycles else None
+            e['mfma_busy_expected_from_flops'] = m['flops'] / 32768.0 * 32.0
+        res['entries'].append(e)
+    json.dump(res, open(out_p, 'w'), indent=1)
     for e in res['entries']:
-        s = e['shape']
-        print(f"{e['kind']:5s} {e['variant']:20s} {s['d']}x{s['h']}x{s['w']} {s['cin']:3d}->{s['cout']:3d} read {e['read_bytes'] / 1e6:8.1f} MB "
-              f"write {e['write_bytes'] / 1e6:8.1f} MB  alg {e['algorithmic_bytes'] / 1e6:8.1f} MB  x{e['traffic_over_algorithmic']:.2f}")
+        extra = f" mfma-busy {e['mfma_busy_frac']:.3f}" if e.get('mfma_busy_frac') is not None else ''
+        print(f"{e['tag']:58s} read {e['read_bytes'] / 1e6:9.1f} MB write {e['write_bytes'] / 1e6:9.1f} MB alg {e['algorithmic_bytes'] / 1e6:9.1f} MB "
+              f"x{e['traffic_over_algorithmic']:.2f}{extra}")
 
 
 if __name__ == '__main__':

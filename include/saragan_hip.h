@@ -162,6 +162,12 @@ int sg_upscale_nn(const void* x, void* y, const void* mask_bits, float mask_slop
                   int32_t w, int32_t c, int32_t fd, int32_t fh, int32_t fw, float gain, sg_dtype dt, sg_stream_t st);
 int sg_downscale_sum(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c, int32_t fd,
                      int32_t fh, int32_t fw, float gain, sg_dtype dt, sg_stream_t st);
+/* Trilinear x2 up-sampling with half-pixel centres (`align_corners=False`; BASELINE north_star names a trilinear
+ * resampler, the reference itself only has the nearest one): adjoint == 0: x [n,d,h,w,c] -> y [n,2d,2h,2w,c];
+ * adjoint != 0: the gradient, x = dy [n,2d,2h,2w,c] -> y = dx [n,d,h,w,c] ((d,h,w) is always the LOW-resolution
+ * extent).  Trilinear x2 down-sampling with half-pixel centres is the 2x2x2 mean: sg_downscale2x(gain 1/8). */
+int sg_trilinear_up2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c, int32_t adjoint,
+                      sg_dtype dt, sg_stream_t st);
 /* out = wa*a + wb*b     (fade-in lerp pgan/generator.py:100-101, pgan/discriminator.py:105; b may be NULL) */
 int sg_axpby(const void* a, const void* b, void* out, float wa, float wb, int64_t numel, sg_dtype dt,
              sg_stream_t st);

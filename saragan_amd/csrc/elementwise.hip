@@ -500,6 +500,122 @@ __global__ void downscale2x_kernel(const T* __restrict__ x, T* __restrict__ y, i
   }
 }
 
+// Trilinear x2 up-sampling (half-pixel centres, i.e. torch / TF2 `align_corners=False`): per axis
+//   out[2i] = 0.25 x[i-1] + 0.75 x[i],  out[2i+1] = 0.75 x[i] + 0.25 x[i+1]   (indices clamped at the borders)
+// and its adjoint (the gradient), written as a gather so that no atomics are needed: input voxel i receives
+//   0.25 g[2i-1] + w0 g[2i] + w1 g[2i+1] + 0.25 g[2i+2],  w0 = 0.75 (+0.25 at i = 0), w1 = 0.75 (+0.25 at i = n-1).
+// The reference has no trilinear op (nearest only); BASELINE north_star names one, so it is
+// offered next to upscale3d with torch's CPU interpolate as its oracle.  Trilinear x2 DOWN-sampling with half-pixel
+// centres samples exactly between two voxels per axis, i.e. it IS the 2x2x2 mean: sg_downscale2x(gain 1/8).
+__device__ __forceinline__ void tri_up_taps(int o, int n, int& i0, int& i1, float& w0, float& w1) {
+  const int i = o >> 1;
+  if (o & 1) { i0 = i; i1 = min(i + 1, n - 1); w0 = 0.75f; w1 = 0.25f; }
+  else { i0 = max(i - 1, 0); i1 = i; w0 = 0.25f; w1 = 0.75f; }
+}
+
+template <typename T, bool VEC>
+__global__ void trilinear_up2x_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int d, int h, int w, int c) {
+  constexpr int E = VEC ? Piece<T>::E : 1;
+  const int P = c / E;
+  const int64_t total = (int64_t)n * (2 * d) * (2 * h) * (2 * w) * P;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i % P);
+    int64_t q = i / P;
+    const int ow = (int)(q % (2 * w)); q /= 2 * w;
+    const int oh = (int)(q % (2 * h)); q /= 2 * h;
+    const int od = (int)(q % (2 * d));
+    const int nn = (int)(q / (2 * d));
+    int id[2], ih[2], iw[2];
+    float wd[2], wh[2], ww[2];
+    tri_up_taps(od, d, id[0], id[1], wd[0], wd[1]);
+    tri_up_taps(oh, h, ih[0], ih[1], wh[0], wh[1]);
+    tri_up_taps(ow, w, iw[0], iw[1], ww[0], ww[1]);
+    float acc[Piece<T>::E];
+#pragma unroll
+    for (int e = 0; e < Piece<T>::E; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int a = k >> 2, b = (k >> 1) & 1, cc = k & 1;
+      const float wt = wd[a] * wh[b] * ww[cc];
+      const int64_t src = ((((int64_t)nn * d + id[a]) * h + ih[b]) * w + iw[cc]) * c + (int64_t)p * E;
+      if (VEC) {
+        Piece<T> pc;
+        pc.load(x + src);
+#pragma unroll
+        for (int e = 0; e < Piece<T>::E; ++e) acc[e] += wt * pc.v[e];
+      } else {
+        acc[0] += wt * sg_traits<T>::to_f(x[src]);
+      }
+    }
+    if (VEC) {
+      Piece<T> o;
+#pragma unroll
+      for (int e = 0; e < Piece<T>::E; ++e) o.v[e] = acc[e];
+      o.store(y + i * E);
+    } else {
+      y[i] = sg_traits<T>::from_f(acc[0]);
+    }
+  }
+}
+
+// adjoint: g [n,2d,2h,2w,c] -> dx [n,d,h,w,c]
+template <typename T, bool VEC>
+__global__ void trilinear_up2x_adj_kernel(const T* __restrict__ g, T* __restrict__ dx, int n, int d, int h, int w, int c) {
+  constexpr int E = VEC ? Piece<T>::E : 1;
+  const int P = c / E;
+  const int64_t total = (int64_t)n * d * h * w * P;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int p = (int)(i % P);
+    int64_t q = i / P;
+    const int xw = (int)(q % w); q /= w;
+    const int xh = (int)(q % h); q /= h;
+    const int xd = (int)(q % d);
+    const int nn = (int)(q / d);
+    float wd[4], wh[4], ww[4];      // taps o = 2i-1 .. 2i+2 (weight 0 where o falls outside)
+    auto taps = [](int idx, int len, float (&wt)[4]) {
+      wt[0] = idx > 0 ? 0.25f : 0.f;
+      wt[1] = idx == 0 ? 1.0f : 0.75f;
+      wt[2] = idx == len - 1 ? 1.0f : 0.75f;
+      wt[3] = idx < len - 1 ? 0.25f : 0.f;
+    };
+    taps(xd, d, wd); taps(xh, h, wh); taps(xw, w, ww);
+    float acc[Piece<T>::E];
+#pragma unroll
+    for (int e = 0; e < Piece<T>::E; ++e) acc[e] = 0.f;
+    for (int a = 0; a < 4; ++a) {
+      if (wd[a] == 0.f) continue;
+      const int od = 2 * xd - 1 + a;
+      for (int b = 0; b < 4; ++b) {
+        if (wh[b] == 0.f) continue;
+        const int oh = 2 * xh - 1 + b;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+          const float wt = wd[a] * wh[b] * ww[cc];
+          if (ww[cc] == 0.f) continue;
+          const int ow = 2 * xw - 1 + cc;
+          const int64_t src = ((((int64_t)nn * 2 * d + od) * 2 * h + oh) * 2 * w + ow) * c + (int64_t)p * E;
+          if (VEC) {
+            Piece<T> pc;
+            pc.load(g + src);
+#pragma unroll
+            for (int e = 0; e < Piece<T>::E; ++e) acc[e] += wt * pc.v[e];
+          } else {
+            acc[0] += wt * sg_traits<T>::to_f(g[src]);
+          }
+        }
+      }
+    }
+    if (VEC) {
+      Piece<T> o;
+#pragma unroll
+      for (int e = 0; e < Piece<T>::E; ++e) o.v[e] = acc[e];
+      o.store(dx + i * E);
+    } else {
+      dx[i] = sg_traits<T>::from_f(acc[0]);
+    }
+  }
+}
+
 template <typename T>
 __global__ void axpby_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, float wa,
                              float wb, int64_t numel) {
@@ -902,6 +1018,29 @@ extern "C" int sg_downscale_sum(const void* x, void* y, int32_t n, int32_t d, in
 extern "C" int sg_downscale2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
                               float gain, sg_dtype dt, sg_stream_t st) {
   return sg_downscale_sum(x, y, n, d, h, w, c, 2, 2, 2, gain, dt, st);
+}
+
+extern "C" int sg_trilinear_up2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
+                                 int32_t adjoint, sg_dtype dt, sg_stream_t st) {
+  if (!x || !y || n < 1 || d < 1 || h < 1 || w < 1 || c < 1) return SG_EINVAL;
+  hipStream_t hs = sg_st(st);
+  const int E = dt == SG_BF16 ? 8 : 4;
+  const bool vec = (c % E == 0) && sg_aligned16(x) && sg_aligned16(y);
+  const int64_t items = (int64_t)n * d * h * w * (adjoint ? 1 : 8) * (vec ? c / E : c);
+  const int blocks = grid_for(items, 256, 8192);
+#define LU(T, V) hipLaunchKernelGGL((trilinear_up2x_kernel<T, V>), dim3(blocks), dim3(256), 0, hs, (const T*)x, (T*)y, n, d, h, w, c)
+#define LA(T, V) hipLaunchKernelGGL((trilinear_up2x_adj_kernel<T, V>), dim3(blocks), dim3(256), 0, hs, (const T*)x, (T*)y, n, d, h, w, c)
+  if (!adjoint) {
+    if (vec) SG_DISPATCH(dt, LU(bf16_t, true), LU(float, true));
+    else SG_DISPATCH(dt, LU(bf16_t, false), LU(float, false));
+  } else {
+    if (vec) SG_DISPATCH(dt, LA(bf16_t, true), LA(float, true));
+    else SG_DISPATCH(dt, LA(bf16_t, false), LA(float, false));
+  }
+#undef LU
+#undef LA
+  SG_LAUNCH_CHECK();
+  return SG_OK;
 }
 
 extern "C" int sg_axpby(const void* a, const void* b, void* out, float wa, float wb, int64_t numel, sg_dtype dt,

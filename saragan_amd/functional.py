@@ -670,6 +670,31 @@ class _Down(torch.autograd.Function):
         return _Up.apply(gy, ctx.gain, None, 0.0, ctx.factors), None, None, None
 
 
+class _TriUp(torch.autograd.Function):
+    """Trilinear x2 up-sampling, half-pixel centres (sg_trilinear_up2x); adjoint=True is its transpose (the gradient).
+    The two are each other's backward, so the pair is differentiable to any order."""
+
+    @staticmethod
+    def forward(ctx, x, adjoint):
+        lib = _lib.load()
+        _req_cuda(x)
+        x = ndhwc(x)
+        n, c, d, h, w = _dims(x)
+        if adjoint:
+            if (d | h | w) & 1:
+                raise ValueError('the adjoint takes a tensor of even extents')
+            d, h, w = d // 2, h // 2, w // 2
+        y = _empty_like_shape(x, c, (d, h, w) if adjoint else (2 * d, 2 * h, 2 * w))
+        check(lib.sg_trilinear_up2x(_ptr(x), _ptr(y), n, d, h, w, c, 1 if adjoint else 0, _dt(x), _stream()),
+              'sg_trilinear_up2x')
+        ctx.adjoint = adjoint
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        return _TriUp.apply(gy, not ctx.adjoint), None
+
+
 class _Axpby(torch.autograd.Function):
     """out = wa*a + wb*b (fade-in lerp, pgan/generator.py:100-101, pgan/discriminator.py:105)."""
 
@@ -767,6 +792,10 @@ def upscale2x(x, gain=1.0, factors=(2, 2, 2)):
 
 def downscale2x(x, gain=0.125, in_info=None, factors=(2, 2, 2)):
     return _Down.apply(x, gain, in_info, factors)
+
+
+def upscale_trilinear2x(x):
+    return _TriUp.apply(x, False)
 
 
 def lerp(a, b, wa, wb):

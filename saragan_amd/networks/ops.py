@@ -309,6 +309,21 @@ def upscale3d(x, factor=2):
     return _LazyUp(_val(x))
 
 
+def upscale3d_trilinear(x, factor=2):
+    """Trilinear alternative to upscale3d (half-pixel centres).  Not part of the reference's pgan (nearest only,
+    ops.py:276-289): offered because BASELINE north_star names it; the networks keep the reference's upscale3d."""
+    if factor == 1:
+        return x
+    if factor != 2:
+        raise NotImplementedError('only factor 2')
+    return F.upscale_trilinear2x(_val(x))
+
+
+def downscale3d_trilinear(x, factor=2):
+    """Trilinear x2 down-sampling with half-pixel centres samples midway between two voxels per axis: the 2x2x2 mean."""
+    return avg_pool3d(x, factor)
+
+
 def downscale3d(x, factor=2):
     """networks/ops.py:292-305."""
     return avg_pool3d(x, factor)

@@ -1,0 +1,101 @@
+"""Phase hand-off: the product's training loop over two phases (4x4x1 -> 8x8x2 with fade-in)
+against a CPU replay of the reference loop on the oracle (oracle/replay.py): the weights written to model_1 and
+model_2 (EMA-overwritten, quirk Q5), after restore-by-name, fresh Adam state, the alpha schedule, frozen previous-phase
+variables while mixing (Q4) and stabilising steps.  Same files, same shuffled batch order, same host-drawn randomness."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pgan_oracle as O
+from oracle import replay as R
+from tests.stepfix import BASE_SHAPE, FILTER_SPEC, KERNEL_SPEC, LATENT
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_random_source_class(F, L):
+    class HostRandom(L.RandomSource):
+        """z, both noise tensors and gamma from ONE host generator, in the order forward_simultaneous asks for them."""
+
+        def __init__(self, seed=0, device='cuda'):
+            self.g = torch.Generator().manual_seed(int(seed))
+
+        def latent(self, n, latent_dim, device):
+            return torch.randn(n, latent_dim, generator=self.g, dtype=torch.float64).float().to(device)
+
+        def gamma(self, n, device):
+            return torch.rand(n, 1, 1, 1, 1, generator=self.g, dtype=torch.float64).float().to(device)
+
+        def add_noise(self, x, stddev, tag):
+            noise = torch.randn(tuple(x.shape), generator=self.g, dtype=torch.float64).to(x.device, x.dtype)
+            return F.lerp(x, noise.contiguous(memory_format=torch.channels_last_3d), 1.0, float(stddev))
+    return HostRandom
+
+
+def test_two_phase_handoff_matches_oracle_replay(tmp_path, monkeypatch):
+    from saragan_amd import functional as F
+    from saragan_amd import train as T
+    from saragan_amd.dataset import NumpyPathDataset
+    from saragan_amd.networks import loss as L
+    from saragan_amd.utils import load_checkpoint
+    from saragan_amd.varstore import VariableStore
+    seed, mix, stab, bbs = 5, 8, 8, 4
+    rng = np.random.default_rng(0)
+    for size, shape in ((4, (1, 4, 4)), (8, (2, 8, 8))):
+        d = tmp_path / 'data' / f'{size}x{size}'
+        d.mkdir(parents=True)
+        for i in range(12):
+            np.save(d / f'{i:03d}.npy', np.clip(rng.normal(1024, 512, shape), 0, 4095).astype(np.int16))
+    monkeypatch.setattr(T.L, 'RandomSource', _make_random_source_class(F, L))
+    args = argparse.Namespace(
+        architecture='pgan', dataset_path=str(tmp_path / 'data'), start_shape=str(BASE_SHAPE), final_shape='(1, 2, 8, 8)',
+        starting_phase=1, ending_phase=2, scratch_path=None, base_batch_size=bbs, max_global_batch_size=None,
+        mixing_nimg=mix, stabilizing_nimg=stab, seed=seed, horovod=False, checkpoint_every_nsteps=10 ** 9,
+        logdir=str(tmp_path / 'run'), continue_path=None, starting_alpha=1.0, latent_dim=LATENT, activation='leaky_relu',
+        leakiness=0.2, kernel_spec=KERNEL_SPEC, filter_spec=FILTER_SPEC, g_lr=1e-3, d_lr=1e-3, g_lr_increase=None,
+        g_lr_decrease=None, g_lr_rise_niter=None, g_lr_decay_niter=None, d_lr_increase=None, d_lr_decrease=None,
+        d_lr_rise_niter=None, d_lr_decay_niter=None, g_scaling='none', d_scaling='none', g_clipping=False, d_clipping=False,
+        loss_fn='wgan', gp_weight=10.0, optim_strategy='simultaneous', ema_beta=0.9, noise_stddev=0.01, optimizer='Adam',
+        d_optimizer='Adam', adam_beta1=0.0, adam_beta2=0.9, d_adam_beta1=0.0, d_adam_beta2=0.9, data_mean=1024.0,
+        data_stddev=1024.0, dtype='f32')
+    out = T.run_training(args, log_every=10 ** 6)
+    assert out['stats'][1]['steps'] == 4 and out['stats'][2]['steps'] == 8 and out['stats'][2]['batch_size'] == 2
+
+    # ---- the oracle-side replay with the same initial values, batch order and randomness
+    init_store = VariableStore('cpu', seed=seed)            # the product's initialiser: N(0,1) / zeros in creation order
+
+    def new_variable(name, shape):
+        return init_store.get(name, tuple(shape), 'normal' if name.endswith('weight') else 'zeros').detach().double()
+
+    def batches(phase, bs):
+        size = 4 * 2 ** (phase - 1)
+        ds = NumpyPathDataset(os.path.join(args.dataset_path, f'{size}x{size}/'), None, False, True, seed=seed)
+        while True:
+            b = ds.batch(bs)
+            yield torch.as_tensor((b - np.float32(1024.0)) / np.float32(1024.0)).double()
+
+    def randomness(phase, n, img):
+        g = torch.Generator().manual_seed(seed * 1000 + phase)
+        while True:
+            z = torch.randn(n, LATENT, generator=g, dtype=torch.float64).float().double()
+            nr = torch.randn((n, *img), generator=g, dtype=torch.float64).float().double()
+            nf = torch.randn((n, *img), generator=g, dtype=torch.float64).float().double()
+            gm = torch.rand(n, 1, 1, 1, 1, generator=g, dtype=torch.float64).float().double()
+            yield dict(z=z, noise_real=nr, noise_fake=nf, gamma=gm)
+
+    want = R.replay(2, BASE_SHAPE, LATENT, KERNEL_SPEC, FILTER_SPEC, bbs, mix, stab, 1.0, 1e-3, 0.9, 'wgan', 10.0, 0.01,
+                    new_variable, batches, randomness)
+    for phase in (1, 2):
+        got = load_checkpoint(os.path.join(out['logdir'], f'model_{phase}'))
+        assert set(got) == set(want[phase]), phase
+        for k, ref in want[phase].items():
+            # twelve Adam steps from fp32 kernels vs the fp64 replay: elements whose gradient is ~0 may have stepped the
+            # other way once or twice (EMA beta 0.9 keeps ~2/3 of such a 2e-3 difference)
+            d = np.abs(got[k].astype(np.float64) - ref.numpy())
+            assert float(d.max()) <= 6e-3, (phase, k, float(d.max()))
+            assert float((d > 2e-4).mean()) <= 0.02, (phase, k, float((d > 2e-4).mean()))
+    # phase 2 started from model_1: a variable both phases share moved only while stabilising (frozen while mixing)
+    assert 'generator/to_rgb_1/weight' in want[2] and 'generator/to_rgb_1/weight' in want[1]

@@ -502,3 +502,31 @@ def test_conv_epilogue_fused_downscale():
     _mostly_close(g2g, g2r, 2e-2, 2e-2, 'second-order dw', max_bad=5e-3)
     # requests no kernel fuses (f32 storage) are refused, not mis-computed
     assert F.raw_conv(xg.float(), wg, coef, False, bias=bg, act=True, want_signs=True, pool=True) is None
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('shape', [(2, 16, 3, 5, 7), (1, 6, 4, 4, 4), (2, 32, 1, 8, 8)])
+def test_trilinear_up2x_and_adjoint(shape, dtype):
+    """Trilinear x2 (half-pixel centres) against torch's CPU interpolate(mode='trilinear', align_corners=False) in fp64:
+    forward, gradient (the adjoint kernel), second order, and down-sampling == the 2x2x2 mean."""
+    import torch.nn.functional as TF
+    from saragan_amd import functional as F
+    x = rnd(shape, 71, dtype)
+    xr = x.clone().requires_grad_(True)
+    yr = TF.interpolate(xr, scale_factor=2, mode='trilinear', align_corners=False)
+    xg = cl(x, dtype).requires_grad_(True)
+    yg = F.upscale_trilinear2x(xg)
+    close(yg, yr, dtype, 'trilinear up')
+    gy = rnd(tuple(yr.shape), 72, dtype)
+    (gxr,) = torch.autograd.grad(yr, xr, gy, create_graph=True)
+    (gxg,) = torch.autograd.grad(yg, xg, cl(gy, dtype), create_graph=True)
+    close(gxg, gxr, dtype, 'trilinear adjoint')
+    (ggr,) = torch.autograd.grad((gxr * gxr).sum(), xr, allow_unused=True)
+    assert ggr is None                      # linear op: no second-order term w.r.t. x
+    gy2 = cl(gy, dtype).requires_grad_(True)
+    gx2 = torch.autograd.grad(F.upscale_trilinear2x(xg), xg, gy2, create_graph=True)[0]
+    (back,) = torch.autograd.grad(gx2, gy2, cl(x, dtype))       # adjoint of the adjoint = the forward op
+    close(back, yr, dtype, 'adjoint of the adjoint')
+    if all(s % 2 == 0 for s in shape[2:]):
+        dn = TF.interpolate(x, scale_factor=0.5, mode='trilinear', align_corners=False)
+        close(F.downscale2x(cl(x, dtype)), dn, dtype, 'trilinear down == 2x2x2 mean')

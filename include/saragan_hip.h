@@ -87,6 +87,11 @@ typedef struct {
    * needs).  Only the sliding-halo kernel implements it (bf16, 3x3x3, cin <= 32, w % 32 == 0, cout % 32 == 0, even
    * d and h, no pixel-norm / mask): anything else returns SG_EUNSUPPORTED and the caller runs conv + downscale. */
   int32_t pool;
+  /* Optional scratch for layers the library computes in two passes over halves of the input channels (64 -> 32 at
+   * 3x3x3, bf16: f32 partial sums of the first half, n*d*h*w*cout*4 bytes, 16-byte aligned, contents irrelevant on
+   * entry).  NULL: such layers run as one pass of the streamed kernel.  sg_conv3d_fwd_workspace() gives the size. */
+  void* workspace;
+  size_t workspace_bytes;
 } sg_conv_epilogue;
 
 /* Sign words of an NDHWC tensor t[nvox][c]: uint32 words[nvox][ceil(c/32)], bit j of word (v, k) = (t[v][32k+j] < 0),
@@ -105,6 +110,8 @@ size_t sg_conv3d_packed_bytes(const sg_conv_shape* s, sg_dtype dt);
  * (kD,kH,kW) and transposed in (I,O) (what tf's Conv3DBackpropInputV2 computes for stride 1). */
 int sg_conv3d_pack_weights(const float* w_dhwio, float coef, int transpose_flip, void* wp,
                            const sg_conv_shape* s, sg_dtype dt, sg_stream_t st);
+/* Bytes of sg_conv_epilogue.workspace that let this shape take its fastest path (0: none needed). */
+size_t sg_conv3d_fwd_workspace(const sg_conv_shape* s, sg_dtype dt);
 /* y = epilogue(conv3d(x, wp)).  x: [n,d,h,w,cin] (or half-res if upsample_in), y: [n,d,h,w,cout]. */
 int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_conv_shape* s,
                   const sg_conv_epilogue* ep, sg_dtype dt, sg_stream_t st);

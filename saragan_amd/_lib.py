@@ -23,7 +23,8 @@ class ConvEpilogue(C.Structure):
                 ('bias', C.c_void_p), ('act', C.c_int32), ('slope', C.c_float), ('pixel_norm', C.c_int32),
                 ('eps', C.c_float), ('pn_scale', C.c_void_p), ('mask_bits', C.c_void_p), ('mask_slope', C.c_float),
                 ('sign_out', C.c_void_p), ('out_scale', C.c_int32), ('out_off', C.c_int32 * 3),
-                ('tap_off', C.c_int32 * 3), ('pool', C.c_int32)]
+                ('tap_off', C.c_int32 * 3), ('pool', C.c_int32), ('workspace', C.c_void_p),
+                ('workspace_bytes', C.c_size_t)]
 
     def __init__(self, *args, **kw):
         super().__init__(C.sizeof(type(self)), *args, **kw)
@@ -43,6 +44,7 @@ SIGNATURES = {
     'sg_error_string': (C.c_char_p, [C.c_int]),
     'sg_conv3d_packed_bytes': (_sz, [_SHP, C.c_int]),
     'sg_conv3d_pack_weights': (C.c_int, [_p, _f, C.c_int, _p, _SHP, C.c_int, _p]),
+    'sg_conv3d_fwd_workspace': (_sz, [_SHP, C.c_int]),
     'sg_conv3d_fwd': (C.c_int, [_p, _p, _p, _SHP, C.POINTER(ConvEpilogue), C.c_int, _p]),
     'sg_conv3d_wgrad_workspace': (_sz, [_SHP, C.c_int]),
     'sg_conv3d_wgrad': (C.c_int, [_p, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),

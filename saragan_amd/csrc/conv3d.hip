@@ -116,6 +116,8 @@ struct ConvFwdArgs {
   int wres;             // v4: all weight slabs resident in LDS
   int lean;             // v4: input below 2 GiB and no fused up-sampling: buffer addressing for the halo
   int tap_d, tap_h, tap_w;   // added to the tap index when addressing the halo (sub-pixel classes)
+  int xcs, xco;              // sliding-halo kernel: channels per voxel of the x TENSOR and first channel of the slice convolved (K split)
+  const float* addend;       // sliding-halo kernel, second K-split pass: the first pass's f32 partial sums [voxel][cout]
   int pool;                  // 1: y is the D x W mean-pooled output [n, D/2, H, W/2, cout] (sliding-halo kernel only)
   int os, oa, ob, oc;        // output scatter: os == 2 writes voxel (2d+oa, 2h+ob, 2w+oc) of a [n,2D,2H,2W,cout] tensor
   unsigned long long* dbg;  // diagnostic time stamps (NULL in production)
@@ -1140,7 +1142,7 @@ struct sg_unrolled_ks2 {
   }
 };
 
-template <typename T, int GC>
+template <typename T, int GC, int KS>   // KS: 0 whole layer; 1 / 2: first / second pass of a layer split over its input channels
 __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TAPS = 27;
@@ -1174,7 +1176,8 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + n0 * sample_bytes, 0,
                                              (int)sample_bytes, 0x00020000);
   };
-  const int64_t xsb = svox * a.cin * ES, ysb = svox * a.cout * ES, wsb = svox * a.ntile * 4, psb = svox * 4;
+  const int64_t xsb = svox * a.xcs * ES, ysb = svox * a.cout * (KS == 1 ? 4 : ES), wsb = svox * a.ntile * 4, psb = svox * 4;
+  const int64_t asb = svox * a.cout * 4;                   // f32 addend, per sample
 
   // column schedule: a block walks PAIRS of H-adjacent tile columns along D, wave group g taking the column with
   // tile row 2*k + g, one phase apart: the two halo rows the pair shares are fetched twice within ~2 us on the same
@@ -1214,7 +1217,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
     const int hh_ = row / 34, hw = row - hh_ * 34;
     const int c = p * EPP;
     const bool live = row < 204 && c < a.cin && (wave + 4 * k) < PPIECES;
-    relb[k] = live ? (uint32_t)(((hh_ * g.W + hw) * a.cin + c) * ES) : 0xC0000000u;   // stays >= DEAD after + tile offset
+    relb[k] = live ? (uint32_t)(((hh_ * g.W + hw) * a.xcs + a.xco + c) * ES) : 0xC0000000u;   // stays >= DEAD after + tile offset
     crdp[k] = live ? (hw | (hh_ << 8)) : 0x7F7F;
   }
   // LDS position of my piece inside its 1-KiB block: slot p of row lands at p ^ f(row), and f(row) only depends on
@@ -1228,7 +1231,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
     yvo[mt] = (uint32_t)((v * a.cout + nt0 * 32) * ES);
     svo[mt] = (uint32_t)(v * a.ntile + nt0) * 4u;
   }
-  const uint32_t plane_bytes = (uint32_t)(g.H * g.W * a.cin * ES);
+  const uint32_t plane_bytes = (uint32_t)(g.H * g.W * a.xcs * ES);
 
   struct Item { int n0, d0, h0, w0, di; };
   auto item_of = [&](int q) {
@@ -1247,7 +1250,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
 
   // per-lane offsets of my pieces for the tile at o (same for all of its planes)
   auto piece_offsets = [&](const Item& o, uint32_t (&vk)[MAXP]) {
-    const int tile_off = ((o.h0 - 1) * g.W + (o.w0 - 1)) * a.cin * ES;   // may be negative: only dead lanes go below 0
+    const int tile_off = ((o.h0 - 1) * g.W + (o.w0 - 1)) * a.xcs * ES;   // may be negative: only dead lanes go below 0
     const bool hw_interior = o.h0 >= 1 && o.w0 >= 1 && o.h0 + 5 <= g.H && o.w0 + 33 <= g.W;
     if (hw_interior) {
 #pragma unroll
@@ -1289,6 +1292,24 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
     }
   };
 
+  // K-split second pass: the first pass's f32 partial sums of tile o go straight into the (free) accumulators
+  // during the off-phase before the tile's MFMA phase; the other wave group's MFMA phase covers their latency
+  f32x16 acc[2];
+  auto load_partial = [&](const Item& o) {
+    const __amdgpu_buffer_rsrc_t ra = rsrc_of(a.addend, asb, o.n0);
+    const uint32_t soff = (uint32_t)((o.d0 * g.H + o.h0) * g.W + o.w0) * (uint32_t)(a.cout * 4);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const bool ok = o.h0 + wave < g.H && o.d0 + mt < g.D;
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            ra, ok ? (uint32_t)((((mt * g.H + wave) * g.W + r) * a.cout + nt0 * 32 + 8 * qd + 4 * hh) * 4) : DEAD, soff, 0));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[mt][4 * qd + e] = v[e];
+      }
+    }
+  };
   // resident weights (all 8 waves) and bias
   {
     constexpr int nfrag = TAPS * GC;
@@ -1313,13 +1334,13 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
     store_planes(o0, 0, stg);
     load_planes(o0, 2, vk, stg);
     store_planes(o0, 2, stg);
+    if (KS == 2) load_partial(o0);
   }
   __syncthreads();
 
   const int wl_off = (int)(wlds - smem) + lane * 16;
   const float inv_c = 1.f / (float)a.cout;
   const bool wide_store = ES == 2 && (a.cout % 8 == 0) && nt0 * 32 + 32 <= a.cout && !(a.dbg_flags & 16);
-  f32x16 acc[2];
 
   int dbgi = 0;
   auto stamp = [&]() {
@@ -1336,7 +1357,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc[mt][i] = bias_lds[(i & 3) + 8 * (i >> 2) + 4 * hh];   // bias rides in C
+          for (int i = 0; i < 16; ++i) acc[mt][i] = bias_lds[(i & 3) + 8 * (i >> 2) + 4 * hh] + (KS == 2 ? acc[mt][i] : 0.f);   // bias (+ partial) rides in C
         const int di = q % g.nTd;
         if (a.dbg_flags & 8) { /* diagnostic: no MFMA phase */ }
         else if (a.dbg_flags & 32) {   // diagnostic: the 9-reads-per-6-MFMAs loop
@@ -1379,6 +1400,17 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
           const bool ok = row_ok && o.d0 + mt < g.D;   // uniform
+          if (KS == 1) {     // K-split first pass: the accumulators as they stand, 4 x 16 bytes per lane
+            const __amdgpu_buffer_rsrc_t ryf = rsrc_of(a.y, ysb, o.n0);
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+              f32x4 v4 = {acc[mt][4 * qd], acc[mt][4 * qd + 1], acc[mt][4 * qd + 2], acc[mt][4 * qd + 3]};
+              if (ok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), ryf,
+                                                             (uint32_t)((((mt * g.H + wave) * g.W + r) * a.cout + nt0 * 32 + 8 * qd + 4 * hh) * 4),
+                                                             tile_vox * (uint32_t)(a.cout * 4), 0);
+            }
+            continue;
+          }
           if (a.act) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][i] = fmaxf(acc[mt][i], acc[mt][i] * a.slope);
@@ -1460,6 +1492,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (KS == 2 && qn < items_mine) load_partial(on);
       if (restage) store_planes(on, 2, stg);
     }
     stamp();
@@ -1467,7 +1500,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   }
 }
 
-template <typename T, int GC>
+template <typename T, int GC, int KS = 0>
 static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used) {
   *used = false;
   if (s->upsample_in || s->kd != 3 || s->kh != 3 || s->kw != 3) return SG_OK;
@@ -1479,7 +1512,7 @@ static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
   {   // buffer addressing (rebased per sample): one sample of every tensor this kernel touches stays below 2 GiB
     const int64_t svox = (int64_t)s->d * s->h * s->w;
     const int es = (int)sizeof(T);
-    if (svox * s->cin * es >= (1ll << 31) || svox * s->cout * es >= (1ll << 31) || svox * a.ntile * 4 >= (1ll << 31)) return SG_OK;
+    if (svox * a.xcs * es >= (1ll << 31) || svox * s->cout * 4 >= (1ll << 31) || svox * a.ntile * 4 >= (1ll << 31)) return SG_OK;
   }
   int gx = (256 / a.ntile) / 8 * 8;
   if (gx < 8) gx = 8;
@@ -1491,9 +1524,9 @@ static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
   a.rs = GC * 32;
   a.vec_in = 1;
   a.vec_out = (s->cout % 4 == 0) ? 1 : 0;
-  auto kern = conv_fwd3s_kernel<T, GC>;
+  auto kern = conv_fwd3s_kernel<T, GC, KS>;
   SG_ALLOW_160K_LDS(kern);
-  SG_KNAME("conv_fwd3s<%s,%d>", sg_tname<T>(), GC);
+  SG_KNAME(KS ? "conv_fwd3s<%s,%d> K-split" : "conv_fwd3s<%s,%d>", sg_tname<T>(), GC);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.ntile), dim3(512), lds, st, a);
   SG_LAUNCH_CHECK();
   *used = true;
@@ -2110,6 +2143,13 @@ static int launch_pw_fwd(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st,
 static unsigned long long* g_dbg_ts = nullptr;
 extern "C" __attribute__((visibility("default"))) void sg_debug_set_ts_buffer(void* p) { g_dbg_ts = (unsigned long long*)p; }
 
+extern "C" size_t sg_conv3d_fwd_workspace(const sg_conv_shape* s, sg_dtype dt) {
+  if (!conv_shape_ok(s) || dt != SG_BF16) return 0;
+  if (s->kd == 3 && s->kh == 3 && s->kw == 3 && s->cin == 64 && s->cout <= 32 && !s->upsample_in && s->w % 32 == 0 && s->d >= 4)
+    return (size_t)s->n * s->d * s->h * s->w * (size_t)s->cout * 4;
+  return 0;
+}
+
 extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_conv_shape* s,
                              const sg_conv_epilogue* ep, sg_dtype dt, sg_stream_t st) {
   if (!conv_shape_ok(s) || !x || !wp || !y) return SG_EINVAL;
@@ -2129,6 +2169,7 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
   a.tap_d = ep ? ep->tap_off[0] : 0; a.tap_h = ep ? ep->tap_off[1] : 0; a.tap_w = ep ? ep->tap_off[2] : 0;
   a.pool = ep ? ep->pool : 0;
   if (a.pool != 0 && a.pool != 1) return SG_EINVAL;
+  a.xcs = s->cin; a.xco = 0; a.addend = nullptr;
   a.os = (ep && ep->out_scale == 2) ? 2 : 1;
   a.oa = ep ? ep->out_off[0] : 0; a.ob = ep ? ep->out_off[1] : 0; a.oc = ep ? ep->out_off[2] : 0;
   const bool subpixel = a.os == 2 || a.tap_d || a.tap_h || a.tap_w || s->kd == 2;
@@ -2169,6 +2210,31 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     bool used = false;
     rc = SG_OK;
     const bool k333 = s->kd == 3 && s->kh == 3 && s->kw == 3, k133 = s->kd == 1 && s->kh == 3 && s->kw == 3;
+    if (dt == SG_BF16 && k333 && !sg_cfg().fwd_no_v3s && !sg_cfg().fwd_no_v5 && a.nchunk == 4 && a.ntile == 1 && s->cin == 64 &&
+        !s->upsample_in && !a.pool && !a.pixel_norm && ep && ep->workspace &&
+        ep->workspace_bytes >= (size_t)s->n * s->d * s->h * s->w * (size_t)s->cout * 4 && sg_aligned16(ep->workspace)) {
+      // K split: 64 input channels as two sliding-halo passes over 32 channels each (resident weights, a 64-byte
+      // half of every 128-byte channel row fetched ONCE per pass) with the f32 partial sums in the caller's workspace.
+      // The streamed kernel fetches every row as four 32-byte slivers in four passes too far apart for L2: each
+      // sliver costs a whole line (tools/probe/sliver_probe.hip), 3.1x the algorithmic traffic, 0.27 of MFMA peak.
+      ConvFwdArgs p1 = a, p2 = a;
+      sg_conv_shape sh = *s;
+      sh.cin = 32;
+      p1.cin = p2.cin = 32; p1.nchunk = p2.nchunk = 2; p1.xcs = p2.xcs = 64;
+      p1.xco = 0; p1.y = ep->workspace; p1.bias = nullptr; p1.act = 0; p1.mask_bits = nullptr; p1.sign_out = nullptr;
+      p2.xco = 32; p2.addend = reinterpret_cast<const float*>(ep->workspace);
+      p2.wp = reinterpret_cast<const char*>(a.wp) + (size_t)2 * a.taps * a.ntile * 1024;   // chunks 2, 3 of the packed image
+      bool u1 = false, u2 = false;
+      rc = launch_fwd3s<bf16_t, 2, 1>(p1, &sh, hs, &u1);
+      if (rc == SG_OK && u1) {
+        rc = launch_fwd3s<bf16_t, 2, 2>(p2, &sh, hs, &u2);
+        if (rc == SG_OK && !u2) rc = SG_EINVAL;     // same geometry as pass 1: cannot decline
+        SG_KNAME("conv_fwd3s<bf16,2> x2 (K split)");
+        prof.done(rc);
+        return rc;
+      }
+      if (rc != SG_OK) { prof.done(rc); return rc; }
+    }
     if (dt == SG_BF16 && k333 && !sg_cfg().fwd_no_v3s) {   // sliding-halo variant where its tile fits
       if (a.nchunk == 2) rc = launch_fwd3s<bf16_t, 2>(a, s, hs, &used);
       else if (a.nchunk == 1) rc = launch_fwd3s<bf16_t, 1>(a, s, hs, &used);

@@ -224,6 +224,10 @@ def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel
     ep = ConvEpilogue(_ptr(b32), 1 if act else 0, float(slope), 1 if pixel_norm else 0, float(eps), _ptr(scale),
                       _ptr(mask_bits), float(mask_slope), _ptr(signs))
     ep.pool = 1 if pool else 0
+    ws_bytes = lib.sg_conv3d_fwd_workspace(C.byref(shp), dt)
+    if ws_bytes and not pool:      # scratch for the library's two-pass (K-split) path of this layer
+        ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
+        ep.workspace, ep.workspace_bytes = ws.data_ptr(), ws_bytes
     rc = lib.sg_conv3d_fwd(_ptr(x), _ptr(wp), _ptr(y), C.byref(shp), C.byref(ep), dt, st)
     if pool and rc == _lib.SG_EUNSUPPORTED:
         return None

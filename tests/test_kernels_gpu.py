@@ -504,6 +504,62 @@ def test_conv_epilogue_fused_downscale():
     assert F.raw_conv(xg.float(), wg, coef, False, bias=bg, act=True, want_signs=True, pool=True) is None
 
 
+def test_conv_64_to_32_split_over_input_channels(sg_env):
+    """The 64 -> 32 channel 3x3x3 bf16 layers run as two sliding-halo passes over 32 input channels each, f32 partial
+    sums in sg_conv_epilogue.workspace (sg_conv3d_fwd_workspace).  Same inputs through the split path, through the
+    streamed single-pass kernel (SG_FWD_NO_V5=1) and through the oracle: bias, LeakyReLU, recorded sign words and the
+    masked (second-order) epilogue; ragged H (a dead row in the last tile pair) and odd D."""
+    import ctypes as C
+    from saragan_amd import functional as F, _lib
+    dtype = torch.bfloat16
+    n, cin, cout, sp = 2, 64, 32, (5, 22, 64)
+    x = rnd((n, cin, *sp), 71, dtype)
+    w = rnd((3, 3, 3, cin, cout), 72, dtype)
+    b = rnd((cout,), 73, torch.float32) * 0.3
+    coef = O.runtime_coef(w.shape, 'leaky_relu', 0.2)
+    wq = (w * coef).to(dtype).double() / coef
+    yr = O.act(O.apply_bias(O.conv3d(x.double(), wq, 'leaky_relu', 0.2), b.double()), 'leaky_relu', 0.2)
+    lin = O.apply_bias(O.conv3d(x.double(), wq, 'leaky_relu', 0.2), b.double())
+    xg, wg, bg = cl(x, dtype), w.float().to(dev()), b.float().to(dev())
+    lib = _lib.load()
+    shp = _lib.ConvShape(n, *sp, cin, cout, 3, 3, 3, 0)
+    assert lib.sg_conv3d_fwd_workspace(C.byref(shp), _lib.SG_BF16) == n * sp[0] * sp[1] * sp[2] * cout * 4
+
+    def kernels_of(fn):
+        lib.sg_prof_enable(1)
+        out = fn()
+        torch.cuda.synchronize()
+        ents = (_lib.ProfEntry * 64)()
+        cnt = C.c_int32(0)
+        lib.sg_prof_collect(ents, 64, C.byref(cnt))
+        lib.sg_prof_enable(0)
+        return out, [ents[i].kernel.decode() for i in range(cnt.value)]
+
+    (y2, s2), names = kernels_of(lambda: F.raw_conv(xg, wg, coef, False, bias=bg, act=True, want_signs=True)[::2])
+    assert any('K split' in k for k in names), names
+    sg_env(SG_FWD_NO_V5=1)
+    (y1, s1), names1 = kernels_of(lambda: F.raw_conv(xg, wg, coef, False, bias=bg, act=True, want_signs=True)[::2])
+    assert not any('K split' in k for k in names1) and any('conv_fwd4' in k for k in names1), names1
+    sg_env(SG_FWD_NO_V5=0)
+    close(y2, yr, dtype, 'split 64 -> 32')
+    close(y1, yr, dtype, 'streamed 64 -> 32')
+    # f32 partial sums in both: the two paths round the same f32 sums to bf16 (summation order differs by a few ulp of f32)
+    d = (y2.float() - y1.float()).abs()
+    assert float((d > 0).float().mean()) < 2e-3 and float(d.max()) <= 2.0 ** -6 * float(yr.abs().max()), (float(d.max()),)
+    # sign words: equal except where the pre-activation is within rounding of zero
+    flips = (s2 != s1)
+    if bool(flips.any()):
+        near0 = (lin.abs() < 1e-4 * float(lin.abs().max())).float().mean()
+        assert float(flips.float().mean()) <= 64 * float(near0) + 1e-6, (float(flips.float().mean()), float(near0))
+    # masked epilogue (the double-backward path): mask = recorded signs
+    ym2 = F.raw_conv(xg, wg, coef, False, mask_bits=s1, mask_slope=0.2)[0]
+    sg_env(SG_FWD_NO_V5=1)
+    ym1 = F.raw_conv(xg, wg, coef, False, mask_bits=s1, mask_slope=0.2)[0]
+    sg_env(SG_FWD_NO_V5=0)
+    dm = (ym2.float() - ym1.float()).abs()
+    assert float(dm.max()) <= 2.0 ** -6 * float(ym1.float().abs().max()), float(dm.max())
+
+
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('shape', [(2, 16, 3, 5, 7), (1, 6, 4, 4, 4), (2, 32, 1, 8, 8)])
 def test_trilinear_up2x_and_adjoint(shape, dtype):

@@ -49,7 +49,7 @@ def test_gpu_swd_matches_oracle():
     got = G.get_descriptors_for_minibatch(x, (2, 8, 8), 16)
     np.testing.assert_array_equal(got.cpu().numpy(), want)
     np.random.seed(9)
-    want = M.get_swd_for_volumes(x, y, nhoods_per_image=32, dir_repeats=2, dirs_per_repeat=64)
+    want = M.get_swd_for_volumes(x.copy(), y.copy(), nhoods_per_image=32, dir_repeats=2, dirs_per_repeat=64)   # (in place)
     np.random.seed(9)
     got = G.get_swd_for_volumes(x, y, nhoods_per_image=32, dir_repeats=2, dirs_per_repeat=64)
     assert len(got) == len(want) == 3

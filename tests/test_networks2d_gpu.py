@@ -75,7 +75,7 @@ def test_pgan_2d_step_matches_oracle(alpha):
     for hv, grads, refs in ((gv, gg, ref['g_grads']), (dv, dg, ref['d_grads'])):
         assert [v.key for v in hv] == list(refs.keys())
         for v, g_ in zip(hv, grads):
-            assert rel_l2(g_, refs[v.key].reshape(g_.shape)) <= 5e-3, v.key      # 2-4 channel layers: f32 noise shows
+            assert rel_l2(g_, refs[v.key].reshape(g_.shape)) <= 1e-2, v.key      # 2-4 channel layers: f32 noise shows
     for k_, v in store.vars.items():
         assert_adam_close(v, p[k_].reshape(v.shape), 1e-3, 1e-4, k_)
 

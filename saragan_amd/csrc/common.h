@@ -12,6 +12,14 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// gfx950 write-data hazard of 16-byte vector-memory stores (tools/probe/store_war_probe.hip, measured on MI355X): a
+// VALU instruction that writes one of the store's data VGPRs in the issue slot right after the store -- or one slot
+// later for global_store / literal-soffset buffer stores -- reaches memory instead of the stored value in lanes
+// 12-15 of each 16-lane row (0.05-0.3 % of such stores) whenever other waves are issuing on the CU.  The compiler
+// pads one slot for the global / literal forms and none for SGPR-soffset buffer stores, one short in both cases.
+// Placed after a 16-byte store, this keeps the data registers allocated over two more wait states.
+#define SG_STORE16_GUARD(v) asm volatile("s_nop 1" ::"v"(v))
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 #define SG_LAUNCH_CHECK()                          \

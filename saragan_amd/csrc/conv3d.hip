@@ -171,6 +171,7 @@ __device__ __forceinline__ void sg_store_tile_row_bf16(bf16_t* row32, const f32x
     u32x4 out;
     out[0] = s0[0]; out[1] = s1[0]; out[2] = s0[1]; out[3] = s1[1];
     if (ok) *reinterpret_cast<u32x4*>(row32 + 16 * j + 8 * hh) = out;
+    SG_STORE16_GUARD(out);
   }
 }
 
@@ -232,7 +233,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[MTW][NTB], const int
             if (sizeof(T) == 2)
               *reinterpret_cast<u32x2*>(yrow + co) = *reinterpret_cast<u32x2*>(tmp);
             else
-              *reinterpret_cast<u32x4*>(yrow + co) = *reinterpret_cast<u32x4*>(tmp);
+              { const u32x4 t16 = *reinterpret_cast<u32x4*>(tmp); *reinterpret_cast<u32x4*>(yrow + co) = t16; SG_STORE16_GUARD(t16); }
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -983,7 +984,7 @@ __global__ __launch_bounds__(512) void conv_fwd3r_kernel(ConvFwdArgs a) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) tmp[e] = sg_traits<T>::from_f(acc[mt][qd * 4 + e]);
                 if (sizeof(T) == 2) *reinterpret_cast<u32x2*>(yrow + co) = *reinterpret_cast<u32x2*>(tmp);
-                else *reinterpret_cast<u32x4*>(yrow + co) = *reinterpret_cast<u32x4*>(tmp);
+                else { const u32x4 t16 = *reinterpret_cast<u32x4*>(tmp); *reinterpret_cast<u32x4*>(yrow + co) = t16; SG_STORE16_GUARD(t16); }
               } else {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -1142,20 +1143,28 @@ struct sg_unrolled_ks2 {
   }
 };
 
-template <typename T, int GC, int KS>   // KS: 0 whole layer; 1 / 2: first / second pass of a layer split over its input channels
+// Epilogue features of the sliding-halo kernel, compile-time: the off-phase of the generic (run-time flags) version
+// spent most of its ~4.3k cycles on scalar bookkeeping -- 200 spilled SGPRs (v_readlane), kernel arguments re-read
+// from memory behind s_waitcnt lgkmcnt(0), branches around features the launch did not use.
+enum : int { SG_EP_SIGN = 1, SG_EP_MASK = 2, SG_EP_PN = 4, SG_EP_POOL = 8 };
+
+template <int GC, int KS, int EPI>   // KS: 0 whole layer; 1 / 2: first / second pass of a layer split over its input channels
 __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef bf16_t T;
   constexpr int TAPS = 27;
-  constexpr int ES = (int)sizeof(T);
-  constexpr int EPP = 16 / ES;
+  constexpr int ES = 2, EPP = 8;
   constexpr int S = GC * 2;                          // 16-byte slots per halo row
   constexpr int sshift = GC == 1 ? 1 : 2;
   constexpr int rshift = GC == 1 ? 3 : 2;            // rows per 256-byte bank row
   constexpr int rb = GC * 32;
   constexpr int PR = GC == 1 ? 224 : 208, PB = PR * rb, PPIECES = PB / 1024;   // 13 (GC=2) / 7 (GC=1) pieces per plane
-  static_assert(PB % 1024 == 0 && PB == sg_unrolled_ks<T, GC, 1, 3>::PB, "plane slot must be whole pieces");
+  static_assert(PB % 1024 == 0 && PB == sg_unrolled_ks2<T, GC, 1, 6>::PB, "plane slot must be whole pieces");
   constexpr int RINGB = 4 * PB;
   constexpr uint32_t DEAD = 0x80000000u;             // byte offset beyond every buffer: loads return 0, stores drop
+  constexpr bool SIGN = (EPI & SG_EP_SIGN) != 0, MASK = (EPI & SG_EP_MASK) != 0, PN = (EPI & SG_EP_PN) != 0,
+                 POOL = (EPI & SG_EP_POOL) != 0;
+  static_assert(!(PN && POOL) && !(KS == 1 && EPI != 0), "unsupported epilogue combination");
   const sg_tile_geom& g = a.g;                       // TN=1, TD=2, TH=4, TW=32, HD=4, HH=6, HW=34 (host-checked)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1166,18 +1175,17 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   char* wlds = smem + 2 * RINGB;
   const char* wp = reinterpret_cast<const char*>(a.wp);
   const int nt0 = blockIdx.y;
-  // Everything global goes through buffer resources: a scalar base, a scalar per-tile / per-plane offset and a
-  // 32-bit per-lane offset computed once.  The off-phase of this kernel was bound by the INSTRUCTIONS of 64-bit
-  // address arithmetic and pointer selects (~1000 per tile), not by memory; dead lanes simply carry DEAD.
-  // The resources are rebased per batch sample (one 64-bit scalar add per tile), so only ONE SAMPLE of each tensor
-  // has to stay below 2 GiB.
-  const int64_t svox = (int64_t)g.D * g.H * g.W;           // voxels per sample
+  const int H = g.H, W = g.W, D = g.D, nTd = g.nTd, cout = a.cout, ntile = a.ntile;
+  // Everything global goes through buffer resources: a scalar base (rebased per batch sample, so only ONE SAMPLE of a
+  // tensor has to stay below 2 GiB), a scalar per-tile / per-plane offset and a 32-bit per-lane offset computed once;
+  // dead lanes carry DEAD.  A tile column (fixed sample, H, W origin; 2 planes further along D per step) keeps its
+  // resources and per-lane offsets: per step only the scalar offsets advance.
+  const int64_t svox = (int64_t)D * H * W;           // voxels per sample
   auto rsrc_of = [&](const void* base, int64_t sample_bytes, int n0) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + n0 * sample_bytes, 0,
                                              (int)sample_bytes, 0x00020000);
   };
-  const int64_t xsb = svox * a.xcs * ES, ysb = svox * a.cout * (KS == 1 ? 4 : ES), wsb = svox * a.ntile * 4, psb = svox * 4;
-  const int64_t asb = svox * a.cout * 4;                   // f32 addend, per sample
+  const int64_t xsb = svox * a.xcs * ES, ysb = svox * cout * (KS == 1 ? 4 : ES), wsb = svox * ntile * 4, psb = svox * 4;
 
   // column schedule: a block walks PAIRS of H-adjacent tile columns along D, wave group g taking the column with
   // tile row 2*k + g, one phase apart: the two halo rows the pair shares are fetched twice within ~2 us on the same
@@ -1191,7 +1199,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   const int c_begin = xg * cpx, c_end = min(npair, c_begin + cpx);
   const int cfirst = c_begin + bslot;
   const int ncols_blk = cfirst < c_end ? (c_end - cfirst + per_x - 1) / per_x : 0;
-  const int items_mine = ncols_blk * g.nTd;
+  const int items_mine = ncols_blk * nTd;
 
   // fragment addresses inside a plane slot: voxel (h = wave + kh, w = r + kw), channel chunk gi, half hh
   int xa[9][GC];
@@ -1206,7 +1214,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
         xa[kh * 3 + kw][gi] = grp * RINGB + row * rb + (((2 * gi + hh) ^ f) << 4);
     }
   // plane-local staging table: this lane's 16-byte pieces of 1-KiB blocks wave, wave+4, ... of a plane.  The halo
-  // goes global -> registers -> LDS (the loads of a whole step stay in flight across the epilogue).
+  // goes global -> registers -> LDS.
   constexpr int MAXP = (PPIECES + 3) / 4;
   uint32_t relb[MAXP];   // byte offset of my piece relative to the plane's first halo voxel (h0-1, w0-1); dead: huge
   int crdp[MAXP];        // packed (hw, hh) for the boundary test; dead pieces fail every range
@@ -1217,7 +1225,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
     const int hh_ = row / 34, hw = row - hh_ * 34;
     const int c = p * EPP;
     const bool live = row < 204 && c < a.cin && (wave + 4 * k) < PPIECES;
-    relb[k] = live ? (uint32_t)(((hh_ * g.W + hw) * a.xcs + a.xco + c) * ES) : 0xC0000000u;   // stays >= DEAD after + tile offset
+    relb[k] = live ? (uint32_t)(((hh_ * W + hw) * a.xcs + a.xco + c) * ES) : 0xC0000000u;   // stays >= DEAD after + tile offset
     crdp[k] = live ? (hw | (hh_ << 8)) : 0x7F7F;
   }
   // LDS position of my piece inside its 1-KiB block: slot p of row lands at p ^ f(row), and f(row) only depends on
@@ -1227,95 +1235,86 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   uint32_t yvo[2], svo[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
-    const int v = (mt * g.H + wave) * g.W + r;
-    yvo[mt] = (uint32_t)((v * a.cout + nt0 * 32) * ES);
-    svo[mt] = (uint32_t)(v * a.ntile + nt0) * 4u;
+    const int v = (mt * H + wave) * W + r;
+    yvo[mt] = (uint32_t)((v * cout + nt0 * 32) * (KS == 1 ? 4 : ES));
+    svo[mt] = (uint32_t)(v * ntile + nt0) * 4u;
   }
-  const uint32_t plane_bytes = (uint32_t)(g.H * g.W * a.xcs * ES);
+  const uint32_t plane_bytes = (uint32_t)(H * W * a.xcs * ES);
+  const int plane_vox = H * W;
 
-  struct Item { int n0, d0, h0, w0, di; };
-  auto item_of = [&](int q) {
-    Item o;
-    const int cj = q / g.nTd;
-    o.di = q - cj * g.nTd;
-    const int pr = cfirst + cj * per_x;
+  // A cursor walks my tiles in order: column cj of my list, step di along D.  Three run one behind the other: the
+  // tile whose halo planes were requested last (P), the tile computed next (same as P until P advances at the end of
+  // an off-phase) and the tile whose results are stored (E).
+  struct Cur { int cj, di, n0, h0, w0; };
+  auto enter_column = [&](Cur& c) {
+    const int pr = cfirst + c.cj * per_x;
     const int c1 = (int)sg_div((uint32_t)pr, g.fnTw);
-    o.w0 = (pr - c1 * g.nTw) * 32;
+    c.w0 = (pr - c1 * g.nTw) * 32;
     const int c2 = c1 / nTh2;
-    o.h0 = (2 * (c1 - c2 * nTh2) + grp) * 4;         // may lie beyond H for the last odd row: a dead column
-    o.n0 = c2;
-    o.d0 = o.di * 2;
-    return o;
+    c.h0 = (2 * (c1 - c2 * nTh2) + grp) * 4;         // may lie beyond H for the last odd row: a dead column
+    c.n0 = c2;
   };
-
-  // per-lane offsets of my pieces for the tile at o (same for all of its planes)
-  auto piece_offsets = [&](const Item& o, uint32_t (&vk)[MAXP]) {
-    const int tile_off = ((o.h0 - 1) * g.W + (o.w0 - 1)) * a.xcs * ES;   // may be negative: only dead lanes go below 0
-    const bool hw_interior = o.h0 >= 1 && o.w0 >= 1 && o.h0 + 5 <= g.H && o.w0 + 33 <= g.W;
-    if (hw_interior) {
+  // ---- halo side (cursor P): per-column resource and per-lane offsets
+  Cur P{0, 0, 0, 0, 0};
+  __amdgpu_buffer_rsrc_t rxP;
+  uint32_t vk[MAXP];
+  auto enter_column_P = [&]() {
+    enter_column(P);
+    rxP = rsrc_of(a.x, xsb, P.n0);
+    const int tile_off = ((P.h0 - 1) * W + (P.w0 - 1)) * a.xcs * ES;   // may be negative: only dead lanes go below 0
+    const int lo_w = max(0, 1 - P.w0), hi_w = min(34, W + 1 - P.w0) - 1;
+    const int lo_h = max(0, 1 - P.h0), hi_h = min(6, H + 1 - P.h0) - 1;   // hi_h < 0 for a dead column
+    const uint32_t lo = (uint32_t)(lo_w | (lo_h << 8));
+    const uint32_t hi = (uint32_t)(hi_w | ((hi_h & 0x7F) << 8)) | 0x8080u;
 #pragma unroll
-      for (int k = 0; k < MAXP; ++k) vk[k] = relb[k] + (uint32_t)tile_off;
-    } else {
-      const int lo_w = max(0, 1 - o.w0), hi_w = min(34, g.W + 1 - o.w0) - 1;
-      const int lo_h = max(0, 1 - o.h0), hi_h = min(6, g.H + 1 - o.h0) - 1;   // hi_h < 0 for a dead column
-      const uint32_t lo = (uint32_t)(lo_w | (lo_h << 8));
-      const uint32_t hi = (uint32_t)(hi_w | ((hi_h & 0x7F) << 8)) | 0x8080u;
-#pragma unroll
-      for (int k = 0; k < MAXP; ++k) {
-        const uint32_t c_ = (uint32_t)crdp[k];
-        const uint32_t t1 = (c_ | 0x8080u) - lo, t2 = hi - c_;
-        vk[k] = ((t1 & t2 & 0x8080u) == 0x8080u && hi_h >= 0) ? relb[k] + (uint32_t)tile_off : DEAD;
-      }
+    for (int k = 0; k < MAXP; ++k) {
+      const uint32_t c_ = (uint32_t)crdp[k];
+      const uint32_t t1 = (c_ | 0x8080u) - lo, t2 = hi - c_;
+      vk[k] = ((t1 & t2 & 0x8080u) == 0x8080u && hi_h >= 0) ? relb[k] + (uint32_t)tile_off : DEAD;
     }
   };
-  auto load_planes = [&](const Item& o, int hd0, const uint32_t (&vk)[MAXP], u32x4 (&stg)[2][MAXP]) {
-    const __amdgpu_buffer_rsrc_t rx = rsrc_of(a.x, xsb, o.n0);
+  u32x4 stg[2][MAXP];
+  auto load_planes = [&](int d0, int hd0) {          // planes d0 - 1 + hd0 + {0, 1} of P's column
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int gp = o.d0 - 1 + hd0 + j;             // global D plane
-      const bool plane_ok = gp >= 0 && gp < g.D;
+      const int gp = d0 - 1 + hd0 + j;               // global D plane
+      const bool plane_ok = gp >= 0 && gp < D;
       const uint32_t soff = plane_ok ? (uint32_t)gp * plane_bytes : 0u;
 #pragma unroll
-      for (int k = 0; k < MAXP; ++k)
-        if (wave + 4 * k < PPIECES)
-          stg[j][k] = __builtin_amdgcn_raw_buffer_load_b128(rx, plane_ok ? vk[k] : DEAD, soff, 0);
+      for (int k = 0; k < MAXP; ++k) stg[j][k] = __builtin_amdgcn_raw_buffer_load_b128(rxP, plane_ok ? vk[k] : DEAD, soff, 0);
     }
   };
-  auto store_planes = [&](const Item& o, int hd0, const u32x4 (&stg)[2][MAXP]) {
+  auto store_planes = [&](int d0, int hd0) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int gp = o.d0 - 1 + hd0 + j;
+      const int gp = d0 - 1 + hd0 + j;
       char* dst = xmine + ((gp + 8) & 3) * PB + wofs;
 #pragma unroll
       for (int k = 0; k < MAXP; ++k)
         if (wave + 4 * k < PPIECES) *reinterpret_cast<u32x4*>(dst + (wave + 4 * k) * 1024) = stg[j][k];
     }
   };
-
-  // K-split second pass: the first pass's f32 partial sums of tile o go straight into the (free) accumulators
-  // during the off-phase before the tile's MFMA phase; the other wave group's MFMA phase covers their latency
-  f32x16 acc[2];
-  auto load_partial = [&](const Item& o) {
-    const __amdgpu_buffer_rsrc_t ra = rsrc_of(a.addend, asb, o.n0);
-    const uint32_t soff = (uint32_t)((o.d0 * g.H + o.h0) * g.W + o.w0) * (uint32_t)(a.cout * 4);
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const bool ok = o.h0 + wave < g.H && o.d0 + mt < g.D;
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            ra, ok ? (uint32_t)((((mt * g.H + wave) * g.W + r) * a.cout + nt0 * 32 + 8 * qd + 4 * hh) * 4) : DEAD, soff, 0));
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[mt][4 * qd + e] = v[e];
-      }
-    }
+  // ---- output side (cursor E): per-column resources, validity and voxel origin
+  Cur E{0, 0, 0, 0, 0};
+  __amdgpu_buffer_rsrc_t ryE, rsE, rmE, rpE;
+  int colvoxE = 0;
+  bool row_okE = false;
+  auto enter_column_E = [&]() {
+    enter_column(E);
+    row_okE = E.h0 + wave < H;
+    colvoxE = E.h0 * W + E.w0;
+    ryE = rsrc_of(a.y, POOL ? ysb / 4 : ysb, E.n0);
+    if (SIGN) rsE = rsrc_of(a.sign_out, wsb, E.n0);
+    if (MASK) rmE = rsrc_of(a.mask_bits, wsb, E.n0);
+    if (PN) rpE = rsrc_of(a.pn_scale, psb, E.n0);
   };
+
   // resident weights (all 8 waves) and bias
   {
     constexpr int nfrag = TAPS * GC;
     for (int f = wave8; f < nfrag; f += 8) {
       const int tap = f / GC, gi = f - tap * GC;
-      const char* src = gi < a.nchunk ? wp + ((((int64_t)gi * TAPS + tap) * a.ntile + nt0) << 10)
+      const char* src = gi < a.nchunk ? wp + ((((int64_t)gi * TAPS + tap) * ntile + nt0) << 10)
                                       : reinterpret_cast<const char*>(sg_zero_page);
       sg_glds16(src + (gi < a.nchunk ? lane * 16 : 0), wlds + ((size_t)f << 10));
     }
@@ -1323,24 +1322,37 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   float* bias_lds = reinterpret_cast<float*>(wlds + TAPS * GC * 1024);
   if (tid < 32) {
     const int co = nt0 * 32 + tid;
-    bias_lds[tid] = (a.bias != nullptr && co < a.cout) ? a.bias[co] : 0.f;
+    bias_lds[tid] = (a.bias != nullptr && co < cout) ? a.bias[co] : 0.f;
   }
-  u32x4 stg[2][MAXP];
-  uint32_t vk[MAXP];
-  if (grp == 0 && items_mine > 0) {   // the very first tile of group 0: all four planes, latency exposed once
-    const Item o0 = item_of(0);
-    piece_offsets(o0, vk);
-    load_planes(o0, 0, vk, stg);
-    store_planes(o0, 0, stg);
-    load_planes(o0, 2, vk, stg);
-    store_planes(o0, 2, stg);
-    if (KS == 2) load_partial(o0);
+  f32x16 acc[2];
+  // The upper two halo planes of a group's NEXT tile are requested at the END of an off-phase and written to the ring
+  // at the start of the following one: they are in flight during the group's whole MFMA phase.  (Requested at the
+  // start of the off-phase that needs them, their ~3 us under load made the off-phase longer than the MFMA phase:
+  // in-kernel stamps, 5.1k against 4.6k cycles.)  `stg` is therefore live across the MFMA phase.
+  const bool no_stage = (a.dbg_flags & 1) != 0, no_epi = (a.dbg_flags & 2) != 0, no_mfma = (a.dbg_flags & 8) != 0;
+  int qP = 0;                                        // index of P's tile in my list
+  if (items_mine > 0) {
+    enter_column_P();
+    enter_column_E();
+    if (grp == 0) {   // the very first tile of group 0: all four planes, latency exposed once
+      load_planes(0, 0);
+      store_planes(0, 0);
+      load_planes(0, 2);
+      store_planes(0, 2);
+      if (items_mine > 1) {
+        qP = 1;
+        P.di = 1;     // nTd >= 2
+        load_planes(2, 2);
+      }
+    } else {
+      load_planes(0, 2);
+    }
   }
   __syncthreads();
 
   const int wl_off = (int)(wlds - smem) + lane * 16;
-  const float inv_c = 1.f / (float)a.cout;
-  const bool wide_store = ES == 2 && (a.cout % 8 == 0) && nt0 * 32 + 32 <= a.cout && !(a.dbg_flags & 16);
+  const float inv_c = 1.f / (float)cout;
+  const float slope = a.act ? a.slope : 1.f;         // max(x, 1 * x) = x: no branch for "no activation"
 
   int dbgi = 0;
   auto stamp = [&]() {
@@ -1348,92 +1360,101 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
       a.dbg[grp * 128 + dbgi] = __builtin_amdgcn_s_memtime();
     ++dbgi;
   };
-  const int nphase = 2 * items_mine + 1;
-  for (int p = 0; p < nphase; ++p) {
-    const int q = p >> 1;
+  auto mfma_phase = [&](int di) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mt][i] = bias_lds[(i & 3) + 8 * (i >> 2) + 4 * hh];   // bias rides in C
+    if (no_mfma) { /* diagnostic: no MFMA phase */ }
+    else if (di & 1) sg_unrolled_ks2<T, GC, 1, 6>::run(acc, xa, wl_off);
+    else sg_unrolled_ks2<T, GC, 3, 6>::run(acc, xa, wl_off);
+  };
+
+  // ---- off-phase: P's planes (requested one phase ago) into the ring, epilogue of E's tile (if `closes`), request
+  // the planes of the tile after P
+  auto off_phase = [&](bool closes, bool stage) {
+    const int d0E = 2 * E.di;
+    const uint32_t tile_vox = (uint32_t)(d0E * plane_vox + colvoxE);   // within sample E.n0
+    const bool okE[2] = {closes && row_okE, closes && row_okE && d0E + 1 < D};
+    // sign words of the tile about to be stored, requested ahead of everything else.  Issued and consumed
+    // UNCONDITIONALLY (DEAD offset: no memory access): with the request under one `if` and the use under another the
+    // compiler sees a path on which the load is never waited for and puts s_waitcnt vmcnt(0) -- which also waits for
+    // the halo planes in flight -- in front of the next MFMA that reuses the register.
+    uint32_t mb[2] = {0u, 0u};
+    if (MASK) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        mb[mt] = __builtin_amdgcn_raw_buffer_load_b32(rmE, okE[mt] ? svo[mt] : DEAD, tile_vox * (uint32_t)(ntile * 4), 0);
+    }
+    // K-split second pass: the first pass's f32 partial sums of the tile about to be stored (held across the MFMA
+    // phase they would not fit beside the accumulators, the planes in flight and the fragment ring)
+    f32x4 part[KS == 2 ? 2 : 1][KS == 2 ? 4 : 1];
+    if constexpr (KS == 2) {
+      const __amdgpu_buffer_rsrc_t ra = rsrc_of(a.addend, svox * cout * 4, E.n0);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+          part[mt][qd] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+              ra, okE[mt] ? 2 * yvo[mt] + (uint32_t)((8 * qd + 4 * hh) * 4) : DEAD, tile_vox * (uint32_t)(cout * 4), 0));
+    }
+    if (stage && !no_stage) {
+      const int d0P = 2 * P.di;
+      store_planes(d0P, 2);
+      if (P.di == 0) {   // bottom of a column: the two lower planes too, straight through
+        load_planes(0, 0);
+        store_planes(0, 0);
+      }
+    }
+    if (MASK) asm volatile("" ::"v"(mb[0]), "v"(mb[1]));   // landed, before the first store (stores count in vmcnt too)
+    __builtin_amdgcn_sched_barrier(0);
     stamp();
-    if ((p & 1) == grp) {
-      if (q < items_mine) {
+    if (!no_epi && closes) {
+      if (KS == 1) {     // K-split first pass: the accumulators as they stand, 4 x 16 bytes per lane
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc[mt][i] = bias_lds[(i & 3) + 8 * (i >> 2) + 4 * hh] + (KS == 2 ? acc[mt][i] : 0.f);   // bias (+ partial) rides in C
-        const int di = q % g.nTd;
-        if (a.dbg_flags & 8) { /* diagnostic: no MFMA phase */ }
-        else if (a.dbg_flags & 32) {   // diagnostic: the 9-reads-per-6-MFMAs loop
-          if (di & 1) sg_unrolled_ks<T, GC, 1, 3>::run(acc, xa, wl_off);
-          else sg_unrolled_ks<T, GC, 3, 3>::run(acc, xa, wl_off);
-        } else if (di & 1) sg_unrolled_ks2<T, GC, 1, 6>::run(acc, xa, wl_off);
-        else sg_unrolled_ks2<T, GC, 3, 6>::run(acc, xa, wl_off);
-      }
-    } else {
-      const int qn = (p + 1) >> 1, qp = qn - 1;      // my next / previous item
-      const bool closes = qp >= 0 && qp < items_mine && !(a.dbg_flags & 2);
-      const Item o = item_of(closes ? qp : 0);
-      // W is a multiple of 32 and a wave owns one H row, an M tile one D plane: store predicates are uniform
-      const bool row_ok = closes && o.h0 + wave < g.H;
-      const uint32_t tile_vox = (uint32_t)((o.d0 * g.H + o.h0) * g.W + o.w0);   // within sample o.n0
-      const __amdgpu_buffer_rsrc_t ry = rsrc_of(a.y, ysb, o.n0), rm = rsrc_of(a.mask_bits, wsb, o.n0),
-                                   rs_ = rsrc_of(a.sign_out, wsb, o.n0), rp = rsrc_of(a.pn_scale, psb, o.n0);
-      const uint32_t ysoff = tile_vox * (uint32_t)(a.cout * ES), ssoff = tile_vox * (uint32_t)(a.ntile * 4);
-      uint32_t mb[2];
-      const bool use_mask = a.mask_bits != nullptr && closes;
-      if (use_mask) {   // sign words of the tile about to be stored, requested ahead of everything else
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-          mb[mt] = __builtin_amdgcn_raw_buffer_load_b32(rm, (row_ok && o.d0 + mt < g.D) ? svo[mt] : DEAD, ssoff, 0);
-      }
-      // next tile's new halo planes: loads issued now, written to the ring after the epilogue
-      const bool restage = qn < items_mine && !((a.dbg_flags & 1) && p >= 2);
-      const Item on = item_of(restage ? qn : 0);
-      if (restage) {
-        piece_offsets(on, vk);
-        if (on.di == 0) {   // bottom of a column: the two lower planes first, straight through
-          load_planes(on, 0, vk, stg);
-          store_planes(on, 0, stg);
-        }
-        load_planes(on, 2, vk, stg);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      stamp();
-      if (closes) {
+          for (int qd = 0; qd < 4; ++qd) {
+            f32x4 v4 = {acc[mt][4 * qd], acc[mt][4 * qd + 1], acc[mt][4 * qd + 2], acc[mt][4 * qd + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), ryE,
+                                                   okE[mt] ? yvo[mt] + (uint32_t)((8 * qd + 4 * hh) * 4) : DEAD,
+                                                   tile_vox * (uint32_t)(cout * 4), 0);
+            SG_STORE16_GUARD(v4);
+          }
+      } else {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-          const bool ok = row_ok && o.d0 + mt < g.D;   // uniform
-          if (KS == 1) {     // K-split first pass: the accumulators as they stand, 4 x 16 bytes per lane
-            const __amdgpu_buffer_rsrc_t ryf = rsrc_of(a.y, ysb, o.n0);
+          if constexpr (KS == 2) {
 #pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-              f32x4 v4 = {acc[mt][4 * qd], acc[mt][4 * qd + 1], acc[mt][4 * qd + 2], acc[mt][4 * qd + 3]};
-              if (ok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v4), ryf,
-                                                             (uint32_t)((((mt * g.H + wave) * g.W + r) * a.cout + nt0 * 32 + 8 * qd + 4 * hh) * 4),
-                                                             tile_vox * (uint32_t)(a.cout * 4), 0);
-            }
-            continue;
+            for (int i = 0; i < 16; ++i) acc[mt][i] += part[mt][i >> 2][i & 3];
           }
-          if (a.act) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[mt][i] = fmaxf(acc[mt][i], acc[mt][i] * a.slope);
-          }
-          if (a.pixel_norm) {
+          for (int i = 0; i < 16; ++i) acc[mt][i] = fmaxf(acc[mt][i], acc[mt][i] * slope);   // LeakyReLU (slope 1: none)
+          if (PN) {
             float ss = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) ss += acc[mt][i] * acc[mt][i];
-            ss += __shfl_xor(ss, 32);
+            const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
+            ss = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);   // own half + partner lane ^ 32's
             const float sc = rsqrtf(ss * inv_c + a.eps);
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][i] *= sc;
-            if (a.pn_scale != nullptr && ok)
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc), rp, hh == 0 ? (svo[mt] - nt0 * 4u) / (uint32_t)a.ntile : DEAD,
+            if (a.pn_scale != nullptr)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sc), rpE,
+                                                    (okE[mt] && hh == 0) ? (svo[mt] - nt0 * 4u) / (uint32_t)ntile : DEAD,
                                                     tile_vox * 4u, 0);
           }
-          if (a.sign_out != nullptr) {
-            const uint32_t sw = sg_sign_word(acc[mt], hh);
-            if (ok) __builtin_amdgcn_raw_buffer_store_b32(sw, rs_, hh == 0 ? svo[mt] : DEAD, ssoff, 0);
+          if (SIGN) {
+            uint32_t b = 0u;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) b |= (__float_as_uint(acc[mt][i]) >> 31) << ((i & 3) + 8 * (i >> 2));
+            b <<= 4 * hh;
+            const auto sw2 = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+            __builtin_amdgcn_raw_buffer_store_b32(sw2[0] | sw2[1], rsE, (okE[mt] && hh == 0) ? svo[mt] : DEAD,
+                                                  tile_vox * (uint32_t)(ntile * 4), 0);
           }
-          if (use_mask) sg_apply_sign_word(acc[mt], mb[mt], hh, a.mask_slope);
-          if (a.pool) continue;   // uniform: the pooled store below replaces the full-resolution one
-          if (wide_store) {
+          if (MASK) sg_apply_sign_word(acc[mt], mb[mt], hh, a.mask_slope);
+          if (!POOL) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {   // 16 contiguous bytes per lane (see sg_store_tile_row_bf16)
               const uint32_t a0 = sg_pack_bf16(acc[mt][8 * j + 0], acc[mt][8 * j + 1]), a1 = sg_pack_bf16(acc[mt][8 * j + 2], acc[mt][8 * j + 3]);
@@ -1442,77 +1463,111 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
               const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
               u32x4 out;
               out[0] = s0[0]; out[1] = s1[0]; out[2] = s0[1]; out[3] = s1[1];
-              if (ok) __builtin_amdgcn_raw_buffer_store_b128(out, ry, yvo[mt] + (uint32_t)((16 * j + 8 * hh) * 2), ysoff, 0);
-            }
-          } else if (ok) {
-            T* yrow = reinterpret_cast<T*>(a.y) +
-                      (o.n0 * svox + (int64_t)tile_vox + (int64_t)(mt * g.H + wave) * g.W + r) * (int64_t)a.cout;
-#pragma unroll
-            for (int qd = 0; qd < 4; ++qd) {
-              const int co = nt0 * 32 + 8 * qd + 4 * hh;
-              if (a.vec_out && co + 4 <= a.cout) {
-                T tmp[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) tmp[e] = sg_traits<T>::from_f(acc[mt][qd * 4 + e]);
-                if (sizeof(T) == 2) *reinterpret_cast<u32x2*>(yrow + co) = *reinterpret_cast<u32x2*>(tmp);
-                else *reinterpret_cast<u32x4*>(yrow + co) = *reinterpret_cast<u32x4*>(tmp);
-              } else {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                  if (co + e < a.cout) yrow[co + e] = sg_traits<T>::from_f(acc[mt][qd * 4 + e]);
-              }
+              __builtin_amdgcn_raw_buffer_store_b128(out, ryE, okE[mt] ? yvo[mt] + (uint32_t)((16 * j + 8 * hh) * 2) : DEAD,
+                                                     tile_vox * (uint32_t)(cout * ES), 0);
+              SG_STORE16_GUARD(out);
             }
           }
         }
-      }
-      if (closes && a.pool) {
-        // fused downscale3d, first stage (pgan/discriminator.py:44 after conv_2 + bias + LeakyReLU): the tile's two D
-        // planes are this wave's two M tiles (a lane-local add) and W neighbours are adjacent lanes (one cross-lane
-        // exchange), so the mean over the 2 x 1 x 2 block costs 32 VALU ops and the full-resolution activation --
-        // the largest tensor of the network, needed by nobody else: the backward only wants its sign words -- is never
-        // written.  Output [n, D/2, H, W/2, cout]; the H pairs (two different waves) are pooled by sg_downscale_sum(1,2,1).
-        const __amdgpu_buffer_rsrc_t ryp = rsrc_of(a.y, ysb / 4, o.n0);
-        const uint32_t psoff = (uint32_t)((((o.d0 >> 1) * g.H + o.h0) * (g.W >> 1) + (o.w0 >> 1)) * a.cout * ES);
-        const uint32_t pvo = (r & 1) ? DEAD : (uint32_t)(((wave * (g.W >> 1) + (r >> 1)) * a.cout + nt0 * 32) * ES);
-        float sp[16];
+        if (POOL) {
+          // fused downscale3d, first stage (pgan/discriminator.py:44 after conv_2 + bias + LeakyReLU): the tile's two D
+          // planes are this wave's two M tiles (a lane-local add) and W neighbours are adjacent lanes (one cross-lane
+          // exchange), so the mean over the 2 x 1 x 2 block costs 32 VALU ops and the full-resolution activation --
+          // the largest tensor of the network, needed by nobody else: the backward only wants its sign words -- is never
+          // written.  Output [n, D/2, H, W/2, cout]; the H pairs (two different waves) are pooled by sg_downscale_sum(1,2,1).
+          const uint32_t psoff = (uint32_t)(((E.di * H + E.h0) * (W >> 1) + (E.w0 >> 1)) * cout * ES);
+          const uint32_t pvo = ((r & 1) || !okE[0]) ? DEAD : (uint32_t)(((wave * (W >> 1) + (r >> 1)) * cout + nt0 * 32) * ES);
+          float sp[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float t = acc[0][i] + acc[1][i];
-          sp[i] = (t + __shfl_xor(t, 1)) * 0.25f;     // lane r <-> r ^ 1: the W neighbour
-        }
+          for (int i = 0; i < 16; ++i) {
+            const float t = acc[0][i] + acc[1][i];
+            sp[i] = (t + __shfl_xor(t, 1)) * 0.25f;     // lane r <-> r ^ 1: the W neighbour
+          }
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const uint32_t a0 = sg_pack_bf16(sp[8 * j + 0], sp[8 * j + 1]), a1 = sg_pack_bf16(sp[8 * j + 2], sp[8 * j + 3]);
-          const uint32_t b0 = sg_pack_bf16(sp[8 * j + 4], sp[8 * j + 5]), b1 = sg_pack_bf16(sp[8 * j + 6], sp[8 * j + 7]);
-          const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-          const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-          u32x4 out;
-          out[0] = s0[0]; out[1] = s1[0]; out[2] = s0[1]; out[3] = s1[1];
-          if (row_ok) __builtin_amdgcn_raw_buffer_store_b128(out, ryp, pvo + (uint32_t)((16 * j + 8 * hh) * 2), psoff, 0);
+          for (int j = 0; j < 2; ++j) {
+            const uint32_t a0 = sg_pack_bf16(sp[8 * j + 0], sp[8 * j + 1]), a1 = sg_pack_bf16(sp[8 * j + 2], sp[8 * j + 3]);
+            const uint32_t b0 = sg_pack_bf16(sp[8 * j + 4], sp[8 * j + 5]), b1 = sg_pack_bf16(sp[8 * j + 6], sp[8 * j + 7]);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            u32x4 out;
+            out[0] = s0[0]; out[1] = s1[0]; out[2] = s0[1]; out[3] = s1[1];
+            __builtin_amdgcn_raw_buffer_store_b128(out, ryE, pvo == DEAD ? DEAD : pvo + (uint32_t)((16 * j + 8 * hh) * 2), psoff, 0);
+            SG_STORE16_GUARD(out);
+          }
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
-      if (KS == 2 && qn < items_mine) load_partial(on);
-      if (restage) store_planes(on, 2, stg);
     }
-    stamp();
-    __syncthreads();
+    if (closes) {   // E moves on (its column's resources follow at a column change)
+      if (++E.di == nTd) {
+        E.di = 0;
+        ++E.cj;
+        if (E.cj < ncols_blk) enter_column_E();
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (stage) {   // request the upper planes of the tile after P
+      ++qP;
+      if (++P.di == nTd) {
+        P.di = 0;
+        ++P.cj;
+        if (qP < items_mine) enter_column_P();
+      }
+      if (qP < items_mine && !no_stage) load_planes(2 * P.di, 2);
+    }
+  };
+  // Each wave group runs its own straight loop (one phase apart, paced by the block barrier) so that the registers
+  // that live across phases -- the accumulators and the halo planes in flight -- are plain loop-carried values: in
+  // one loop over phases with a group-dependent branch the compiler copied all 64 of them at the loop's end, behind
+  // an s_waitcnt vmcnt(0) that undid the prefetch.
+  if (grp == 0) {
+    for (int q = 0; q < items_mine; ++q) {
+      stamp();
+      mfma_phase(q % nTd);
+      stamp();
+      __syncthreads();
+      stamp();
+      off_phase(true, q + 1 < items_mine);
+      stamp();
+      __syncthreads();
+    }
+  } else {
+    for (int q = 0; q < items_mine; ++q) {
+      stamp();
+      off_phase(q > 0, true);
+      stamp();
+      __syncthreads();
+      stamp();
+      mfma_phase(q % nTd);
+      stamp();
+      __syncthreads();
+    }
+    if (items_mine > 0) off_phase(true, false);
   }
 }
 
-template <typename T, int GC, int KS = 0>
+template <int GC, int KS, int EPI>
+static int launch_fwd3s_inst(const ConvFwdArgs& a, unsigned gx, size_t lds, hipStream_t st) {
+  auto kern = conv_fwd3s_kernel<GC, KS, EPI>;
+  SG_ALLOW_160K_LDS(kern);
+  hipLaunchKernelGGL(kern, dim3(gx, (unsigned)a.ntile), dim3(512), lds, st, a);
+  return SG_OK;
+}
+
+// The sliding-halo kernel exists for bf16 with whole 32-channel output tiles; KS as in the kernel.
+template <int GC, int KS = 0>
 static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used) {
   *used = false;
   if (s->upsample_in || s->kd != 3 || s->kh != 3 || s->kw != 3) return SG_OK;
-  if (s->d < 4 || (s->w % 32) != 0) return SG_OK;   // needs >= 2 steps per column; full 32-wide rows
-  if (a.pool && (sizeof(T) != 2 || (s->d & 1) || (s->h & 1) || s->cout % 32 != 0 || a.pixel_norm || a.mask_bits)) return SG_OK;
+  if (s->d < 4 || (s->w % 32) != 0 || (s->cout % 32) != 0) return SG_OK;   // >= 2 steps per column; full 32-wide rows and tiles
+  if (a.pool && ((s->d & 1) || (s->h & 1) || a.pixel_norm || a.mask_bits || KS != 0)) return SG_OK;
+  if (a.pixel_norm && (a.mask_bits || KS != 0)) return SG_OK;
+  if (a.mask_bits && a.sign_out) return SG_OK;
   a.g = sg_make_geom(s, 256, /*prefer_w32=*/true, /*td=*/2, /*th=*/4);
   const sg_tile_geom& g = a.g;
-  if (g.TN != 1 || g.TD != 2 || g.TH != 4 || g.TW != 32 || g.HD != 4 || g.HH != 6 || g.HW != 34) return SG_OK;
+  if (g.TN != 1 || g.TD != 2 || g.TH != 4 || g.TW != 32 || g.HD != 4 || g.HH != 6 || g.HW != 34 || g.nTd < 2) return SG_OK;
   {   // buffer addressing (rebased per sample): one sample of every tensor this kernel touches stays below 2 GiB
     const int64_t svox = (int64_t)s->d * s->h * s->w;
-    const int es = (int)sizeof(T);
-    if (svox * a.xcs * es >= (1ll << 31) || svox * s->cout * 4 >= (1ll << 31) || svox * a.ntile * 4 >= (1ll << 31)) return SG_OK;
+    if (svox * a.xcs * 2 >= (1ll << 31) || svox * s->cout * 4 >= (1ll << 31) || svox * a.ntile * 4 >= (1ll << 31)) return SG_OK;
   }
   int gx = (256 / a.ntile) / 8 * 8;
   if (gx < 8) gx = 8;
@@ -1523,11 +1578,33 @@ static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
   a.G = GC;
   a.rs = GC * 32;
   a.vec_in = 1;
-  a.vec_out = (s->cout % 4 == 0) ? 1 : 0;
-  auto kern = conv_fwd3s_kernel<T, GC, KS>;
-  SG_ALLOW_160K_LDS(kern);
-  SG_KNAME(KS ? "conv_fwd3s<%s,%d> K-split" : "conv_fwd3s<%s,%d>", sg_tname<T>(), GC);
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.ntile), dim3(512), lds, st, a);
+  a.vec_out = 1;
+  const int epi = (a.sign_out ? SG_EP_SIGN : 0) | (a.mask_bits ? SG_EP_MASK : 0) | (a.pixel_norm ? SG_EP_PN : 0) |
+                  (a.pool ? SG_EP_POOL : 0);
+  int rc = SG_OK;
+  if constexpr (KS == 1) {
+    rc = launch_fwd3s_inst<GC, 1, 0>(a, (unsigned)gx, lds, st);
+  } else if constexpr (KS == 2) {
+    switch (epi) {
+      case 0: rc = launch_fwd3s_inst<GC, 2, 0>(a, (unsigned)gx, lds, st); break;
+      case SG_EP_SIGN: rc = launch_fwd3s_inst<GC, 2, SG_EP_SIGN>(a, (unsigned)gx, lds, st); break;
+      case SG_EP_MASK: rc = launch_fwd3s_inst<GC, 2, SG_EP_MASK>(a, (unsigned)gx, lds, st); break;
+      default: return SG_OK;
+    }
+  } else {
+    switch (epi) {
+      case 0: rc = launch_fwd3s_inst<GC, 0, 0>(a, (unsigned)gx, lds, st); break;
+      case SG_EP_SIGN: rc = launch_fwd3s_inst<GC, 0, SG_EP_SIGN>(a, (unsigned)gx, lds, st); break;
+      case SG_EP_MASK: rc = launch_fwd3s_inst<GC, 0, SG_EP_MASK>(a, (unsigned)gx, lds, st); break;
+      case SG_EP_PN: rc = launch_fwd3s_inst<GC, 0, SG_EP_PN>(a, (unsigned)gx, lds, st); break;
+      case SG_EP_PN | SG_EP_SIGN: rc = launch_fwd3s_inst<GC, 0, SG_EP_PN | SG_EP_SIGN>(a, (unsigned)gx, lds, st); break;
+      case SG_EP_SIGN | SG_EP_POOL: rc = launch_fwd3s_inst<GC, 0, SG_EP_SIGN | SG_EP_POOL>(a, (unsigned)gx, lds, st); break;
+      case SG_EP_POOL: rc = launch_fwd3s_inst<GC, 0, SG_EP_POOL>(a, (unsigned)gx, lds, st); break;
+      default: return SG_OK;
+    }
+  }
+  if (rc != SG_OK) return rc;
+  SG_KNAME(KS ? "conv_fwd3s<bf16,%d> K-split" : "conv_fwd3s<bf16,%d>", GC);
   SG_LAUNCH_CHECK();
   *used = true;
   return SG_OK;
@@ -1866,7 +1943,7 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
 #pragma unroll
                   for (int e = 0; e < 4; ++e) tmp[e] = sg_traits<T>::from_f(acc[mt][nt][qd * 4 + e]);
                   if (sizeof(T) == 2) *reinterpret_cast<u32x2*>(yrow + co) = *reinterpret_cast<u32x2*>(tmp);
-                  else *reinterpret_cast<u32x4*>(yrow + co) = *reinterpret_cast<u32x4*>(tmp);
+                  else { const u32x4 t16 = *reinterpret_cast<u32x4*>(tmp); *reinterpret_cast<u32x4*>(yrow + co) = t16; SG_STORE16_GUARD(t16); }
                 } else {
 #pragma unroll
                   for (int e = 0; e < 4; ++e)
@@ -1990,6 +2067,7 @@ __global__ __launch_bounds__(256) void pw_fwd_small_cin_kernel(ConvFwdArgs a, in
 #pragma unroll
     for (int e = 0; e < E; ++e) t[e] = sg_traits<T>::from_f(o[e]);
     *reinterpret_cast<u32x4*>(y + v * a.cout + c0) = raw;
+    SG_STORE16_GUARD(raw);
   }
 }
 
@@ -2211,7 +2289,7 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     rc = SG_OK;
     const bool k333 = s->kd == 3 && s->kh == 3 && s->kw == 3, k133 = s->kd == 1 && s->kh == 3 && s->kw == 3;
     if (dt == SG_BF16 && k333 && !sg_cfg().fwd_no_v3s && !sg_cfg().fwd_no_v5 && a.nchunk == 4 && a.ntile == 1 && s->cin == 64 &&
-        !s->upsample_in && !a.pool && !a.pixel_norm && ep && ep->workspace &&
+        !s->upsample_in && !a.pool && !a.pixel_norm && !(a.mask_bits && a.sign_out) && ep && ep->workspace &&
         ep->workspace_bytes >= (size_t)s->n * s->d * s->h * s->w * (size_t)s->cout * 4 && sg_aligned16(ep->workspace)) {
       // K split: 64 input channels as two sliding-halo passes over 32 channels each (resident weights, a 64-byte
       // half of every 128-byte channel row fetched ONCE per pass) with the f32 partial sums in the caller's workspace.
@@ -2225,9 +2303,9 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
       p2.xco = 32; p2.addend = reinterpret_cast<const float*>(ep->workspace);
       p2.wp = reinterpret_cast<const char*>(a.wp) + (size_t)2 * a.taps * a.ntile * 1024;   // chunks 2, 3 of the packed image
       bool u1 = false, u2 = false;
-      rc = launch_fwd3s<bf16_t, 2, 1>(p1, &sh, hs, &u1);
+      rc = launch_fwd3s<2, 1>(p1, &sh, hs, &u1);
       if (rc == SG_OK && u1) {
-        rc = launch_fwd3s<bf16_t, 2, 2>(p2, &sh, hs, &u2);
+        rc = launch_fwd3s<2, 2>(p2, &sh, hs, &u2);
         if (rc == SG_OK && !u2) rc = SG_EINVAL;     // same geometry as pass 1: cannot decline
         SG_KNAME("conv_fwd3s<bf16,2> x2 (K split)");
         prof.done(rc);
@@ -2236,8 +2314,8 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
       if (rc != SG_OK) { prof.done(rc); return rc; }
     }
     if (dt == SG_BF16 && k333 && !sg_cfg().fwd_no_v3s) {   // sliding-halo variant where its tile fits
-      if (a.nchunk == 2) rc = launch_fwd3s<bf16_t, 2>(a, s, hs, &used);
-      else if (a.nchunk == 1) rc = launch_fwd3s<bf16_t, 1>(a, s, hs, &used);
+      if (a.nchunk == 2) rc = launch_fwd3s<2>(a, s, hs, &used);
+      else if (a.nchunk == 1) rc = launch_fwd3s<1>(a, s, hs, &used);
       if (rc != SG_OK || used) { prof.done(rc); return rc; }
     }
     if (a.pool) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }   // only the sliding-halo kernel pools

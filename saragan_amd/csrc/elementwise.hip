@@ -23,6 +23,7 @@ struct Piece {
 #pragma unroll
     for (int e = 0; e < E; ++e) t[e] = sg_traits<T>::from_f(v[e]);
     *reinterpret_cast<u32x4*>(p) = raw;
+    SG_STORE16_GUARD(raw);
   }
 };
 

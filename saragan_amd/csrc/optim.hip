@@ -22,13 +22,17 @@ __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__
 #pragma unroll
       for (int e = 0; e < 4; ++e) pp[e] -= lr_t * mm[e] / (sqrtf(vv[e]) + eps);
       reinterpret_cast<f32x4*>(m)[i] = mm;
+      SG_STORE16_GUARD(mm);
       reinterpret_cast<f32x4*>(v)[i] = vv;
+      SG_STORE16_GUARD(vv);
       reinterpret_cast<f32x4*>(p)[i] = pp;
+      SG_STORE16_GUARD(pp);
     }
     if (ema) {
       f32x4 ee = reinterpret_cast<f32x4*>(ema)[i];
       ee -= omd * (ee - pp);
       reinterpret_cast<f32x4*>(ema)[i] = ee;
+      SG_STORE16_GUARD(ee);
     }
   }
   for (int64_t i = nv * 4 + tid0; i < numel; i += stride) {
@@ -86,12 +90,16 @@ __global__ void optim_step_kernel(float* __restrict__ p, const float* __restrict
       pp[e] = pe; a[e] = ae; b[e] = be;
     }
     if (KIND != SG_OPT_SGD) reinterpret_cast<f32x4*>(s1)[i] = a;
+    SG_STORE16_GUARD(a);
     if (KIND == SG_OPT_ADADELTA) reinterpret_cast<f32x4*>(s2)[i] = b;
+    SG_STORE16_GUARD(b);
     reinterpret_cast<f32x4*>(p)[i] = pp;
+    SG_STORE16_GUARD(pp);
     if (ema) {
       f32x4 ee = reinterpret_cast<f32x4*>(ema)[i];
       ee -= omd * (ee - pp);
       reinterpret_cast<f32x4*>(ema)[i] = ee;
+      SG_STORE16_GUARD(ee);
     }
   }
   for (int64_t i = nv * 4 + tid0; i < numel; i += stride) {

@@ -51,7 +51,8 @@ def test_two_phase_handoff_matches_oracle_replay(tmp_path, monkeypatch):
             np.save(d / f'{i:03d}.npy', np.clip(rng.normal(1024, 512, shape), 0, 4095).astype(np.int16))
     monkeypatch.setattr(T.L, 'RandomSource', _make_random_source_class(F, L))
     args = argparse.Namespace(
-        architecture='pgan', dataset_path=str(tmp_path / 'data'), start_shape=str(BASE_SHAPE), final_shape='(1, 2, 8, 8)',
+        architecture='pgan', dataset_path=str(tmp_path / 'data'), start_shape=str(BASE_SHAPE), final_shape='(1, 4, 16, 16)',     # utils.py:211-217: log2(16 / 4) = 2 phases
+        
         starting_phase=1, ending_phase=2, scratch_path=None, base_batch_size=bbs, max_global_batch_size=None,
         mixing_nimg=mix, stabilizing_nimg=stab, seed=seed, horovod=False, checkpoint_every_nsteps=10 ** 9,
         logdir=str(tmp_path / 'run'), continue_path=None, starting_alpha=1.0, latent_dim=LATENT, activation='leaky_relu',

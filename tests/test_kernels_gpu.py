@@ -512,7 +512,7 @@ def test_conv_64_to_32_split_over_input_channels(sg_env):
     import ctypes as C
     from saragan_amd import functional as F, _lib
     dtype = torch.bfloat16
-    n, cin, cout, sp = 2, 64, 32, (5, 22, 64)
+    n, cin, cout, sp = 2, 64, 32, (5, 126, 256)     # 256 column pairs: one per block of the persistent grid
     x = rnd((n, cin, *sp), 71, dtype)
     w = rnd((3, 3, 3, cin, cout), 72, dtype)
     b = rnd((cout,), 73, torch.float32) * 0.3
@@ -577,8 +577,7 @@ def test_trilinear_up2x_and_adjoint(shape, dtype):
     (gxr,) = torch.autograd.grad(yr, xr, gy, create_graph=True)
     (gxg,) = torch.autograd.grad(yg, xg, cl(gy, dtype), create_graph=True)
     close(gxg, gxr, dtype, 'trilinear adjoint')
-    (ggr,) = torch.autograd.grad((gxr * gxr).sum(), xr, allow_unused=True)
-    assert ggr is None                      # linear op: no second-order term w.r.t. x
+    assert not gxr.requires_grad            # linear op: the gradient does not depend on x
     gy2 = cl(gy, dtype).requires_grad_(True)
     gx2 = torch.autograd.grad(F.upscale_trilinear2x(xg), xg, gy2, create_graph=True)[0]
     (back,) = torch.autograd.grad(gx2, gy2, cl(x, dtype))       # adjoint of the adjoint = the forward op

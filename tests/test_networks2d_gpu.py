@@ -77,7 +77,7 @@ def test_pgan_2d_step_matches_oracle(alpha):
         for v, g_ in zip(hv, grads):
             assert rel_l2(g_, refs[v.key].reshape(g_.shape)) <= 1e-2, v.key      # 2-4 channel layers: f32 noise shows
     for k_, v in store.vars.items():
-        assert_adam_close(v, p[k_].reshape(v.shape), 1e-3, 1e-4, k_)
+        assert_adam_close(v, p[k_].reshape(v.shape), 1e-3, 1e-4, k_, max_flip_frac=1e-3)
 
 
 def test_pgan_2d_legacy_signature_1024():

@@ -1,0 +1,99 @@
+"""Every epilogue variant of the sliding-halo forward kernel against the same layer through the other forward kernels
+(SG_FWD_NO_V3S=1) on a shape that engages it (>= 256 tile-column pairs): plain, bias + LeakyReLU + sign words,
+masked, pixel-norm (+ scale, sign words), pooled, and the K-split pair.  Diagnostic; prints the worst deviations."""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from saragan_amd import _lib, functional as F   # noqa: E402
+
+lib = _lib.load()
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+
+
+def run(no_v3s, fn):
+    os.environ['SG_FWD_NO_V3S'] = '1' if no_v3s else '0'
+    lib.sg_config_reload()
+    lib.sg_prof_enable(1)
+    out = fn()
+    torch.cuda.synchronize()
+    ents = (_lib.ProfEntry * 64)()
+    cnt = C.c_int32(0)
+    lib.sg_prof_collect(ents, 64, C.byref(cnt))
+    lib.sg_prof_enable(0)
+    return out, sorted({ents[i].kernel.decode() for i in range(cnt.value)})
+
+
+def cmp(tag, a, b):
+    worst = 0.0
+    for x, y in zip(a, b):
+        if x is None and y is None:
+            continue
+        if x.dtype in (torch.int32, torch.int64):
+            d = float((x != y).float().mean())
+            print(f'   {tag}: sign words differing {d:.2e}')
+            worst = max(worst, d * 10)
+            continue
+        x, y = x.float(), y.float()
+        bad = ~torch.isfinite(x)
+        d = float((x - y).abs().max() / y.abs().max())
+        if d > 2e-2:
+            wrong = ((x - y).abs() > 2e-2 * y.abs().max()).nonzero()
+            print(f'      {wrong.shape[0]} wrong elements of {x.numel()}, shape {tuple(x.shape)} strides {x.stride()}')
+            print('      first:', wrong[:6].tolist(), ' last:', wrong[-6:].tolist())
+            for dim in range(wrong.shape[1]):
+                u = torch.unique(wrong[:, dim])
+                print(f'      dim {dim}: {u.numel()} distinct, {u[:12].tolist()}')
+        print(f'   {tag}: max |diff| / max |ref| = {d:.3e}   non-finite {int(bad.sum())}')
+        worst = max(worst, d if not bool(bad.any()) else 1e9)
+    return worst
+
+
+ok = True
+for (n, cin, cout, sp) in [(2, 32, 32, (6, 128, 256)), (2, 32, 64, (8, 126, 256)), (3, 16, 32, (4, 128, 256)),
+                           (2, 64, 32, (6, 128, 256))]:
+    x = torch.randn(n, cin, *sp, device=dev).bfloat16().contiguous(memory_format=torch.channels_last_3d)
+    w = torch.randn(3, 3, 3, cin, cout, device=dev)
+    b = torch.randn(cout, device=dev) * 0.3
+    coef = (2.0 / (27 * cin)) ** 0.5
+    words = torch.randint(-2 ** 31, 2 ** 31 - 1, (n * sp[0] * sp[1] * sp[2] * (cout // 32),), device=dev, dtype=torch.int64).to(torch.int32)
+    cases = {
+        'plain': dict(),
+        'bias+act+signs': dict(bias=b, act=True, want_signs=True),
+        'masked': dict(mask_bits=words, mask_slope=0.2),
+        'pn+act+scale+signs': dict(bias=b, act=True, pixel_norm=True, want_scale=True, want_signs=True),
+        'pn': dict(bias=b, act=True, pixel_norm=True),
+        'pool+signs': dict(bias=b, act=True, want_signs=True, pool=True),
+    }
+    for name, kw in cases.items():
+        if kw.get('pool') and cin > 32:
+            continue
+        got, kg = run(False, lambda: F.raw_conv(x, w, coef, False, **kw))
+        ref, kr = run(True, lambda: F.raw_conv(x, w, coef, False, **kw))
+        print(f'n{n} {cin}->{cout} {sp} {name}: {kg} vs {kr}')
+        if ref is None or got is None:
+            print('   (not available on one path)', got is None, ref is None)
+            continue
+        wst = cmp(name, got, ref)
+        if wst > 2e-2:
+            ok = False
+            print('   ** MISMATCH')
+            if not kw.get('pixel_norm') and not kw.get('pool') and 'mask_bits' not in kw:
+                wq = (w * coef).bfloat16().float()
+                z = torch.nn.functional.conv3d(x.float(), wq.permute(4, 3, 0, 1, 2).contiguous(), padding=1)
+                if 'bias' in kw:
+                    z = z + b.view(1, -1, 1, 1, 1)
+                if kw.get('act'):
+                    z = torch.nn.functional.leaky_relu(z, 0.2)
+                for nm, t in (('sliding-halo', got[0]), ('other', ref[0])):
+                    e = (t.float() - z).abs()
+                    print(f'      {nm} vs torch fp32: max err {float(e.max()):.3e} (ref max {float(z.abs().max()):.3e}), '
+                          f'{int((e > 0.05 * z.abs().max()).sum())} elements off')
+os.environ['SG_FWD_NO_V3S'] = '0'
+lib.sg_config_reload()
+print('OK' if ok else 'FAILED')
+sys.exit(0 if ok else 1)

@@ -2218,7 +2218,7 @@ static int launch_pw_fwd(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st,
   return SG_OK;
 }
 
-static unsigned long long* g_dbg_ts = nullptr;
+unsigned long long* g_dbg_ts = nullptr;   // in-kernel phase stamps (tools/ts_conv.py, tools/ts_wgrad.py); also read by wgrad.hip
 extern "C" __attribute__((visibility("default"))) void sg_debug_set_ts_buffer(void* p) { g_dbg_ts = (unsigned long long*)p; }
 
 extern "C" size_t sg_conv3d_fwd_workspace(const sg_conv_shape* s, sg_dtype dt) {

@@ -28,7 +28,9 @@ struct WgradArgs {
   int plane_rows;  // wgrad3: LDS rows per halo plane slot
   float* dbias;    // optional [cout]: column sums of dy (bias gradient), accumulated by the ci_t == 0 blocks
   int dbg_flags;   // diagnostic ablations (0 in production): 1 = stage only the first items
+  unsigned long long* dbg;   // in-kernel phase stamps (sg_debug_set_ts_buffer), nullptr in production
 };
+extern unsigned long long* g_dbg_ts;
 
 constexpr int WG_MAXT = 7;  // taps per wave
 
@@ -824,9 +826,16 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
   __syncthreads();
 
   typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
+  int dbgi = 0;
+  auto stamp = [&]() {
+    if (a.dbg != nullptr && blockIdx.x == 8 && blockIdx.y == 0 && lane == 0 && wave == 0 && dbgi < 120)
+      a.dbg[grp * 128 + dbgi] = __builtin_amdgcn_s_memtime();
+    ++dbgi;
+  };
   const int nphase = 2 * items_max + 1;
   for (int p = 0; p < nphase; ++p) {
     const int q = p >> 1;
+    stamp();
     if ((p & 1) == grp) {
       if (q < items_mine) {
         const int di = q % g.nTd;
@@ -846,11 +855,292 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
     } else {
       const int qn = (p + 1) >> 1;
       if (qn < items_mine && !((a.dbg_flags & 1) && p >= 2)) stage_item(qn);
+      stamp();
+      if (a.dbg != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stamps only: issue vs landed
     }
+    stamp();
     __syncthreads();
   }
   const int r = lane & 31, hh = lane >> 5;
   if (ones_last && items_mine > 0 && hh == 0 && co_t * 32 + r < a.cout)   // row 0 of the ones product = column sums
+    unsafeAtomicAdd(a.dbias + co_t * 32 + r, acc[MAXT - 1][0]);
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    const int tap = wave + 4 * j;
+    if (tap < TAPS && items_mine > 0) {
+      float* dst = a.dwt + ((((int64_t)tap * a.ciT + ci_t) * a.coT + co_t) << 10);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+        unsafeAtomicAdd(dst + row * 32 + r, acc[j][i]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// wgrad v3 "lean" (bf16, 3x3x3, no fused up-sampling; tiles 2 x 4 x 32, halo plane slots of 208 64-byte rows):
+// the sliding-halo kernel above with (a) the fragment addresses of the unrolled K loop folded into 14 per-tile base
+// registers + instruction offsets -- the loop above spends three of its seven instructions per MFMA on address
+// arithmetic, and one wave issues roughly one instruction per 5 cycles: in-kernel stamps, 49 cycles per MFMA --
+// and (b) staging through buffer resources with per-column lane offsets and scalar per-tile offsets (LDS-DMA,
+// hardware zero fill) instead of 64-bit pointer selects per piece: the staging of one tile took 4.8-5.8k cycles
+// to ISSUE, as long as the MFMA phase it should hide behind.
+// ------------------------------------------------------------------------------------------------------
+template <int PF>
+struct sg_wgrad_tile_lean {
+  static constexpr int MAXT = 7, TH = 4, HW = 34;
+  static constexpr int IPS = 1 + MAXT, NI = 16 * IPS, RING = PF + 1;
+  typedef s16x4 frag_t;
+  struct Ctx {
+    int xb[2][MAXT];   // per (td, tap slot): lane part + ring slot + tap shift
+    int yb;            // lane part of the dy image
+    int ones_last;
+  };
+  template <int I>
+  static __device__ __forceinline__ void load(const Ctx& c, frag_t (&a0)[RING], frag_t (&a1)[RING], frag_t (&b0)[2],
+                                              frag_t (&b1)[2]) {
+    constexpr int ks = I / IPS, r = I % IPS, line = ks / 2, half = ks % 2, td = line / TH, th = line % TH;
+    if constexpr (r == 0) {
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b0[ks & 1]) : "v"(c.yb), "n"(ks * 1024));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b1[ks & 1]) : "v"(c.yb), "n"(ks * 1024 + 256));
+    } else {
+      constexpr int j = r - 1, SL = (ks * MAXT + j) % RING;
+      constexpr int off = th * HW * 64 + half * 1024;
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a0[SL]) : "v"(c.xb[td][j]), "n"(off));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a1[SL]) : "v"(c.xb[td][j]), "n"(off + 256));
+    }
+  }
+  template <int I>
+  static __device__ __forceinline__ void step(const Ctx& c, f32x16 (&acc)[MAXT], frag_t (&a0)[RING], frag_t (&a1)[RING],
+                                              frag_t (&b0)[2], frag_t (&b1)[2]) {
+    if constexpr (I < NI) {
+      if constexpr (I + PF < NI) load<I + PF>(c, a0, a1, b0, b1);
+      constexpr int ks = I / IPS, r = I % IPS;
+      if constexpr (r != 0) {
+        constexpr int younger = (NI - 1 - I < PF ? NI - 1 - I : PF) * 2;
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger));
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int j = r - 1, SL = (ks * MAXT + j) % RING;
+        u32x4 af, bf;
+        af[0] = __builtin_bit_cast(u32x2, a0[SL])[0]; af[1] = __builtin_bit_cast(u32x2, a0[SL])[1];
+        af[2] = __builtin_bit_cast(u32x2, a1[SL])[0]; af[3] = __builtin_bit_cast(u32x2, a1[SL])[1];
+        if constexpr (j == MAXT - 1) {
+          if (c.ones_last) af = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};   // bf16 1.0 x 8
+        }
+        bf[0] = __builtin_bit_cast(u32x2, b0[ks & 1])[0]; bf[1] = __builtin_bit_cast(u32x2, b0[ks & 1])[1];
+        bf[2] = __builtin_bit_cast(u32x2, b1[ks & 1])[0]; bf[3] = __builtin_bit_cast(u32x2, b1[ks & 1])[1];
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf),
+                                                        acc[j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      step<I + 1>(c, acc, a0, a1, b0, b1);
+    }
+  }
+  template <int I>
+  static __device__ __forceinline__ void prologue(const Ctx& c, frag_t (&a0)[RING], frag_t (&a1)[RING], frag_t (&b0)[2],
+                                                  frag_t (&b1)[2]) {
+    if constexpr (I < PF && I < NI) {
+      load<I>(c, a0, a1, b0, b1);
+      prologue<I + 1>(c, a0, a1, b0, b1);
+    }
+  }
+  static __device__ __forceinline__ void run(const Ctx& c, f32x16 (&acc)[MAXT]) {
+    frag_t a0[RING], a1[RING], b0[2], b1[2];
+    prologue<0>(c, a0, a1, b0, b1);
+    step<0>(c, acc, a0, a1, b0, b1);
+  }
+};
+
+__global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int TAPS = 27, MAXT = 7;
+  constexpr int HH = 6, HW = 34, PB = 208 * 64, XB = 4 * PB, YB = 256 * 64, BUF = XB + YB;
+  constexpr int XPIECES = PB / 1024;                 // 13 1-KiB pieces per halo plane
+  constexpr uint32_t DEAD = 0x80000000u;             // byte offset beyond every buffer: the DMA writes zeros
+  const sg_tile_geom& g = a.g;                       // TN=1, TD=2, TH=4, TW=32, HD=4, HH=6, HW=34, no up-sampling (host-checked)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave8 >> 2, wave = wave8 & 3;
+  const int xmine = grp * BUF, ymine = xmine + XB;   // byte offsets into smem
+  const int ci_t = blockIdx.y / a.coT, co_t = blockIdx.y % a.coT;
+  const int D = g.D, H = g.H, W = g.W, nTd = g.nTd, cin = a.cin, cout = a.cout;
+
+  // column schedule: XCD group xg owns a contiguous chunk of the (n, h, w) column list; group g takes columns g, g+2, ...
+  const int ncol = g.nTn * g.nTh * g.nTw;
+  const int xg = blockIdx.x & 7, bslot = blockIdx.x >> 3;
+  const int per_x = gridDim.x >> 3;
+  const int cpx = (ncol + 7) >> 3;
+  const int c_begin = xg * cpx, c_end = min(ncol, c_begin + cpx);
+  const int cfirst = c_begin + bslot;
+  const int ncols_blk = cfirst < c_end ? (c_end - cfirst + per_x - 1) / per_x : 0;
+  const int ncols_mine = (ncols_blk + 1 - grp) >> 1;
+  const int items_mine = ncols_mine * nTd;
+  const int items_max = ((ncols_blk + 1) >> 1) * nTd;
+
+  const int i16 = lane & 15, q16 = lane >> 4;
+  const int qd = i16 >> 2, pp = i16 & 3;
+  const int colb = (16 * (q16 & 1) + 4 * pp) * 2;
+  const int kb = 8 * (q16 >> 1) + qd;
+  const int xl0 = xmine + kb * 64 + colb, yl0 = ymine + kb * 64 + colb;
+
+  // plane-local staging tables: this lane's 16-byte pieces of 1-KiB blocks wave, wave+4, ... of a halo plane / the dy tile
+  constexpr int MAXP = 4, MAXY = 4;
+  uint32_t relx[MAXP], rely[MAXY];
+  int crdx[MAXP], crdy[MAXY];
+#pragma unroll
+  for (int k = 0; k < MAXP; ++k) {
+    const int it = (wave + 4 * k) * 64 + lane;
+    const int row = it >> 2, c = ci_t * 32 + (it & 3) * 8;
+    const int hh_ = row / HW, hw = row - hh_ * HW;
+    const bool live = row < HH * HW && c < cin && (wave + 4 * k) < XPIECES;
+    relx[k] = live ? (uint32_t)(((hh_ * W + hw) * cin + c) * 2) : 0xC0000000u;   // stays >= DEAD after + tile offset
+    crdx[k] = live ? (hw | (hh_ << 8)) : 0x7F7F;
+  }
+#pragma unroll
+  for (int k = 0; k < MAXY; ++k) {
+    const int it = (wave + 4 * k) * 64 + lane;
+    const int row = it >> 2, c = co_t * 32 + (it & 3) * 8;   // row = (td * 4 + th) * 32 + tw
+    const int tw = row & 31, th = (row >> 5) & 3, td = row >> 7;
+    rely[k] = c < cout ? (uint32_t)((((td * H + th) * W + tw) * cout + c) * 2) : 0xC0000000u;
+    crdy[k] = th;
+  }
+  const int64_t svox = (int64_t)D * H * W;
+  const int64_t xsb = svox * cin * 2, ysb = svox * cout * 2;
+  const uint32_t xplane = (uint32_t)(H * W * cin * 2), yplane = (uint32_t)(H * W * cout * 2);
+
+  // cursor over my tiles: column cj of my list, step di along D; per column: resources and lane offsets
+  int cj = 0, di = 0;
+  __amdgpu_buffer_rsrc_t rx, ry;
+  uint32_t vkx[MAXP], vky[MAXY];
+  auto enter_column = [&]() {
+    const int col = cfirst + (2 * cj + grp) * per_x;
+    const int c1 = (int)sg_div((uint32_t)col, g.fnTw);
+    const int w0 = (col - c1 * g.nTw) * 32;
+    const int c2 = (int)sg_div((uint32_t)c1, g.fnTh);
+    const int h0 = (c1 - c2 * g.nTh) * 4;
+    const int n0 = c2;
+    rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.x)) + n0 * xsb, 0, (int)xsb, 0x00020000);
+    ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.dy)) + n0 * ysb, 0, (int)ysb, 0x00020000);
+    const int tile_off = ((h0 - 1) * W + (w0 - 1)) * cin * 2;   // may be negative: only dead lanes go below 0
+    const int lo_w = max(0, 1 - w0), hi_w = min(HW, W + 1 - w0) - 1;
+    const int lo_h = max(0, 1 - h0), hi_h = min(HH, H + 1 - h0) - 1;
+    const uint32_t lo = (uint32_t)(lo_w | (lo_h << 8));
+    const uint32_t hi = (uint32_t)(hi_w | (hi_h << 8)) | 0x8080u;
+#pragma unroll
+    for (int k = 0; k < MAXP; ++k) {
+      const uint32_t c_ = (uint32_t)crdx[k];
+      const uint32_t t1 = (c_ | 0x8080u) - lo, t2 = hi - c_;
+      vkx[k] = (t1 & t2 & 0x8080u) == 0x8080u ? relx[k] + (uint32_t)tile_off : DEAD;
+    }
+    const int col_off = (h0 * W + w0) * cout * 2;
+    const int rows_left = H - h0;                                // W is a multiple of 32 (host-checked): every tw is inside
+#pragma unroll
+    for (int k = 0; k < MAXY; ++k) vky[k] = (crdy[k] < rows_left && rely[k] < DEAD) ? rely[k] + (uint32_t)col_off : DEAD;
+  };
+  // staging of the cursor's tile: the new halo planes (all four at the bottom of a column) and the dy tile
+  auto stage = [&]() {
+    const int d0 = 2 * di;
+#pragma unroll
+    for (int hd = 0; hd < 4; ++hd) {
+      if (hd < 2 && di != 0) continue;                           // uniform
+      const int gp = d0 - 1 + hd;
+      const bool plane_ok = gp >= 0 && gp < D;
+      const uint32_t soff = plane_ok ? (uint32_t)gp * xplane : 0u;
+      char* dst = smem + xmine + ((gp + 8) & 3) * PB;
+#pragma unroll
+      for (int k = 0; k < MAXP; ++k)
+        if (wave + 4 * k < XPIECES)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(dst + (wave + 4 * k) * 1024), 16, plane_ok ? vkx[k] : DEAD, soff, 0, 0);
+    }
+    const uint32_t ysoff = (uint32_t)d0 * yplane;
+#pragma unroll
+    for (int k = 0; k < MAXY; ++k) {
+      const bool ok = d0 + (k >> 1) < D;                          // pieces 8..15 are the tile's second D plane
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_ptr_t)(smem + ymine + (wave + 4 * k) * 1024), 16, ok ? vky[k] : DEAD, ysoff, 0, 0);
+    }
+  };
+  auto advance = [&]() {
+    if (++di == nTd) {
+      di = 0;
+      ++cj;
+      if (cj < ncols_mine) enter_column();
+    }
+  };
+
+  // per-wave taps
+  int tap_hw[MAXT], tap_kd[MAXT];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j) {
+    const int tap = wave + 4 * j;
+    const int kw_i = tap % 3, kh_i = (tap / 3) % 3, kd_i = tap / 9;
+    tap_hw[j] = tap < TAPS ? (kh_i * HW + kw_i) * 64 : 0;
+    tap_kd[j] = tap < TAPS ? kd_i : 0;
+  }
+  // bias gradient: wave 3's last slot is spare (27 = 4*7 - 1 taps); it multiplies dy by ones
+  const int ones_last = (a.dbias != nullptr && ci_t == 0 && wave == 3) ? 1 : 0;
+  f32x16 acc[MAXT];
+#pragma unroll
+  for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  int dbgi = 0;
+  auto stamp = [&]() {
+    if (a.dbg != nullptr && blockIdx.x == 8 && blockIdx.y == 0 && lane == 0 && wave == 0 && dbgi < 120)
+      a.dbg[grp * 128 + dbgi] = __builtin_amdgcn_s_memtime();
+    ++dbgi;
+  };
+  typedef sg_wgrad_tile_lean<5> KT;
+  auto mfma_phase = [&](int q) {
+    const int dq = q % nTd;
+    const int pbase = 2 * dq - 1 + 8;                             // plane of halo index 0 (kept non-negative)
+    KT::Ctx c;
+    c.yb = yl0;
+    c.ones_last = ones_last;
+#pragma unroll
+    for (int td = 0; td < 2; ++td)
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j) c.xb[td][j] = xl0 + ((pbase + td + tap_kd[j]) & 3) * PB + tap_hw[j];
+    KT::run(c, acc);
+  };
+  const bool stage_first_only = (a.dbg_flags & 1) != 0;
+  auto off_phase = [&](int qn) {                                  // stage my tile qn (the cursor's)
+    if (qn < items_mine && !(stage_first_only && qn >= 1)) stage();
+    stamp();
+    if (qn < items_mine) advance();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the DMA has landed before the barrier releases the readers
+  };
+
+  if (items_mine > 0) enter_column();
+  if (grp == 0) {
+    off_phase(0);
+    __syncthreads();
+    for (int q = 0; q < items_max; ++q) {
+      stamp();
+      if (q < items_mine) mfma_phase(q);
+      stamp();
+      __syncthreads();
+      stamp();
+      off_phase(q + 1);
+      stamp();
+      __syncthreads();
+    }
+  } else {
+    __syncthreads();
+    for (int q = 0; q < items_max; ++q) {
+      stamp();
+      off_phase(q);
+      stamp();
+      __syncthreads();
+      stamp();
+      if (q < items_mine) mfma_phase(q);
+      stamp();
+      __syncthreads();
+    }
+  }
+  const int r = lane & 31, hh = lane >> 5;
+  if (ones_last && items_mine > 0 && hh == 0 && co_t * 32 + r < cout)   // row 0 of the ones product = column sums
     unsafeAtomicAdd(a.dbias + co_t * 32 + r, acc[MAXT - 1][0]);
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
@@ -892,11 +1182,21 @@ static int launch_wgrad3(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   a.ybytes = 256 * 64;
   const size_t lds = 2ull * (a.xbytes + a.ybytes);
   if (lds > 160 * 1024) return SG_OK;
-  auto kern = conv_wgrad3_kernel<KD, KH, KW>;
-  SG_ALLOW_160K_LDS(kern);
   a.tap0 = 0; a.taps_blk = a.taps;
-  SG_KNAME("conv_wgrad3<%d,%d,%d>", KD, KH, KW);
-  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);
+  // the lean variant: 3x3x3 without fused up-sampling, whole 32-wide rows, one sample of either tensor below 2 GiB
+  const bool lean = KD == 3 && KH == 3 && KW == 3 && !g.ups && g.HH == 6 && g.HW == 34 && g.HD == 4 && a.plane_rows == 208 &&
+                    s->w % 32 == 0 && !sg_cfg().wgrad_no_lean;
+  if (lean) {
+    auto kern = conv_wgrad3l_kernel;
+    SG_ALLOW_160K_LDS(kern);
+    SG_KNAME("conv_wgrad3l");
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);
+  } else {
+    auto kern = conv_wgrad3_kernel<KD, KH, KW>;
+    SG_ALLOW_160K_LDS(kern);
+    SG_KNAME("conv_wgrad3<%d,%d,%d>", KD, KH, KW);
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);
+  }
   SG_LAUNCH_CHECK();
   *used = true;
   return SG_OK;
@@ -960,6 +1260,7 @@ extern "C" int sg_conv3d_wgrad_bias(const void* x, const void* dy, float* dw, fl
   a.dbias = dbias;
   bool db_done = false;
   a.dbg_flags = sg_cfg().dbg_flags;
+  a.dbg = g_dbg_ts;
   a.x = x; a.dy = dy; a.dwt = reinterpret_cast<float*>(workspace);
   a.cin = s->cin; a.cout = s->cout;
   a.taps = s->kd * s->kh * s->kw; a.kh = s->kh; a.kw = s->kw;

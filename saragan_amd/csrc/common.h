@@ -95,6 +95,21 @@ __device__ __forceinline__ f32x16 sg_mfma_chunk<bf16_t>(u32x4 a, u32x4 b, f32x16
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b),
                                                  c, 0, 0, 0);
 }
+// In-place form for the unrolled ping-pong loops (bf16): the accumulator is tied to one register tuple.  With the
+// builtin the compiler may write the product to another tuple (D != C) and, at the joins of the per-variant code paths,
+// copies 16-32 accumulator registers per phase behind the MFMA result hazard (s_nop 11 + v_mov runs: ~250 cycles of a
+// 4k-cycle phase).  Hazards are the caller's: no VALU may read `c` within 18 issue slots of the last call (the loops end
+// with sg_mfma_drain), and `c` must not have been written by a VALU instruction in the two slots before the first.
+__device__ __forceinline__ void sg_mfma_bf16_acc(f32x16& c, u32x4 a, u32x4 b) {
+  asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+// 18 wait states after the last sg_mfma_bf16_acc on these accumulators; tied to them so that no compiler-generated
+// read (a register copy at a join, say) can be scheduled in front of it
+template <int N>
+__device__ __forceinline__ void sg_mfma_drain(f32x16 (&acc)[N]) {
+  static_assert(N == 2, "extend the operand list");
+  asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]));
+}
 template <>
 __device__ __forceinline__ f32x16 sg_mfma_chunk<float>(u32x4 a, u32x4 b, f32x16 c) {
   f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);

@@ -1123,8 +1123,8 @@ struct sg_unrolled_ks2 {
       asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger(ST)));
       __builtin_amdgcn_sched_barrier(0);
       constexpr int pl = ST & 3;
-      if constexpr (pl <= 2) acc[0] = sg_mfma_chunk<T>(wfr[ST % RING], xfr[ST % RING], acc[0]);
-      if constexpr (pl >= 1) acc[1] = sg_mfma_chunk<T>(wfr[(ST - 1) % RING], xfr[ST % RING], acc[1]);
+      if constexpr (pl <= 2) sg_mfma_bf16_acc(acc[0], wfr[ST % RING], xfr[ST % RING]);
+      if constexpr (pl >= 1) sg_mfma_bf16_acc(acc[1], wfr[(ST - 1) % RING], xfr[ST % RING]);
       __builtin_amdgcn_sched_barrier(0);
       step<ST + 1>(acc, wfr, xfr, xa, wl_off);
     }
@@ -1137,9 +1137,11 @@ struct sg_unrolled_ks2 {
     }
   }
   static __device__ __forceinline__ void run(f32x16 (&acc)[2], const int (&xa)[9][GC], int wl_off) {
+    static_assert(sizeof(T) == 2, "bf16 only");
     u32x4 wfr[RING], xfr[RING];
     prologue<0>(wfr, xfr, xa, wl_off);
     step<0>(acc, wfr, xfr, xa, wl_off);
+    sg_mfma_drain(acc);
   }
 };
 
@@ -1147,6 +1149,9 @@ struct sg_unrolled_ks2 {
 // spent most of its ~4.3k cycles on scalar bookkeeping -- 200 spilled SGPRs (v_readlane), kernel arguments re-read
 // from memory behind s_waitcnt lgkmcnt(0), branches around features the launch did not use.
 enum : int { SG_EP_SIGN = 1, SG_EP_MASK = 2, SG_EP_PN = 4, SG_EP_POOL = 8 };
+#ifndef SG_V3S_RING
+#define SG_V3S_RING 6   // fragment ring of the MFMA phase: reads run RING - 2 steps (of 1-2 MFMAs) ahead of their use
+#endif
 
 template <int GC, int KS, int EPI>   // KS: 0 whole layer; 1 / 2: first / second pass of a layer split over its input channels
 __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
@@ -1284,11 +1289,18 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
       for (int k = 0; k < MAXP; ++k) stg[j][k] = __builtin_amdgcn_raw_buffer_load_b128(rxP, plane_ok ? vk[k] : DEAD, soff, 0);
     }
   };
+  // Ring slot of a halo plane: by its D index, shifted by two slots for the columns that START at an odd running tile
+  // index (qP - P.di odd).  The tiles of a group then alternate strictly between the two ring rotations whatever the
+  // number of tiles per column -- all four planes are rewritten at a column start anyway -- and the two rotations
+  // of the unrolled MFMA code follow each other in straight-line code instead of behind a branch on the tile's parity
+  // (at whose join the compiler shuffled all 32 accumulator registers, every phase).
+  int qP = 0;                                        // index of P's tile in my list
   auto store_planes = [&](int d0, int hd0) {
+    const int rot2 = 2 * ((qP - P.di) & 1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int gp = d0 - 1 + hd0 + j;
-      char* dst = xmine + ((gp + 8) & 3) * PB + wofs;
+      char* dst = xmine + ((gp + rot2 + 8) & 3) * PB + wofs;
 #pragma unroll
       for (int k = 0; k < MAXP; ++k)
         if (wave + 4 * k < PPIECES) *reinterpret_cast<u32x4*>(dst + (wave + 4 * k) * 1024) = stg[j][k];
@@ -1329,8 +1341,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   // at the start of the following one: they are in flight during the group's whole MFMA phase.  (Requested at the
   // start of the off-phase that needs them, their ~3 us under load made the off-phase longer than the MFMA phase:
   // in-kernel stamps, 5.1k against 4.6k cycles.)  `stg` is therefore live across the MFMA phase.
-  const bool no_stage = (a.dbg_flags & 1) != 0, no_epi = (a.dbg_flags & 2) != 0, no_mfma = (a.dbg_flags & 8) != 0;
-  int qP = 0;                                        // index of P's tile in my list
+  const bool no_stage = (a.dbg_flags & 1) != 0, no_epi = (a.dbg_flags & 2) != 0;
   if (items_mine > 0) {
     enter_column_P();
     enter_column_E();
@@ -1360,15 +1371,17 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
       a.dbg[grp * 128 + dbgi] = __builtin_amdgcn_s_memtime();
     ++dbgi;
   };
-  auto mfma_phase = [&](int di) {
+  auto init_acc = [&]() {   // at the end of an off-phase (the accumulators are free once the epilogue has run)
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mt][i] = bias_lds[(i & 3) + 8 * (i >> 2) + 4 * hh];   // bias rides in C
-    if (no_mfma) { /* diagnostic: no MFMA phase */ }
-    else if (di & 1) sg_unrolled_ks2<T, GC, 1, 6>::run(acc, xa, wl_off);
-    else sg_unrolled_ks2<T, GC, 3, 6>::run(acc, xa, wl_off);
+    // two separate register tuples from here on (equal values: left to itself the compiler keeps ONE copy, lets the
+    // first MFMA of each chain write elsewhere and shuffles 32 registers per phase to get back)
+    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
   };
+  auto mfma_even = [&]() { sg_unrolled_ks2<T, GC, 3, SG_V3S_RING>::run(acc, xa, wl_off); };   // tiles 0, 2, ... of my list
+  auto mfma_odd = [&]() { sg_unrolled_ks2<T, GC, 1, SG_V3S_RING>::run(acc, xa, wl_off); };
 
   // ---- off-phase: P's planes (requested one phase ago) into the ring, epilogue of E's tile (if `closes`), request
   // the planes of the tile after P
@@ -1514,34 +1527,46 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
       }
       if (qP < items_mine && !no_stage) load_planes(2 * P.di, 2);
     }
+    init_acc();
   };
-  // Each wave group runs its own straight loop (one phase apart, paced by the block barrier) so that the registers
-  // that live across phases -- the accumulators and the halo planes in flight -- are plain loop-carried values: in
-  // one loop over phases with a group-dependent branch the compiler copied all 64 of them at the loop's end, behind
-  // an s_waitcnt vmcnt(0) that undid the prefetch.
+  // Each wave group runs its own straight loop (one phase apart, paced by the block barrier), two tiles per trip, so
+  // that the registers that live across phases -- the accumulators and the halo planes in flight -- are plain
+  // loop-carried values: in one loop over phases with a group-dependent branch the compiler copied all 64 of them at
+  // the loop's end, behind an s_waitcnt vmcnt(0) that undid the prefetch.
   if (grp == 0) {
-    for (int q = 0; q < items_mine; ++q) {
+    init_acc();
+    for (int q = 0; q < items_mine; q += 2) {
+      const bool second = q + 1 < items_mine;
       stamp();
-      mfma_phase(q % nTd);
+      mfma_even();
       stamp();
       __syncthreads();
       stamp();
-      off_phase(true, q + 1 < items_mine);
+      off_phase(true, second);
       stamp();
+      __syncthreads();
+      if (second) mfma_odd();
+      __syncthreads();
+      off_phase(second, q + 2 < items_mine);
       __syncthreads();
     }
   } else {
-    for (int q = 0; q < items_mine; ++q) {
+    for (int q = 0; q < items_mine; q += 2) {
+      const bool second = q + 1 < items_mine;
       stamp();
       off_phase(q > 0, true);
       stamp();
       __syncthreads();
       stamp();
-      mfma_phase(q % nTd);
+      mfma_even();
       stamp();
       __syncthreads();
+      off_phase(true, second);
+      __syncthreads();
+      if (second) mfma_odd();
+      __syncthreads();
     }
-    if (items_mine > 0) off_phase(true, false);
+    if (items_mine > 0 && (items_mine & 1) == 0) off_phase(true, false);
   }
 }
 

@@ -5,7 +5,8 @@ from saragan_amd._lib import ConvEpilogue, ConvShape
 lib = _lib.load()
 lib.sg_debug_set_ts_buffer.argtypes = [C.c_void_p]
 dev = torch.device('cuda:0')
-n, d, h, w, cin, cout = int(os.environ.get('TS_N', '16')), 32, 128, 128, int(os.environ.get('TS_CIN', '32')), int(os.environ.get('TS_COUT', '32'))
+d, h, w = (int(t) for t in os.environ.get('TS_DHW', '32,128,128').split(','))
+n, cin, cout = int(os.environ.get('TS_N', '16')), int(os.environ.get('TS_CIN', '32')), int(os.environ.get('TS_COUT', '32'))
 shp = ConvShape(n, d, h, w, cin, cout, 3, 3, 3, 0)
 dt = _lib.SG_BF16
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)

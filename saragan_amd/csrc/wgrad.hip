@@ -952,6 +952,7 @@ struct sg_wgrad_tile_lean {
   }
 };
 
+template <bool UPS>   // UPS: x is the half-resolution tensor, gathered nearest-x2 (upscale3d fused into the layer)
 __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TAPS = 27, MAXT = 7;
@@ -994,7 +995,10 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
     const int row = it >> 2, c = ci_t * 32 + (it & 3) * 8;
     const int hh_ = row / HW, hw = row - hh_ * HW;
     const bool live = row < HH * HW && c < cin && (wave + 4 * k) < XPIECES;
-    relx[k] = live ? (uint32_t)(((hh_ * W + hw) * cin + c) * 2) : 0xC0000000u;   // stays >= DEAD after + tile offset
+    // tile origins are even, so a halo voxel's halved coordinate is a per-lane constant relative to the tile's
+    // half-resolution origin: ((h0 - 1 + hh) >> 1) = h0 / 2 + ((hh - 1) >> 1), likewise along W
+    const int rel = UPS ? ((((hh_ - 1) >> 1) * (W >> 1) + ((hw - 1) >> 1)) * cin + c) * 2 : ((hh_ * W + hw) * cin + c) * 2;
+    relx[k] = live ? (uint32_t)rel : 0xC0000000u;   // dead: stays >= DEAD after + tile offset
     crdx[k] = live ? (hw | (hh_ << 8)) : 0x7F7F;
   }
 #pragma unroll
@@ -1006,8 +1010,8 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
     crdy[k] = th;
   }
   const int64_t svox = (int64_t)D * H * W;
-  const int64_t xsb = svox * cin * 2, ysb = svox * cout * 2;
-  const uint32_t xplane = (uint32_t)(H * W * cin * 2), yplane = (uint32_t)(H * W * cout * 2);
+  const int64_t xsb = (UPS ? svox >> 3 : svox) * cin * 2, ysb = svox * cout * 2;
+  const uint32_t xplane = (uint32_t)((UPS ? (H >> 1) * (W >> 1) : H * W) * cin * 2), yplane = (uint32_t)(H * W * cout * 2);
 
   // cursor over my tiles: column cj of my list, step di along D; per column: resources and lane offsets
   int cj = 0, di = 0;
@@ -1022,7 +1026,8 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
     const int n0 = c2;
     rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.x)) + n0 * xsb, 0, (int)xsb, 0x00020000);
     ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.dy)) + n0 * ysb, 0, (int)ysb, 0x00020000);
-    const int tile_off = ((h0 - 1) * W + (w0 - 1)) * cin * 2;   // may be negative: only dead lanes go below 0
+    const int tile_off = UPS ? ((h0 >> 1) * (W >> 1) + (w0 >> 1)) * cin * 2
+                             : ((h0 - 1) * W + (w0 - 1)) * cin * 2;   // may be negative: only dead lanes go below 0
     const int lo_w = max(0, 1 - w0), hi_w = min(HW, W + 1 - w0) - 1;
     const int lo_h = max(0, 1 - h0), hi_h = min(HH, H + 1 - h0) - 1;
     const uint32_t lo = (uint32_t)(lo_w | (lo_h << 8));
@@ -1046,7 +1051,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
       if (hd < 2 && di != 0) continue;                           // uniform
       const int gp = d0 - 1 + hd;
       const bool plane_ok = gp >= 0 && gp < D;
-      const uint32_t soff = plane_ok ? (uint32_t)gp * xplane : 0u;
+      const uint32_t soff = plane_ok ? (uint32_t)(UPS ? gp >> 1 : gp) * xplane : 0u;
       char* dst = smem + xmine + ((gp + 8) & 3) * PB;
 #pragma unroll
       for (int k = 0; k < MAXP; ++k)
@@ -1184,10 +1189,15 @@ static int launch_wgrad3(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   if (lds > 160 * 1024) return SG_OK;
   a.tap0 = 0; a.taps_blk = a.taps;
   // the lean variant: 3x3x3 without fused up-sampling, whole 32-wide rows, one sample of either tensor below 2 GiB
-  const bool lean = KD == 3 && KH == 3 && KW == 3 && !g.ups && g.HH == 6 && g.HW == 34 && g.HD == 4 && a.plane_rows == 208 &&
-                    s->w % 32 == 0 && !sg_cfg().wgrad_no_lean;
-  if (lean) {
-    auto kern = conv_wgrad3l_kernel;
+  const bool lean = KD == 3 && KH == 3 && KW == 3 && g.HH == 6 && g.HW == 34 && g.HD == 4 && a.plane_rows == 208 &&
+                    s->w % 32 == 0 && !sg_cfg().wgrad_no_lean && (!g.ups || ((s->d | s->h | s->w) & 1) == 0);
+  if (lean && g.ups) {
+    auto kern = conv_wgrad3l_kernel<true>;
+    SG_ALLOW_160K_LDS(kern);
+    SG_KNAME("conv_wgrad3l<ups>");
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);
+  } else if (lean) {
+    auto kern = conv_wgrad3l_kernel<false>;
     SG_ALLOW_160K_LDS(kern);
     SG_KNAME("conv_wgrad3l");
     hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);

@@ -507,7 +507,7 @@ def test_conv_epilogue_fused_downscale():
 def test_conv_64_to_32_split_over_input_channels(sg_env):
     """The 64 -> 32 channel 3x3x3 bf16 layers run as two sliding-halo passes over 32 input channels each, f32 partial
     sums in sg_conv_epilogue.workspace (sg_conv3d_fwd_workspace).  Same inputs through the split path, through the
-    streamed single-pass kernel (SG_FWD_NO_V5=1) and through the oracle: bias, LeakyReLU, recorded sign words and the
+    streamed single-pass kernel (SG_FWD_NO_KSPLIT=1) and through the oracle: bias, LeakyReLU, recorded sign words and the
     masked (second-order) epilogue; ragged H (a dead row in the last tile pair) and odd D."""
     import ctypes as C
     from saragan_amd import functional as F, _lib
@@ -537,10 +537,10 @@ def test_conv_64_to_32_split_over_input_channels(sg_env):
 
     (y2, s2), names = kernels_of(lambda: F.raw_conv(xg, wg, coef, False, bias=bg, act=True, want_signs=True)[::2])
     assert any('K split' in k for k in names), names
-    sg_env(SG_FWD_NO_V5=1)
+    sg_env(SG_FWD_NO_KSPLIT=1)
     (y1, s1), names1 = kernels_of(lambda: F.raw_conv(xg, wg, coef, False, bias=bg, act=True, want_signs=True)[::2])
     assert not any('K split' in k for k in names1) and any('conv_fwd4' in k for k in names1), names1
-    sg_env(SG_FWD_NO_V5=0)
+    sg_env(SG_FWD_NO_KSPLIT=0)
     close(y2, yr, dtype, 'split 64 -> 32')
     close(y1, yr, dtype, 'streamed 64 -> 32')
     # f32 partial sums in both: the two paths round the same f32 sums to bf16 (summation order differs by a few ulp of f32)
@@ -553,9 +553,9 @@ def test_conv_64_to_32_split_over_input_channels(sg_env):
         assert float(flips.float().mean()) <= 64 * float(near0) + 1e-6, (float(flips.float().mean()), float(near0))
     # masked epilogue (the double-backward path): mask = recorded signs
     ym2 = F.raw_conv(xg, wg, coef, False, mask_bits=s1, mask_slope=0.2)[0]
-    sg_env(SG_FWD_NO_V5=1)
+    sg_env(SG_FWD_NO_KSPLIT=1)
     ym1 = F.raw_conv(xg, wg, coef, False, mask_bits=s1, mask_slope=0.2)[0]
-    sg_env(SG_FWD_NO_V5=0)
+    sg_env(SG_FWD_NO_KSPLIT=0)
     dm = (ym2.float() - ym1.float()).abs()
     assert float(dm.max()) <= 2.0 ** -6 * float(ym1.float().abs().max()), float(dm.max())
 

@@ -28,13 +28,17 @@ def run(no_lean, fn):
 
 
 ok = True
-for (n, cin, cout, sp) in [(2, 32, 64, (6, 128, 256)), (3, 64, 32, (5, 126, 256)), (2, 32, 32, (4, 128, 512)), (1, 64, 64, (8, 128, 256))]:
-    x = torch.randn(n, cin, *sp, device=dev).bfloat16().contiguous(memory_format=torch.channels_last_3d)
+for (n, cin, cout, sp, ups) in [(2, 32, 64, (6, 128, 256), 0), (3, 64, 32, (5, 126, 256), 0), (2, 32, 32, (4, 128, 512), 0),
+                                (1, 64, 64, (8, 128, 256), 0), (2, 64, 32, (8, 128, 256), 1), (3, 32, 32, (4, 124, 256), 1)]:
+    xsp = tuple(t // 2 for t in sp) if ups else sp
+    x = torch.randn(n, cin, *xsp, device=dev).bfloat16().contiguous(memory_format=torch.channels_last_3d)
     dy = torch.randn(n, cout, *sp, device=dev).bfloat16().contiguous(memory_format=torch.channels_last_3d)
-    (gw, gb), kg = run(False, lambda: F.raw_wgrad(x, dy, (3, 3, 3), 0.05, False, True))
-    (rw, rb), kr = run(True, lambda: F.raw_wgrad(x, dy, (3, 3, 3), 0.05, False, True))
+    (gw, gb), kg = run(False, lambda: F.raw_wgrad(x, dy, (3, 3, 3), 0.05, bool(ups), True))
+    (rw, rb), kr = run(True, lambda: F.raw_wgrad(x, dy, (3, 3, 3), 0.05, bool(ups), True))
     # torch fp32: dw[kd,kh,kw,ci,co] = sum_v x[v+tap,ci] dy[v,co]
-    xt = x.float().requires_grad_(False)
+    xt = x.float()
+    if ups:
+        xt = xt.repeat_interleave(2, 2).repeat_interleave(2, 3).repeat_interleave(2, 4)
     wt = torch.zeros(cout, cin, 3, 3, 3, device=dev, requires_grad=True)
     y = torch.nn.functional.conv3d(xt, wt, padding=1)
     (tw,) = torch.autograd.grad(y, wt, dy.float())
@@ -43,7 +47,7 @@ for (n, cin, cout, sp) in [(2, 32, 64, (6, 128, 256)), (3, 64, 32, (5, 126, 256)
     sc = float(tw.abs().max())
     e_lean, e_gen = float((gw - tw).abs().max()) / sc, float((rw - tw).abs().max()) / sc
     eb = float((gb - tb).abs().max() / tb.abs().max())
-    print(f'n{n} {cin}->{cout} {sp}: {kg} vs {kr}: lean err {e_lean:.2e}, general err {e_gen:.2e}, db err {eb:.2e}')
+    print(f'n{n} {cin}->{cout} {sp} ups{ups}: {kg} vs {kr}: lean err {e_lean:.2e}, general err {e_gen:.2e}, db err {eb:.2e}')
     if not any('wgrad3l' in k for k in kg) or e_lean > 5e-3 or eb > 5e-3 or not bool(torch.isfinite(gw).all()):
         ok = False
         print('   ** MISMATCH / lean kernel not engaged')

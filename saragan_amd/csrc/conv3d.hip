@@ -1320,6 +1320,21 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
     if (MASK) rmE = rsrc_of(a.mask_bits, wsb, E.n0);
     if (PN) rpE = rsrc_of(a.pn_scale, psb, E.n0);
   };
+  // LeakyReLU sign words of E's tile (masked epilogue): requested at the END of an off-phase, like the halo planes, and
+  // used in the next one.  Requested at the top of the off-phase that applies them, their latency (2-3k cycles under
+  // load) sat in front of the epilogue: rocprofv3 SQ_VALU_MFMA_BUSY 0.52 for the masked variant against 0.78.
+  int qE = 0;                                        // index of E's tile in my list
+  uint32_t mbn[2] = {0u, 0u};
+  auto request_mask = [&]() {
+    if constexpr (MASK) {
+      const int d0 = 2 * E.di;
+      const bool live = qE < items_mine && row_okE;
+      const uint32_t tv = (uint32_t)(d0 * plane_vox + colvoxE);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        mbn[mt] = __builtin_amdgcn_raw_buffer_load_b32(rmE, (live && d0 + mt < D) ? svo[mt] : DEAD, tv * (uint32_t)(ntile * 4), 0);
+    }
+  };
 
   // resident weights (all 8 waves) and bias
   {
@@ -1389,16 +1404,12 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
     const int d0E = 2 * E.di;
     const uint32_t tile_vox = (uint32_t)(d0E * plane_vox + colvoxE);   // within sample E.n0
     const bool okE[2] = {closes && row_okE, closes && row_okE && d0E + 1 < D};
-    // sign words of the tile about to be stored, requested ahead of everything else.  Issued and consumed
-    // UNCONDITIONALLY (DEAD offset: no memory access): with the request under one `if` and the use under another the
-    // compiler sees a path on which the load is never waited for and puts s_waitcnt vmcnt(0) -- which also waits for
-    // the halo planes in flight -- in front of the next MFMA that reuses the register.
-    uint32_t mb[2] = {0u, 0u};
-    if (MASK) {
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-        mb[mt] = __builtin_amdgcn_raw_buffer_load_b32(rmE, okE[mt] ? svo[mt] : DEAD, tile_vox * (uint32_t)(ntile * 4), 0);
-    }
+    // sign words of the tile about to be stored (requested one phase ago).  Issued and consumed UNCONDITIONALLY (DEAD
+    // offset: no memory access): with the request under one `if` and the use under another the compiler sees a path on
+    // which the load is never waited for and puts s_waitcnt vmcnt(0) -- which also waits for the halo planes in flight --
+    // in front of the next MFMA that reuses the register.
+    uint32_t mb[2] = {mbn[0], mbn[1]};
+    if (MASK) asm volatile("" : "+v"(mb[0]), "+v"(mb[1]));
     // K-split second pass: the first pass's f32 partial sums of the tile about to be stored (held across the MFMA
     // phase they would not fit beside the accumulators, the planes in flight and the fragment ring)
     f32x4 part[KS == 2 ? 2 : 1][KS == 2 ? 4 : 1];
@@ -1419,7 +1430,6 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
         store_planes(0, 0);
       }
     }
-    if (MASK) asm volatile("" ::"v"(mb[0]), "v"(mb[1]));   // landed, before the first store (stores count in vmcnt too)
     __builtin_amdgcn_sched_barrier(0);
     stamp();
     if (!no_epi && closes) {
@@ -1511,6 +1521,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
       }
     }
     if (closes) {   // E moves on (its column's resources follow at a column change)
+      ++qE;
       if (++E.di == nTd) {
         E.di = 0;
         ++E.cj;
@@ -1518,6 +1529,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    request_mask();
     if (stage) {   // request the upper planes of the tile after P
       ++qP;
       if (++P.di == nTd) {
@@ -1535,6 +1547,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   // the loop's end, behind an s_waitcnt vmcnt(0) that undid the prefetch.
   if (grp == 0) {
     init_acc();
+    request_mask();
     for (int q = 0; q < items_mine; q += 2) {
       const bool second = q + 1 < items_mine;
       stamp();
@@ -2212,6 +2225,17 @@ __global__ __launch_bounds__(512) void conv_fwd5_kernel(ConvFwdArgs a) {
       vox[mt] = (d < D && h < H && w < W) ? (uint32_t)((d * H + h) * W + w) : DEAD;
     }
   };
+  // LeakyReLU sign words of E's tile (masked epilogue), requested when E enters the tile: ncg phases before their use
+  uint32_t mbn[2][2] = {{0u, 0u}, {0u, 0u}};
+  auto request_mask = [&]() {
+    if constexpr (MASK) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          mbn[mt][nt] = __builtin_amdgcn_raw_buffer_load_b32(rmE, (kE < kmine && vox[mt] != DEAD) ? (vox[mt] * (uint32_t)ntile + nt0 + nt) * 4u : DEAD, 0, 0);
+    }
+  };
 
   if (tid < 64) {
     const int co = nt0 * 32 + tid;
@@ -2221,6 +2245,7 @@ __global__ __launch_bounds__(512) void conv_fwd5_kernel(ConvFwdArgs a) {
   if (items_mine > 0) {
     enter_tile_S();
     enter_tile_E();
+    request_mask();
     if (grp == 0) stage_halo();
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2249,17 +2274,8 @@ __global__ __launch_bounds__(512) void conv_fwd5_kernel(ConvFwdArgs a) {
 
   // off-phase: halo chunk of my item qn (cursor S), my half of slab js, epilogue of tile kE if `closes`
   auto off_phase = [&](bool closes, int qn, int js, int f0, int f1) {
-    uint32_t mb[2][2] = {{0u, 0u}, {0u, 0u}};
-    if (MASK) {   // issued and consumed unconditionally (see the sliding-halo kernel)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
-          mb[mt][nt] = __builtin_amdgcn_raw_buffer_load_b32(rmE, (closes && vox[mt] != DEAD) ? (vox[mt] * (uint32_t)ntile + nt0 + nt) * 4u : DEAD, 0, 0);
-    }
     if (qn < items_mine) stage_halo();
     if (js < items_max) stage_slab(js, f0, f1, wave, 4);
-    if (MASK) asm volatile("" ::"v"(mb[0][0]), "v"(mb[0][1]), "v"(mb[1][0]), "v"(mb[1][1]));
     __builtin_amdgcn_sched_barrier(0);
     stamp();
     if (closes) {
@@ -2296,7 +2312,7 @@ __global__ __launch_bounds__(512) void conv_fwd5_kernel(ConvFwdArgs a) {
             const auto sw2 = __builtin_amdgcn_permlane32_swap(b, b, false, false);
             __builtin_amdgcn_raw_buffer_store_b32(sw2[0] | sw2[1], rsE, (ok && hh == 0) ? (vox[mt] * (uint32_t)ntile + nt0 + nt) * 4u : DEAD, 0, 0);
           }
-          if (MASK) sg_apply_sign_word(acc[mt][nt], mb[mt][nt], hh, a.mask_slope);
+          if (MASK) sg_apply_sign_word(acc[mt][nt], mbn[mt][nt], hh, a.mask_slope);
 #pragma unroll
           for (int j = 0; j < 2; ++j) {   // 16 contiguous bytes per lane (see sg_store_tile_row_bf16)
             const uint32_t a0 = sg_pack_bf16(acc[mt][nt][8 * j + 0], acc[mt][nt][8 * j + 1]), a1 = sg_pack_bf16(acc[mt][nt][8 * j + 2], acc[mt][nt][8 * j + 3]);
@@ -2312,6 +2328,7 @@ __global__ __launch_bounds__(512) void conv_fwd5_kernel(ConvFwdArgs a) {
       }
       ++kE;
       if (kE < kmine) enter_tile_E();
+      request_mask();
       init_acc();
     }
     if (qn < items_mine) {   // S moves on to my item qn + 1

@@ -42,11 +42,12 @@ def main():
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     manifest = []
 
-    def twice(tag, match, alg_bytes, flops, fn):
+    def twice(tag, match, alg_bytes, flops, fn, per_call=1):
         for rep in range(2):
             fn()
         torch.cuda.synchronize()
-        manifest.append(dict(tag=tag, match=match, algorithmic_bytes=int(alg_bytes), flops=float(flops), repeats=2))
+        manifest.append(dict(tag=tag, match=match, algorithmic_bytes=int(alg_bytes), flops=float(flops), repeats=2 * per_call,
+                             dispatches_per_call=per_call))
         print(tag, 'done', flush=True)
 
     # calibration: out = 1*a + 0.5*b over 2^28 bf16 elements: reads 2 x 512 MiB, writes 512 MiB, 16 B per lane
@@ -72,6 +73,13 @@ def main():
         sout = torch.empty_like(bits)
         ep_plain = ConvEpilogue(bias.data_ptr(), 1, 0.2, 0, 1e-8, None, None, 0.0, sout.data_ptr())
         ep_mask = ConvEpilogue(None, 0, 0.2, 0, 1e-8, None, bits.data_ptr(), 0.2, None)
+        # as functional.raw_conv does: scratch for the two-pass (K-split) path where the library has one for this shape
+        fws_bytes = lib.sg_conv3d_fwd_workspace(C.byref(shp), dt)
+        fws = torch.empty(max(16, fws_bytes), device=dev, dtype=torch.uint8)
+        per_call = 2 if fws_bytes else 1
+        if fws_bytes:
+            for e_ in (ep_plain, ep_mask):
+                e_.workspace, e_.workspace_bytes = fws.data_ptr(), fws_bytes
         wsb = lib.sg_conv3d_wgrad_workspace(C.byref(shp), dt)
         ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
         dw = torch.empty(3, 3, 3, cin, cout, device=dev)
@@ -79,9 +87,9 @@ def main():
         flops = 2.0 * vox * cin * cout * 27
         name = f'n{n} {d}x{h}x{w} {cin}->{cout}'
         twice(f'fwd bias+lrelu+sign_out {name}', 'conv_fwd', vox * (cin + cout) * 2 + vox * nw * 4 + 27 * cin * cout * 2, flops,
-              lambda: _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep_plain), dt, st)))
+              lambda: _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep_plain), dt, st)), per_call)
         twice(f'fwd mask_bits {name}', 'conv_fwd', vox * (cin + cout) * 2 + vox * nw * 4 + 27 * cin * cout * 2, flops,
-              lambda: _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep_mask), dt, st)))
+              lambda: _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep_mask), dt, st)), per_call)
         twice(f'wgrad+dbias {name}', 'conv_wgrad', vox * (cin + cout) * 2 + 27 * cin * cout * 4, flops,
               lambda: _lib.check(lib.sg_conv3d_wgrad_bias(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), 1.0,
                                                           ws.data_ptr(), wsb, C.byref(shp), dt, st)))
@@ -91,7 +99,7 @@ def main():
             ep_pool.pool = 1
             twice(f'fwd pooled (D x W mean) {name}', 'conv_fwd3s', vox * (cin + cout / 4) * 2 + vox * nw * 4 + 27 * cin * cout * 2, flops,
                   lambda: _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), yp.data_ptr(), C.byref(shp), C.byref(ep_pool), dt, st)))
-        del x, dy, y, bits, sout, ws
+        del x, dy, y, bits, sout, ws, fws
     # non-convolution kernels at the top level
     for (n, d, h, w, c) in ((64, 32, 128, 128, 64), (32, 32, 128, 128, 32)):
         vox = n * d * h * w

@@ -29,7 +29,8 @@ def per_dispatch(rows, counter):
 
 
 def match(manifest, disp):
-    """For every manifest entry the LAST of its `repeats` matching dispatches, in order (first-touch effects gone)."""
+    """For every manifest entry the LAST call's matching dispatches (first-touch effects gone), in order: one dispatch,
+    or the sum over `dispatches_per_call` of them (the two passes of a layer split over its input channels)."""
     res, pos = [], 0
     for m in manifest:
         found = []
@@ -38,7 +39,9 @@ def match(manifest, disp):
                 found.append(disp[pos])
             pos += 1
         assert len(found) == m['repeats'], (m['tag'], len(found))
-        res.append(found[-1])
+        last = found[-m.get('dispatches_per_call', 1):]
+        name = last[-1][1] if len(last) == 1 else ' + '.join(d[1].split('(')[0][:40] for d in last)
+        res.append((last[-1][0], name, sum(d[2] for d in last)))
     return res
 
 

@@ -360,8 +360,15 @@ def main():
     barrier()
     table = collect()
     lib.sg_prof_enable(0)
-    if table:
-        lib.sg_prof_set_filter(table[0].kind, C.byref(table[0].shape))
+    # dominant KERNEL = the device kernel (by name) with the largest summed time over the step; the roofline object is
+    # quoted on that kernel's own heaviest (kind, shape)
+    by_kernel = {}
+    for e in table:
+        by_kernel[e.kernel] = by_kernel.get(e.kernel, 0.0) + e.total_ms
+    dom_name = max(by_kernel, key=by_kernel.get) if by_kernel else None
+    dom = next((e for e in table if e.kernel == dom_name), None)
+    if dom is not None:
+        lib.sg_prof_set_filter(dom.kind, C.byref(dom.shape))
     barrier()
     if world > 1:
         for o_ in cfg['optimizers']:
@@ -399,7 +406,7 @@ def main():
     value = vols / dt
     peak = 2500.0 if args.dtype == 'bf16' else 157.3
     roof = None
-    if timed and timed[0].launches > 0:      # dominant kernel = the (kind, shape) with the largest total time
+    if timed and timed[0].launches > 0:      # the dominant kernel's heaviest shape, timed inside the timed region
         best = timed[0]
         avg_ms = best.total_ms / best.launches
         ach = best.flops_per_launch / (avg_ms * 1e-3) / 1e12
@@ -430,6 +437,8 @@ def main():
                            parallelism=f'dp{world}', collective=comm, step_gflop_per_volume=round(step_gf, 1),
                            step_mfma_tflops=round(value * step_gf / 1e3 / world, 2),
                            conv_kernel_ms_per_step=round(total_conv_ms / args.steps, 3),
+                           conv_ms_per_step_by_kernel={k.decode(): round(v / ncal, 3) for k, v in
+                                                       sorted(by_kernel.items(), key=lambda kv: -kv[1])[:8]},
                            losses_after=dict(disc=round(losses[0], 4), gen=round(losses[1], 4))),
                roofline=roof)
     if world == 1 and args.config == 3 and not args.no_extras:

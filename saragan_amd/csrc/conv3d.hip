@@ -156,9 +156,20 @@ __device__ __forceinline__ void sg_apply_sign_word(f32x16& v, uint32_t word, int
 // channels 8*qd + 4*hh + e; v_permlane32_swap exchanges the qd-odd part of the lower half-wave with the qd-even part
 // of the upper one, after which lane hh = 0 holds channels 16j + 0..7 and hh = 1 channels 16j + 8..15: two
 // dwordx4 stores per M tile instead of four dwordx2 (the off-phase is bound by vector-memory instructions).
-__device__ __forceinline__ uint32_t sg_pack_bf16(float lo, float hi) {
-  bf16_t t[2] = {sg_traits<bf16_t>::from_f(lo), sg_traits<bf16_t>::from_f(hi)};
-  return *reinterpret_cast<uint32_t*>(t);
+// LeakyReLU as max(x, slope * x), slope <= 1 (slope 1: identity).  v_max directly: fmaxf() adds a canonicalising
+// v_max(x, x) per element, a third of the epilogue's arithmetic.
+__device__ __forceinline__ float sg_lrelu(float x, float slope) {
+  const float t = x * slope;
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(t));
+  return r;
+}
+
+__device__ __forceinline__ uint32_t sg_pack_bf16(float lo, float hi) {   // one v_cvt_pk_bf16_f32 (round to nearest even, as from_f)
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  const f32x2_ v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
 }
 
 __device__ __forceinline__ void sg_store_tile_row_bf16(bf16_t* row32, const f32x16& v, int hh, bool ok) {
@@ -1452,7 +1463,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
             for (int i = 0; i < 16; ++i) acc[mt][i] += part[mt][i >> 2][i & 3];
           }
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc[mt][i] = fmaxf(acc[mt][i], acc[mt][i] * slope);   // LeakyReLU (slope 1: none)
+          for (int i = 0; i < 16; ++i) acc[mt][i] = sg_lrelu(acc[mt][i], slope);   // slope 1: no activation
           if (PN) {
             float ss = 0.f;
 #pragma unroll
@@ -2285,7 +2296,7 @@ __global__ __launch_bounds__(512) void conv_fwd5_kernel(ConvFwdArgs a) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc[mt][nt][i] = fmaxf(acc[mt][nt][i], acc[mt][nt][i] * slope);   // LeakyReLU (slope 1: none)
+          for (int i = 0; i < 16; ++i) acc[mt][nt][i] = sg_lrelu(acc[mt][nt][i], slope);   // slope 1: no activation
         if (PN) {
           float ss = 0.f;
 #pragma unroll

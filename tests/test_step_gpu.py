@@ -292,8 +292,12 @@ def test_other_optimizers_match_oracle(golden_dir, kind, strategy):
             ref = O.step_alternate(p, rg, rd, shadow, fx['rnd'], fx['real'], fx['alpha'], fx['cfg'], lr, lr)
         np.testing.assert_allclose(float(gl), float(ref['gen_loss']), rtol=1e-4, atol=1e-5, err_msg=f'step {step}')
         np.testing.assert_allclose(float(dl), float(ref['disc_loss']), rtol=1e-4, atol=1e-5, err_msg=f'step {step}')
+        # Adadelta's step is sqrt(acc_update + eps) / sqrt(acc_grad + eps) * g with eps = 1e-7 (TF default): where a
+        # gradient is small against sqrt(eps) the ratio amplifies its f32 rounding (the weight-gradient sums are
+        # atomic, so their last bits also vary run to run) -- 6e-5 absolute was seen on one bias element
+        atol = 1e-4 if kind == 'Adadelta' else 2e-5
         for k, v in store.vars.items():
-            np.testing.assert_allclose(v.detach().double().cpu().numpy(), p[k].numpy(), rtol=2e-4, atol=2e-5,
+            np.testing.assert_allclose(v.detach().double().cpu().numpy(), p[k].numpy(), rtol=2e-4, atol=atol,
                                        err_msg=f'{kind} step {step} {k}')
-            np.testing.assert_allclose(ema.average(k).double().cpu().numpy(), shadow[k].numpy(), rtol=2e-4, atol=2e-5,
+            np.testing.assert_allclose(ema.average(k).double().cpu().numpy(), shadow[k].numpy(), rtol=2e-4, atol=atol,
                                        err_msg=f'{kind} ema step {step} {k}')

@@ -27,6 +27,7 @@ CONVS = [  # n, (d,h,w), cin, cout (all 3x3x3): the >= 1 ms/step entries of `ben
     (64, (32, 128, 128), 32, 32),
     (64, (32, 128, 128), 32, 64),
     (32, (32, 128, 128), 32, 64),
+    (32, (32, 128, 128), 32, 32),
     (32, (32, 128, 128), 64, 32),
     (64, (16, 64, 64), 64, 64),
     (64, (16, 64, 64), 64, 128),

@@ -1164,7 +1164,8 @@ enum : int { SG_EP_SIGN = 1, SG_EP_MASK = 2, SG_EP_PN = 4, SG_EP_POOL = 8 };
 #define SG_V3S_RING 6   // fragment ring of the MFMA phase: reads run RING - 2 steps (of 1-2 MFMAs) ahead of their use
 #endif
 
-template <int GC, int KS, int EPI>   // KS: 0 whole layer; 1 / 2: first / second pass of a layer split over its input channels
+template <int GC, int KS, int EPI, bool UPS>   // KS: 0 whole layer; 1 / 2: first / second pass of a layer split over its input
+                                              // channels; UPS: x is the half-resolution tensor, gathered nearest-x2
 __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef bf16_t T;
@@ -1201,7 +1202,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + n0 * sample_bytes, 0,
                                              (int)sample_bytes, 0x00020000);
   };
-  const int64_t xsb = svox * a.xcs * ES, ysb = svox * cout * (KS == 1 ? 4 : ES), wsb = svox * ntile * 4, psb = svox * 4;
+  const int64_t xsb = (UPS ? svox >> 3 : svox) * a.xcs * ES, ysb = svox * cout * (KS == 1 ? 4 : ES), wsb = svox * ntile * 4, psb = svox * 4;
 
   // column schedule: a block walks PAIRS of H-adjacent tile columns along D, wave group g taking the column with
   // tile row 2*k + g, one phase apart: the two halo rows the pair shares are fetched twice within ~2 us on the same
@@ -1241,7 +1242,10 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
     const int hh_ = row / 34, hw = row - hh_ * 34;
     const int c = p * EPP;
     const bool live = row < 204 && c < a.cin && (wave + 4 * k) < PPIECES;
-    relb[k] = live ? (uint32_t)(((hh_ * W + hw) * a.xcs + a.xco + c) * ES) : 0xC0000000u;   // stays >= DEAD after + tile offset
+    // UPS: tile origins are even, so a halo voxel's halved coordinate is a per-lane constant relative to the tile's
+    // half-resolution origin: ((h0 - 1 + hh) >> 1) = h0 / 2 + ((hh - 1) >> 1), likewise along W
+    const int rel = UPS ? ((((hh_ - 1) >> 1) * (W >> 1) + ((hw - 1) >> 1)) * a.xcs + a.xco + c) * ES : ((hh_ * W + hw) * a.xcs + a.xco + c) * ES;
+    relb[k] = live ? (uint32_t)rel : 0xC0000000u;   // dead: stays >= DEAD after + tile offset
     crdp[k] = live ? (hw | (hh_ << 8)) : 0x7F7F;
   }
   // LDS position of my piece inside its 1-KiB block: slot p of row lands at p ^ f(row), and f(row) only depends on
@@ -1255,7 +1259,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
     yvo[mt] = (uint32_t)((v * cout + nt0 * 32) * (KS == 1 ? 4 : ES));
     svo[mt] = (uint32_t)(v * ntile + nt0) * 4u;
   }
-  const uint32_t plane_bytes = (uint32_t)(H * W * a.xcs * ES);
+  const uint32_t plane_bytes = (uint32_t)((UPS ? (H >> 1) * (W >> 1) : H * W) * a.xcs * ES);
   const int plane_vox = H * W;
 
   // A cursor walks my tiles in order: column cj of my list, step di along D.  Three run one behind the other: the
@@ -1277,7 +1281,8 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   auto enter_column_P = [&]() {
     enter_column(P);
     rxP = rsrc_of(a.x, xsb, P.n0);
-    const int tile_off = ((P.h0 - 1) * W + (P.w0 - 1)) * a.xcs * ES;   // may be negative: only dead lanes go below 0
+    const int tile_off = UPS ? ((P.h0 >> 1) * (W >> 1) + (P.w0 >> 1)) * a.xcs * ES
+                             : ((P.h0 - 1) * W + (P.w0 - 1)) * a.xcs * ES;   // may be negative: only dead lanes go below 0
     const int lo_w = max(0, 1 - P.w0), hi_w = min(34, W + 1 - P.w0) - 1;
     const int lo_h = max(0, 1 - P.h0), hi_h = min(6, H + 1 - P.h0) - 1;   // hi_h < 0 for a dead column
     const uint32_t lo = (uint32_t)(lo_w | (lo_h << 8));
@@ -1295,7 +1300,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
     for (int j = 0; j < 2; ++j) {
       const int gp = d0 - 1 + hd0 + j;               // global D plane
       const bool plane_ok = gp >= 0 && gp < D;
-      const uint32_t soff = plane_ok ? (uint32_t)gp * plane_bytes : 0u;
+      const uint32_t soff = plane_ok ? (uint32_t)(UPS ? gp >> 1 : gp) * plane_bytes : 0u;
 #pragma unroll
       for (int k = 0; k < MAXP; ++k) stg[j][k] = __builtin_amdgcn_raw_buffer_load_b128(rxP, plane_ok ? vk[k] : DEAD, soff, 0);
     }
@@ -1594,9 +1599,9 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   }
 }
 
-template <int GC, int KS, int EPI>
+template <int GC, int KS, int EPI, bool UPS = false>
 static int launch_fwd3s_inst(const ConvFwdArgs& a, unsigned gx, size_t lds, hipStream_t st) {
-  auto kern = conv_fwd3s_kernel<GC, KS, EPI>;
+  auto kern = conv_fwd3s_kernel<GC, KS, EPI, UPS>;
   SG_ALLOW_160K_LDS(kern);
   hipLaunchKernelGGL(kern, dim3(gx, (unsigned)a.ntile), dim3(512), lds, st, a);
   return SG_OK;
@@ -1606,10 +1611,12 @@ static int launch_fwd3s_inst(const ConvFwdArgs& a, unsigned gx, size_t lds, hipS
 template <int GC, int KS = 0>
 static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used) {
   *used = false;
-  if (s->upsample_in || s->kd != 3 || s->kh != 3 || s->kw != 3) return SG_OK;
+  if (s->kd != 3 || s->kh != 3 || s->kw != 3) return SG_OK;
+  // the fused nearest-x2 gather exists for the two passes of a split layer only (G's 64 -> 32 after upscale3d)
+  if (s->upsample_in && (KS == 0 || GC != 2 || ((s->d | s->h | s->w) & 1))) return SG_OK;
   if (s->d < 4 || (s->w % 32) != 0 || (s->cout % 32) != 0) return SG_OK;   // >= 2 steps per column; full 32-wide rows and tiles
   if (a.pool && ((s->d & 1) || (s->h & 1) || a.pixel_norm || a.mask_bits || KS != 0)) return SG_OK;
-  if (a.pixel_norm && (a.mask_bits || KS != 0)) return SG_OK;
+  if (a.pixel_norm && (a.mask_bits || KS == 1 || a.ntile != 1)) return SG_OK;
   if (a.mask_bits && a.sign_out) return SG_OK;
   a.g = sg_make_geom(s, 256, /*prefer_w32=*/true, /*td=*/2, /*th=*/4);
   const sg_tile_geom& g = a.g;
@@ -1632,12 +1639,26 @@ static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
                   (a.pool ? SG_EP_POOL : 0);
   int rc = SG_OK;
   if constexpr (KS == 1) {
-    rc = launch_fwd3s_inst<GC, 1, 0>(a, (unsigned)gx, lds, st);
+    if constexpr (GC == 2) { if (s->upsample_in) rc = launch_fwd3s_inst<GC, 1, 0, true>(a, (unsigned)gx, lds, st); else rc = launch_fwd3s_inst<GC, 1, 0>(a, (unsigned)gx, lds, st); }
+    else rc = launch_fwd3s_inst<GC, 1, 0>(a, (unsigned)gx, lds, st);
   } else if constexpr (KS == 2) {
+    if (s->upsample_in) {
+      if constexpr (GC == 2) {
+        switch (epi) {
+          case 0: rc = launch_fwd3s_inst<GC, 2, 0, true>(a, (unsigned)gx, lds, st); break;
+          case SG_EP_SIGN: rc = launch_fwd3s_inst<GC, 2, SG_EP_SIGN, true>(a, (unsigned)gx, lds, st); break;
+          case SG_EP_PN: rc = launch_fwd3s_inst<GC, 2, SG_EP_PN, true>(a, (unsigned)gx, lds, st); break;
+          case SG_EP_PN | SG_EP_SIGN: rc = launch_fwd3s_inst<GC, 2, SG_EP_PN | SG_EP_SIGN, true>(a, (unsigned)gx, lds, st); break;
+          default: return SG_OK;
+        }
+      } else return SG_OK;
+    } else
     switch (epi) {
       case 0: rc = launch_fwd3s_inst<GC, 2, 0>(a, (unsigned)gx, lds, st); break;
       case SG_EP_SIGN: rc = launch_fwd3s_inst<GC, 2, SG_EP_SIGN>(a, (unsigned)gx, lds, st); break;
       case SG_EP_MASK: rc = launch_fwd3s_inst<GC, 2, SG_EP_MASK>(a, (unsigned)gx, lds, st); break;
+      case SG_EP_PN: rc = launch_fwd3s_inst<GC, 2, SG_EP_PN>(a, (unsigned)gx, lds, st); break;
+      case SG_EP_PN | SG_EP_SIGN: rc = launch_fwd3s_inst<GC, 2, SG_EP_PN | SG_EP_SIGN>(a, (unsigned)gx, lds, st); break;
       default: return SG_OK;
     }
   } else {
@@ -2662,7 +2683,8 @@ extern "C" __attribute__((visibility("default"))) void sg_debug_set_ts_buffer(vo
 
 extern "C" size_t sg_conv3d_fwd_workspace(const sg_conv_shape* s, sg_dtype dt) {
   if (!conv_shape_ok(s) || dt != SG_BF16) return 0;
-  if (s->kd == 3 && s->kh == 3 && s->kw == 3 && s->cin == 64 && s->cout <= 32 && !s->upsample_in && s->w % 32 == 0 && s->d >= 4)
+  if (s->kd == 3 && s->kh == 3 && s->kw == 3 && s->cin == 64 && s->cout == 32 && s->w % 32 == 0 && s->d >= 4 &&
+      (!s->upsample_in || ((s->d | s->h | s->w) & 1) == 0))
     return (size_t)s->n * s->d * s->h * s->w * (size_t)s->cout * 4;
   return 0;
 }
@@ -2728,7 +2750,7 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     rc = SG_OK;
     const bool k333 = s->kd == 3 && s->kh == 3 && s->kw == 3, k133 = s->kd == 1 && s->kh == 3 && s->kw == 3;
     if (dt == SG_BF16 && k333 && !sg_cfg().fwd_no_v3s && !sg_cfg().fwd_no_ksplit && a.nchunk == 4 && a.ntile == 1 && s->cin == 64 &&
-        !s->upsample_in && !a.pool && !a.pixel_norm && !(a.mask_bits && a.sign_out) && ep && ep->workspace &&
+        !a.pool && !(a.mask_bits && a.sign_out) && !(a.pixel_norm && a.mask_bits) && ep && ep->workspace &&
         ep->workspace_bytes >= (size_t)s->n * s->d * s->h * s->w * (size_t)s->cout * 4 && sg_aligned16(ep->workspace)) {
       // K split: 64 input channels as two sliding-halo passes over 32 channels each (resident weights, a 64-byte
       // half of every 128-byte channel row fetched ONCE per pass) with the f32 partial sums in the caller's workspace.
@@ -2739,6 +2761,7 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
       sh.cin = 32;
       p1.cin = p2.cin = 32; p1.nchunk = p2.nchunk = 2; p1.xcs = p2.xcs = 64;
       p1.xco = 0; p1.y = ep->workspace; p1.bias = nullptr; p1.act = 0; p1.mask_bits = nullptr; p1.sign_out = nullptr;
+      p1.pixel_norm = 0; p1.pn_scale = nullptr;
       p2.xco = 32; p2.addend = reinterpret_cast<const float*>(ep->workspace);
       p2.wp = reinterpret_cast<const char*>(a.wp) + (size_t)2 * a.taps * a.ntile * 1024;   // chunks 2, 3 of the packed image
       bool u1 = false, u2 = false;

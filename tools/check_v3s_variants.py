@@ -54,9 +54,10 @@ def cmp(tag, a, b):
 
 
 ok = True
-for (n, cin, cout, sp) in [(2, 32, 32, (6, 128, 256)), (2, 32, 64, (8, 126, 256)), (3, 16, 32, (4, 128, 256)),
-                           (2, 64, 32, (6, 128, 256))]:
-    x = torch.randn(n, cin, *sp, device=dev).bfloat16().contiguous(memory_format=torch.channels_last_3d)
+for (n, cin, cout, sp, ups) in [(2, 32, 32, (6, 128, 256), False), (2, 32, 64, (8, 126, 256), False), (3, 16, 32, (4, 128, 256), False),
+                                (2, 64, 32, (6, 128, 256), False), (2, 64, 32, (8, 128, 256), True), (3, 64, 32, (4, 124, 256), True)]:
+    xsp = tuple(t // 2 for t in sp) if ups else sp
+    x = torch.randn(n, cin, *xsp, device=dev).bfloat16().contiguous(memory_format=torch.channels_last_3d)
     w = torch.randn(3, 3, 3, cin, cout, device=dev)
     b = torch.randn(cout, device=dev) * 0.3
     coef = (2.0 / (27 * cin)) ** 0.5
@@ -70,11 +71,13 @@ for (n, cin, cout, sp) in [(2, 32, 32, (6, 128, 256)), (2, 32, 64, (8, 126, 256)
         'pool+signs': dict(bias=b, act=True, want_signs=True, pool=True),
     }
     for name, kw in cases.items():
-        if kw.get('pool') and cin > 32:
+        if kw.get('pool') and (cin > 32 or ups):
             continue
-        got, kg = run(False, lambda: F.raw_conv(x, w, coef, False, **kw))
-        ref, kr = run(True, lambda: F.raw_conv(x, w, coef, False, **kw))
-        print(f'n{n} {cin}->{cout} {sp} {name}: {kg} vs {kr}')
+        if ups and 'mask_bits' in kw:
+            continue
+        got, kg = run(False, lambda: F.raw_conv(x, w, coef, False, ups, **kw))
+        ref, kr = run(True, lambda: F.raw_conv(x, w, coef, False, ups, **kw))
+        print(f'n{n} {cin}->{cout} {sp} ups{int(ups)} {name}: {kg} vs {kr}')
         if ref is None or got is None:
             print('   (not available on one path)', got is None, ref is None)
             continue
@@ -84,7 +87,10 @@ for (n, cin, cout, sp) in [(2, 32, 32, (6, 128, 256)), (2, 32, 64, (8, 126, 256)
             print('   ** MISMATCH')
             if not kw.get('pixel_norm') and not kw.get('pool') and 'mask_bits' not in kw:
                 wq = (w * coef).bfloat16().float()
-                z = torch.nn.functional.conv3d(x.float(), wq.permute(4, 3, 0, 1, 2).contiguous(), padding=1)
+                xf = x.float()
+                if ups:
+                    xf = xf.repeat_interleave(2, 2).repeat_interleave(2, 3).repeat_interleave(2, 4)
+                z = torch.nn.functional.conv3d(xf, wq.permute(4, 3, 0, 1, 2).contiguous(), padding=1)
                 if 'bias' in kw:
                     z = z + b.view(1, -1, 1, 1, 1)
                 if kw.get('act'):

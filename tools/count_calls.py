@@ -30,14 +30,18 @@ class Proxy:
         def wrapped(*a):
             fr = [f for f in traceback.extract_stack()[:-1] if 'saragan_amd' in f.filename][-4:]
             site = ' < '.join(f'{os.path.basename(f.filename)}:{f.lineno}:{f.name}' for f in reversed(fr))
-            counts[(name, site)] += 1
+            size = ''
+            if name.startswith('sg_bias_act_bwd'):
+                ints = [int(getattr(v, 'value', v)) for v in a[5:7]] if name.endswith('bits') else [int(getattr(v, 'value', v)) for v in a[4:6]]
+                size = f' nvox {ints[0]} c {ints[1]}'
+            counts[(name, site + size)] += 1
             return fn(*a)
         return wrapped
 
 
 ARMED = [False]
 _lib._lib = Proxy(lib)
-sys.argv = [sys.argv[0], '--batch', '2', '--no-extras', '--no-cpu-baseline']
+sys.argv = [sys.argv[0], '--batch', '4', '--no-extras', '--no-cpu-baseline']
 args = bench.parse()
 dev = torch.device('cuda:0')
 cfg = bench.build(args, dev, 'bf16')

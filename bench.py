@@ -142,6 +142,8 @@ def build(args, device, dtype):
         og, od = parallel.DistributedOptimizer(og), parallel.DistributedOptimizer(od)
         og.distributed.timing = od.distributed.timing = True
     sp = [s * 2 ** (args.phase - 1) for s in base_shape[1:]]
+    if args.dims == 2:
+        sp[0] = 1                                     # images: the D extent stays 1 (SURFGAN_2D)
     ph = opt.Placeholder([args.batch, base_shape[0], *sp])
     freeze = None
     if args.alpha > 0 and args.phase > 1:
@@ -294,7 +296,9 @@ def loader_leg(args, cfg, device, nsteps, barrier):
         def step(i):
             sess.run(cfg['train'], feed_dict={ph: pf.next()})
             sess.run(cfg['ema_op'])
-        for i in range(2):
+        # as many untimed steps as the main leg ran before its timed region: after the seconds of GPU idle spent writing
+        # the files the chip boosts for a few hundred ms, and a short leg would read 15 % faster than the main one
+        for i in range(args.warmup + 2 + 3):
             step(i)
         dt = timed_steps(step, nsteps, barrier)
         pf.close()
@@ -443,7 +447,7 @@ def main():
                roofline=roof)
     if world == 1 and args.config == 3 and not args.no_extras:
         extras = {}
-        extras['loader_in_loop'] = loader_leg(args, cfg, device, max(3, args.steps // 2), barrier)
+        extras['loader_in_loop'] = loader_leg(args, cfg, device, max(3, args.steps), barrier)
         # the same workload in fp32 storage / f32-input MFMA (the reference's arithmetic, ops.py:147-150)
         del cfg, sess, batches
         from saragan_amd import functional as F

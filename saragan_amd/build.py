@@ -11,6 +11,11 @@ LIB = os.path.join(HERE, 'libsaragan_hip.so')
 SOURCES = ['conv3d.hip', 'wgrad.hip', 'elementwise.hip', 'optim.hip', 'prof.hip']
 HEADERS = ['common.h', 'prof.h', os.path.join('..', '..', 'include', 'saragan_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+# The MFMA kernels' off-phases share their SIMD with the other wave group's MFMAs, and packed-f32 VALU ops
+# (v_pk_mul_f32 / v_pk_add_f32, which the SLP vectoriser forms from the epilogues' per-element arithmetic) were measured at
+# ~110 cycles EACH there -- they queue behind the matrix pipe -- against 4-8 for the scalar forms: a 32-element masked
+# epilogue took 4.3k cycles instead of 0.7k (tools/ts_conv.py, SG_DBG_FLAGS=128|256).  No SLP in those two files.
+FILE_FLAGS = {'conv3d.hip': ['-fno-slp-vectorize'], 'wgrad.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc():
@@ -57,7 +62,7 @@ def build(force=False, verbose=True):
     for s in SOURCES:
         o = os.path.join(HERE, 'build', s.replace('.hip', '.o'))
         objs.append(o)
-        cmd = [_hipcc()] + FLAGS + ['-Rpass-analysis=kernel-resource-usage', '-c', os.path.join(CSRC, s), '-o', o]
+        cmd = [_hipcc()] + FLAGS + FILE_FLAGS.get(s, []) + ['-Rpass-analysis=kernel-resource-usage', '-c', os.path.join(CSRC, s), '-o', o]
         if verbose:
             print(' '.join(cmd), flush=True)
         log = open(o + '.log', 'w+')

@@ -143,12 +143,15 @@ __device__ __forceinline__ uint32_t sg_sign_word(const f32x16& v, int hh) {
 }
 
 __device__ __forceinline__ void sg_apply_sign_word(f32x16& v, uint32_t word, int hh, float slope) {
+  // v *= bit ? slope : 1, as v += bit ? (slope - 1) * v : 0: a packed multiply per pair, then one bit-field extract
+  // (0 or -1), one AND and one add per element.  (The off-phase shares its SIMD's vector issue with the other wave's
+  // MFMAs: ~6 VALU slots per MFMA, so the epilogue's instruction count is what has to fit under the MFMA phase.)
   const uint32_t wsh = word >> (4 * hh);
-  const uint32_t su = __float_as_uint(slope), one = 0x3F800000u;
+  const float sm1 = slope - 1.f;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int t = ((int)(wsh << (31 - ((i & 3) + 8 * (i >> 2))))) >> 31;   // 1-bit signed field: 0 or -1
-    v[i] *= __uint_as_float(((uint32_t)t & su) | (~(uint32_t)t & one));   // bit ? slope : 1
+    v[i] += __uint_as_float((uint32_t)t & __float_as_uint(v[i] * sm1));
   }
 }
 
@@ -1467,8 +1470,10 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][i] += part[mt][i >> 2][i & 3];
           }
+          if (slope != 1.f) {   // uniform
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc[mt][i] = sg_lrelu(acc[mt][i], slope);   // slope 1: no activation
+            for (int i = 0; i < 16; ++i) acc[mt][i] = sg_lrelu(acc[mt][i], slope);
+          }
           if (PN) {
             float ss = 0.f;
 #pragma unroll
@@ -1492,7 +1497,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
             __builtin_amdgcn_raw_buffer_store_b32(sw2[0] | sw2[1], rsE, (okE[mt] && hh == 0) ? svo[mt] : DEAD,
                                                   tile_vox * (uint32_t)(ntile * 4), 0);
           }
-          if (MASK) sg_apply_sign_word(acc[mt], mb[mt], hh, a.mask_slope);
+          if (MASK && !(a.dbg_flags & 256)) sg_apply_sign_word(acc[mt], mb[mt], hh, a.mask_slope);
           if (!POOL) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {   // 16 contiguous bytes per lane (see sg_store_tile_row_bf16)
@@ -1520,7 +1525,9 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) {
             const float t = acc[0][i] + acc[1][i];
-            sp[i] = (t + __shfl_xor(t, 1)) * 0.25f;     // lane r <-> r ^ 1: the W neighbour
+            // lane r <-> r ^ 1 (the W neighbour) by DPP quad_perm [1,0,3,2]: one VALU op, no LDS round trip
+            const float u = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(t), 0xB1, 0xF, 0xF, true));
+            sp[i] = (t + u) * 0.25f;
           }
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
@@ -1536,6 +1543,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
         }
       }
     }
+    if (a.dbg_flags & 128) stamp();   // fine-grained stamps: end of the epilogue
     if (closes) {   // E moves on (its column's resources follow at a column change)
       ++qE;
       if (++E.di == nTd) {
@@ -1545,6 +1553,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    if (a.dbg_flags & 128) stamp();   // cursor advanced
     request_mask();
     if (stage) {   // request the upper planes of the tile after P
       ++qP;
@@ -1555,6 +1564,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
       }
       if (qP < items_mine && !no_stage) load_planes(2 * P.di, 2);
     }
+    if (a.dbg_flags & 128) stamp();   // requests issued
     init_acc();
   };
   // Each wave group runs its own straight loop (one phase apart, paced by the block barrier), two tiles per trip, so
@@ -2314,10 +2324,12 @@ __global__ __launch_bounds__(512) void conv_fwd5_kernel(ConvFwdArgs a) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const bool ok = vox[mt] != DEAD;
+        if (slope != 1.f) {   // uniform
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+          for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-          for (int i = 0; i < 16; ++i) acc[mt][nt][i] = sg_lrelu(acc[mt][nt][i], slope);   // slope 1: no activation
+            for (int i = 0; i < 16; ++i) acc[mt][nt][i] = sg_lrelu(acc[mt][nt][i], slope);
+        }
         if (PN) {
           float ss = 0.f;
 #pragma unroll

@@ -16,7 +16,19 @@ wp = torch.empty(lib.sg_conv3d_packed_bytes(C.byref(shp), dt), device=dev, dtype
 _lib.check(lib.sg_conv3d_pack_weights(wt.data_ptr(), 0.05, 0, wp.data_ptr(), C.byref(shp), dt, st))
 y = torch.empty(n, d, h, w, cout, device=dev, dtype=torch.bfloat16)
 bias = torch.zeros(cout, device=dev)
-ep = ConvEpilogue(bias.data_ptr(), 1, 0.2, 0, 1e-8, None, None, 0.0, None)
+mode = os.environ.get('TS_EPI', 'act')      # act | signs | mask | pool
+nw = (cout + 31) // 32
+bits = torch.randint(-2 ** 31, 2 ** 31 - 1, (n, d, h, w, nw), device=dev, dtype=torch.int64).to(torch.int32)
+sout = torch.empty_like(bits)
+if mode == 'mask':
+    ep = ConvEpilogue(None, 0, 0.2, 0, 1e-8, None, bits.data_ptr(), 0.2, None)
+elif mode == 'signs':
+    ep = ConvEpilogue(bias.data_ptr(), 1, 0.2, 0, 1e-8, None, None, 0.0, sout.data_ptr())
+elif mode == 'pool':
+    ep = ConvEpilogue(bias.data_ptr(), 1, 0.2, 0, 1e-8, None, None, 0.0, sout.data_ptr())
+    ep.pool = 1
+else:
+    ep = ConvEpilogue(bias.data_ptr(), 1, 0.2, 0, 1e-8, None, None, 0.0, None)
 for _ in range(3):
     _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep), dt, st))
 ts = torch.zeros(256, dtype=torch.int64, device=dev)

@@ -16,7 +16,9 @@ cd $R
 run 200 python tools/ew_roofline.py --json $O/elementwise_roofline.json > $O/elementwise_roofline.txt 2>&1
 run 60 ./saragan_amd/build/probe/store_war_probe > $O/store_war_probe.txt 2>&1
 run 60 ./saragan_amd/build/probe/mfma_lds_probe > $O/mfma_lds_probe.txt 2>&1
+run 60 ./saragan_amd/build/probe/pk_f32_probe > $O/pk_f32_probe.txt 2>&1
 { echo "== conv_fwd3s n32 32->64 128^2"; TS_N=32 TS_CIN=32 TS_COUT=64 run 100 python tools/ts_conv.py;
+  echo "== conv_fwd3s masked epilogue, fine stamps (SG_DBG_FLAGS=128)"; SG_DBG_FLAGS=128 TS_EPI=mask TS_N=32 TS_CIN=32 TS_COUT=64 run 100 python tools/ts_conv.py;
   echo "== conv_fwd5 n32 64->128 64^2"; TS_N=32 TS_DHW=16,64,64 TS_CIN=64 TS_COUT=128 run 100 python tools/ts_conv.py;
   echo "== conv_wgrad3l n32 32->64 128^2"; run 100 python tools/ts_wgrad.py; } > $O/phase_stamps.txt 2>&1
 ls $O

@@ -2594,7 +2594,7 @@ __global__ __launch_bounds__(256) void pw_fwd_small_cout_kernel(ConvFwdArgs a, i
 }
 
 // ------------------------------------------------------------------------------------------------------
-// dense layers on <= 32 "voxels" (the batch): y[v][c] = epilogue(sum_k x[v][k] w[k][c] + b[c]), e.g. D's
+// dense layers on <= 128 "voxels" (the batch; blocks of 32 rows): y[v][c] = epilogue(sum_k x[v][k] w[k][c] + b[c]), e.g. D's
 // 8192 -> 512 (pgan/discriminator.py:60-63).  The whole cost is streaming the weight image once: one block of 16
 // waves per 32-channel output tile, wave w takes K chunks w, w+16, ... (8 loads in flight), 1-KiB weight fragments
 // straight from the packed image into the MFMA A operand, partial tiles summed through LDS.
@@ -2608,8 +2608,9 @@ __global__ __launch_bounds__(1024) void dense_small_m_kernel(ConvFwdArgs a, int 
   const int nt0 = blockIdx.x;
   const char* wp = reinterpret_cast<const char*>(a.wp) + ((int64_t)nt0 << 10) + lane * 16;
   const T* x = reinterpret_cast<const T*>(a.x);
-  const bool vlive = r < nvox;
-  const T* xrow = x + (int64_t)(vlive ? r : 0) * a.cin + hh * (CH / 2);
+  const int vrow = blockIdx.y * 32 + r;          // blockIdx.y: block of 32 rows (the weight slice is re-read from L2)
+  const bool vlive = vrow < nvox;
+  const T* xrow = x + (int64_t)(vlive ? vrow : 0) * a.cin + hh * (CH / 2);
   f32x16 acc;
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -2642,11 +2643,11 @@ __global__ __launch_bounds__(1024) void dense_small_m_kernel(ConvFwdArgs a, int 
     }
     if (a.sign_out != nullptr) {
       const uint32_t sw = sg_sign_word(acc, hh);
-      if (hh == 0 && vlive) a.sign_out[(int64_t)r * a.ntile + nt0] = sw;
+      if (hh == 0 && vlive) a.sign_out[(int64_t)vrow * a.ntile + nt0] = sw;
     }
-    if (a.mask_bits != nullptr && vlive) sg_apply_sign_word(acc, a.mask_bits[(int64_t)r * a.ntile + nt0], hh, a.mask_slope);
+    if (a.mask_bits != nullptr && vlive) sg_apply_sign_word(acc, a.mask_bits[(int64_t)vrow * a.ntile + nt0], hh, a.mask_slope);
     if (vlive) {
-      T* yrow = reinterpret_cast<T*>(a.y) + (int64_t)r * a.cout;
+      T* yrow = reinterpret_cast<T*>(a.y) + (int64_t)vrow * a.cout;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int co = nt0 * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh;
@@ -2662,9 +2663,9 @@ static int launch_pw_fwd(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st,
   constexpr int E = 16 / (int)sizeof(T);
   if (a.taps != 1 || s->upsample_in || a.pixel_norm) return SG_OK;
   const int64_t nvox = (int64_t)s->n * s->d * s->h * s->w;
-  if (nvox <= 32 && s->cin % sg_traits<T>::CH == 0 && a.nchunk >= 64 && !sg_cfg().fwd_no_dense) {
+  if (nvox <= 128 && s->cin % sg_traits<T>::CH == 0 && a.nchunk >= 64 && !sg_cfg().fwd_no_dense) {
     SG_KNAME("dense_small_m<%s>", sg_tname<T>());
-    hipLaunchKernelGGL(dense_small_m_kernel<T>, dim3((unsigned)a.ntile), dim3(1024), 0, st, a, (int)nvox);
+    hipLaunchKernelGGL(dense_small_m_kernel<T>, dim3((unsigned)a.ntile, (unsigned)((nvox + 31) / 32)), dim3(1024), 0, st, a, (int)nvox);
     SG_LAUNCH_CHECK();
     *used = true;
     return SG_OK;

@@ -719,8 +719,10 @@ class _Axpby(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        ga = _Axpby.apply(g, None, ctx.wa, 0.0) if ctx.needs_input_grad[0] else None
-        gb = _Axpby.apply(g, None, ctx.wb, 0.0) if (ctx.has_b and ctx.needs_input_grad[1]) else None
+        def scaled(w):      # w * g; a weight of exactly 1 (the stabilising phase's alpha = 0 side) is the identity: no pass
+            return g if float(w) == 1.0 else _Axpby.apply(g, None, w, 0.0)
+        ga = scaled(ctx.wa) if ctx.needs_input_grad[0] else None
+        gb = scaled(ctx.wb) if (ctx.has_b and ctx.needs_input_grad[1]) else None
         return ga, gb, None, None
 
 

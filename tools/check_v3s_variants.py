@@ -10,9 +10,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from saragan_amd import _lib, functional as F   # noqa: E402
 
-lib = _lib.load()
-dev = torch.device('cuda:0')
-torch.manual_seed(0)
+lib = None
+dev = None
 
 
 def run(no_v3s, fn):
@@ -53,53 +52,62 @@ def cmp(tag, a, b):
     return worst
 
 
-ok = True
-for (n, cin, cout, sp, ups) in [(2, 32, 32, (6, 128, 256), False), (2, 32, 64, (8, 126, 256), False), (3, 16, 32, (4, 128, 256), False),
-                                (2, 64, 32, (6, 128, 256), False), (2, 64, 32, (8, 128, 256), True), (3, 64, 32, (4, 124, 256), True)]:
-    xsp = tuple(t // 2 for t in sp) if ups else sp
-    x = torch.randn(n, cin, *xsp, device=dev).bfloat16().contiguous(memory_format=torch.channels_last_3d)
-    w = torch.randn(3, 3, 3, cin, cout, device=dev)
-    b = torch.randn(cout, device=dev) * 0.3
-    coef = (2.0 / (27 * cin)) ** 0.5
-    words = torch.randint(-2 ** 31, 2 ** 31 - 1, (n * sp[0] * sp[1] * sp[2] * (cout // 32),), device=dev, dtype=torch.int64).to(torch.int32)
-    cases = {
-        'plain': dict(),
-        'bias+act+signs': dict(bias=b, act=True, want_signs=True),
-        'masked': dict(mask_bits=words, mask_slope=0.2),
-        'pn+act+scale+signs': dict(bias=b, act=True, pixel_norm=True, want_scale=True, want_signs=True),
-        'pn': dict(bias=b, act=True, pixel_norm=True),
-        'pool+signs': dict(bias=b, act=True, want_signs=True, pool=True),
-    }
-    for name, kw in cases.items():
-        if kw.get('pool') and (cin > 32 or ups):
-            continue
-        if ups and 'mask_bits' in kw:
-            continue
-        got, kg = run(False, lambda: F.raw_conv(x, w, coef, False, ups, **kw))
-        ref, kr = run(True, lambda: F.raw_conv(x, w, coef, False, ups, **kw))
-        print(f'n{n} {cin}->{cout} {sp} ups{int(ups)} {name}: {kg} vs {kr}')
-        if ref is None or got is None:
-            print('   (not available on one path)', got is None, ref is None)
-            continue
-        wst = cmp(name, got, ref)
-        if wst > 2e-2:
-            ok = False
-            print('   ** MISMATCH')
-            if not kw.get('pixel_norm') and not kw.get('pool') and 'mask_bits' not in kw:
-                wq = (w * coef).bfloat16().float()
-                xf = x.float()
-                if ups:
-                    xf = xf.repeat_interleave(2, 2).repeat_interleave(2, 3).repeat_interleave(2, 4)
-                z = torch.nn.functional.conv3d(xf, wq.permute(4, 3, 0, 1, 2).contiguous(), padding=1)
-                if 'bias' in kw:
-                    z = z + b.view(1, -1, 1, 1, 1)
-                if kw.get('act'):
-                    z = torch.nn.functional.leaky_relu(z, 0.2)
-                for nm, t in (('sliding-halo', got[0]), ('other', ref[0])):
-                    e = (t.float() - z).abs()
-                    print(f'      {nm} vs torch fp32: max err {float(e.max()):.3e} (ref max {float(z.abs().max()):.3e}), '
-                          f'{int((e > 0.05 * z.abs().max()).sum())} elements off')
-os.environ['SG_FWD_NO_V3S'] = '0'
-lib.sg_config_reload()
-print('OK' if ok else 'FAILED')
-sys.exit(0 if ok else 1)
+def main():
+    global lib, dev
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    ok = True
+    for (n, cin, cout, sp, ups) in [(2, 32, 32, (6, 128, 256), False), (2, 32, 64, (8, 126, 256), False), (3, 16, 32, (4, 128, 256), False),
+                                    (2, 64, 32, (6, 128, 256), False), (2, 64, 32, (8, 128, 256), True), (3, 64, 32, (4, 124, 256), True)]:
+        xsp = tuple(t // 2 for t in sp) if ups else sp
+        x = torch.randn(n, cin, *xsp, device=dev).bfloat16().contiguous(memory_format=torch.channels_last_3d)
+        w = torch.randn(3, 3, 3, cin, cout, device=dev)
+        b = torch.randn(cout, device=dev) * 0.3
+        coef = (2.0 / (27 * cin)) ** 0.5
+        words = torch.randint(-2 ** 31, 2 ** 31 - 1, (n * sp[0] * sp[1] * sp[2] * (cout // 32),), device=dev, dtype=torch.int64).to(torch.int32)
+        cases = {
+            'plain': dict(),
+            'bias+act+signs': dict(bias=b, act=True, want_signs=True),
+            'masked': dict(mask_bits=words, mask_slope=0.2),
+            'pn+act+scale+signs': dict(bias=b, act=True, pixel_norm=True, want_scale=True, want_signs=True),
+            'pn': dict(bias=b, act=True, pixel_norm=True),
+            'pool+signs': dict(bias=b, act=True, want_signs=True, pool=True),
+        }
+        for name, kw in cases.items():
+            if kw.get('pool') and (cin > 32 or ups):
+                continue
+            if ups and 'mask_bits' in kw:
+                continue
+            got, kg = run(False, lambda: F.raw_conv(x, w, coef, False, ups, **kw))
+            ref, kr = run(True, lambda: F.raw_conv(x, w, coef, False, ups, **kw))
+            print(f'n{n} {cin}->{cout} {sp} ups{int(ups)} {name}: {kg} vs {kr}')
+            if ref is None or got is None:
+                print('   (not available on one path)', got is None, ref is None)
+                continue
+            wst = cmp(name, got, ref)
+            if wst > 2e-2:
+                ok = False
+                print('   ** MISMATCH')
+                if not kw.get('pixel_norm') and not kw.get('pool') and 'mask_bits' not in kw:
+                    wq = (w * coef).bfloat16().float()
+                    xf = x.float()
+                    if ups:
+                        xf = xf.repeat_interleave(2, 2).repeat_interleave(2, 3).repeat_interleave(2, 4)
+                    z = torch.nn.functional.conv3d(xf, wq.permute(4, 3, 0, 1, 2).contiguous(), padding=1)
+                    if 'bias' in kw:
+                        z = z + b.view(1, -1, 1, 1, 1)
+                    if kw.get('act'):
+                        z = torch.nn.functional.leaky_relu(z, 0.2)
+                    for nm, t in (('sliding-halo', got[0]), ('other', ref[0])):
+                        e = (t.float() - z).abs()
+                        print(f'      {nm} vs torch fp32: max err {float(e.max()):.3e} (ref max {float(z.abs().max()):.3e}), '
+                              f'{int((e > 0.05 * z.abs().max()).sum())} elements off')
+    os.environ['SG_FWD_NO_V3S'] = '0'
+    lib.sg_config_reload()
+    print('OK' if ok else 'FAILED')
+    return ok
+
+
+if __name__ == '__main__':
+    sys.exit(0 if main() else 1)

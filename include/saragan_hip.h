@@ -169,6 +169,10 @@ int sg_upscale_nn(const void* x, void* y, const void* mask_bits, float mask_slop
                   int32_t w, int32_t c, int32_t fd, int32_t fh, int32_t fw, float gain, sg_dtype dt, sg_stream_t st);
 int sg_downscale_sum(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c, int32_t fd,
                      int32_t fh, int32_t fw, float gain, sg_dtype dt, sg_stream_t st);
+/* The same over M * x, M = where(sign bit, mask_slope, 1) from sign words shaped like x [n*d*h*w][ceil(c/32)]: the
+ * gradient of sg_upscale_nn with a mask (networks/ops.py:175-178 composed with :265-273) in one pass. */
+int sg_downscale_sum_masked(const void* x, const void* mask_bits, float mask_slope, void* y, int32_t n, int32_t d, int32_t h,
+                            int32_t w, int32_t c, int32_t fd, int32_t fh, int32_t fw, float gain, sg_dtype dt, sg_stream_t st);
 /* Trilinear x2 up-sampling with half-pixel centres (`align_corners=False`; BASELINE north_star names a trilinear
  * resampler, the reference itself only has the nearest one): adjoint == 0: x [n,d,h,w,c] -> y [n,2d,2h,2w,c];
  * adjoint != 0: the gradient, x = dy [n,2d,2h,2w,c] -> y = dx [n,d,h,w,c] ((d,h,w) is always the LOW-resolution

@@ -63,6 +63,7 @@ SIGNATURES = {
     'sg_downscale2x': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
     'sg_upscale_nn': (C.c_int, [_p, _p, _p, _f, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
     'sg_downscale_sum': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
+    'sg_downscale_sum_masked': (C.c_int, [_p, _p, _f, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
     'sg_trilinear_up2x': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, C.c_int, _p]),
     'sg_axpby': (C.c_int, [_p, _p, _p, _f, _f, _i64, C.c_int, _p]),
     'sg_add_noise': (C.c_int, [_p, _p, _f, _u64, _u64, _i64, C.c_int, _p]),

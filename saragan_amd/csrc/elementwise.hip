@@ -458,9 +458,13 @@ __global__ __launch_bounds__(256) void upscale2x_rows_kernel(const T* __restrict
   }
 }
 
-template <typename T, bool VEC>
+// MASKED: each source voxel is first multiplied by where(sign bit, mask_slope, 1) from sign words shaped like x
+// (the gradient of a masked nearest up-scale in one pass: y = gain * sum_block M * x).
+template <typename T, bool VEC, bool MASKED = false>
 __global__ void downscale2x_kernel(const T* __restrict__ x, T* __restrict__ y, int n, int d, int h, int w, int c,
-                                   int sd, int sh, int sw, float gain) {
+                                   int sd, int sh, int sw, float gain, const uint32_t* __restrict__ bits = nullptr,
+                                   float mask_slope = 0.f) {
+  const int nw = (c + 31) >> 5;
   constexpr int E = VEC ? Piece<T>::E : 1;
   const int P = c / E;
   const int od = d >> sd, oh = h >> sh, ow = w >> sw;
@@ -479,15 +483,18 @@ __global__ void downscale2x_kernel(const T* __restrict__ x, T* __restrict__ y, i
     for (int k = 0; k < 8; ++k) {
       const int kd = k >> 2, kh = (k >> 1) & 1, kw = k & 1;
       if (kd > sd || kh > sh || kw > sw) continue;     // uniform: a factor-1 dimension has one tap
-      const int64_t src =
-          ((((int64_t)nn * d + ((xd << sd) + kd)) * h + ((xh << sh) + kh)) * w + ((xw << sw) + kw)) * c + (int64_t)p * E;
+      const int64_t vox = (((int64_t)nn * d + ((xd << sd) + kd)) * h + ((xh << sh) + kh)) * w + ((xw << sw) + kw);
+      const int64_t src = vox * c + (int64_t)p * E;
+      uint32_t mb = 0u;
+      if (MASKED) mb = bits[vox * nw + ((p * E) >> 5)] >> ((p * E) & 31);
       if (VEC) {
         Piece<T> pc;
         pc.load(x + src);
 #pragma unroll
-        for (int e = 0; e < Piece<T>::E; ++e) s[e] += pc.v[e];
+        for (int e = 0; e < Piece<T>::E; ++e) s[e] += (MASKED && ((mb >> e) & 1u)) ? pc.v[e] * mask_slope : pc.v[e];
       } else {
-        s[0] += sg_traits<T>::to_f(x[src]);
+        const float v = sg_traits<T>::to_f(x[src]);
+        s[0] += (MASKED && (mb & 1u)) ? v * mask_slope : v;
       }
     }
     if (VEC) {
@@ -1009,6 +1016,25 @@ extern "C" int sg_downscale_sum(const void* x, void* y, int32_t n, int32_t d, in
   const int64_t items = (int64_t)n * (d >> sd) * (h >> sh) * (w >> sw) * (vec ? c / E : c);
   const int blocks = grid_for(items, 256, 4096);
 #define L(T, V) hipLaunchKernelGGL((downscale2x_kernel<T, V>), dim3(blocks), dim3(256), 0, hs, (const T*)x, (T*)y, n, d, h, w, c, sd, sh, sw, gain)
+  if (vec) SG_DISPATCH(dt, L(bf16_t, true), L(float, true));
+  else SG_DISPATCH(dt, L(bf16_t, false), L(float, false));
+#undef L
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_downscale_sum_masked(const void* x, const void* mask_bits, float mask_slope, void* y, int32_t n, int32_t d,
+                                       int32_t h, int32_t w, int32_t c, int32_t fd, int32_t fh, int32_t fw, float gain,
+                                       sg_dtype dt, sg_stream_t st) {
+  const int sd = sg_factor_shift(fd), sh = sg_factor_shift(fh), sw = sg_factor_shift(fw);
+  if (!x || !y || !mask_bits || n < 1 || d < fd || h < fh || w < fw || c < 1 || sd < 0 || sh < 0 || sw < 0) return SG_EINVAL;
+  if ((sd && (d & 1)) || (sh && (h & 1)) || (sw && (w & 1))) return SG_EINVAL;
+  hipStream_t hs = sg_st(st);
+  const int E = dt == SG_BF16 ? 8 : 4;
+  const bool vec = (c % E == 0) && sg_aligned16(x) && sg_aligned16(y);
+  const int64_t items = (int64_t)n * (d >> sd) * (h >> sh) * (w >> sw) * (vec ? c / E : c);
+  const int blocks = grid_for(items, 256, 4096);
+#define L(T, V) hipLaunchKernelGGL((downscale2x_kernel<T, V, true>), dim3(blocks), dim3(256), 0, hs, (const T*)x, (T*)y, n, d, h, w, c, sd, sh, sw, gain, (const uint32_t*)mask_bits, mask_slope)
   if (vec) SG_DISPATCH(dt, L(bf16_t, true), L(float, true));
   else SG_DISPATCH(dt, L(bf16_t, false), L(float, false));
 #undef L

@@ -645,9 +645,8 @@ class _Up(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         (mask_bits,) = ctx.saved_tensors
-        if mask_bits is not None:
-            gy, _ = _BiasActBwd.apply(gy, mask_bits, ctx.mask_slope, False)
-        return _Down.apply(gy, ctx.gain, None, ctx.factors), None, None, None, None
+        # y = M * up(x): the gradient is down(M * gy), mask and block sum in one pass (sg_downscale_sum_masked)
+        return _Down.apply(gy, ctx.gain, None, ctx.factors, mask_bits, ctx.mask_slope), None, None, None, None
 
 
 class _Down(torch.autograd.Function):
@@ -655,23 +654,32 @@ class _Down(torch.autograd.Function):
     292-305; gain 1/4 with (1,2,2): downscale2d)."""
 
     @staticmethod
-    def forward(ctx, x, gain, in_info=None, factors=(2, 2, 2)):
+    def forward(ctx, x, gain, in_info=None, factors=(2, 2, 2), mask_bits=None, mask_slope=0.0):
         lib = _lib.load()
         _req_cuda(x)
         x = ndhwc(x)
         n, c, d, h, w = _dims(x)
         fd, fh, fw = factors
         y = _empty_like_shape(x, c, (d // fd, h // fh, w // fw))
-        check(lib.sg_downscale_sum(_ptr(x), _ptr(y), n, d, h, w, c, fd, fh, fw, float(gain), _dt(x), _stream()),
-              'sg_downscale_sum')
-        ctx.gain, ctx.in_info, ctx.factors = gain, in_info, tuple(factors)
+        if mask_bits is not None:     # y = gain * block sum of M * x
+            _check_signs(mask_bits, n * d * h * w, c)
+            check(lib.sg_downscale_sum_masked(_ptr(x), _ptr(mask_bits), float(mask_slope), _ptr(y), n, d, h, w, c, fd, fh, fw,
+                                              float(gain), _dt(x), _stream()), 'sg_downscale_sum_masked')
+        else:
+            check(lib.sg_downscale_sum(_ptr(x), _ptr(y), n, d, h, w, c, fd, fh, fw, float(gain), _dt(x), _stream()),
+                  'sg_downscale_sum')
+        ctx.gain, ctx.in_info, ctx.factors, ctx.mask_slope = gain, in_info, tuple(factors), mask_slope
+        ctx.save_for_backward(mask_bits)
         return y
 
     @staticmethod
     def backward(ctx, gy):
+        (mask_bits,) = ctx.saved_tensors
+        if mask_bits is not None:     # adjoint of (block sum after mask) = mask after nearest up-scale
+            return _Up.apply(gy, ctx.gain, mask_bits, ctx.mask_slope, ctx.factors), None, None, None, None, None
         if _masked_in(ctx.in_info):
-            return _Up.apply(gy, ctx.gain, ctx.in_info.bits, ctx.in_info.slope, ctx.factors), None, None, None
-        return _Up.apply(gy, ctx.gain, None, 0.0, ctx.factors), None, None, None
+            return _Up.apply(gy, ctx.gain, ctx.in_info.bits, ctx.in_info.slope, ctx.factors), None, None, None, None, None
+        return _Up.apply(gy, ctx.gain, None, 0.0, ctx.factors), None, None, None, None, None
 
 
 class _TriUp(torch.autograd.Function):

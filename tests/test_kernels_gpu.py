@@ -504,6 +504,31 @@ def test_conv_epilogue_fused_downscale():
     assert F.raw_conv(xg.float(), wg, coef, False, bias=bg, act=True, want_signs=True, pool=True) is None
 
 
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('shape,factors', [((2, 40, 4, 6, 8), (2, 2, 2)), ((1, 8, 2, 4, 6), (1, 2, 2)), ((2, 33, 4, 4, 4), (2, 1, 2))])
+def test_masked_block_sum_is_the_gradient_of_the_masked_upscale(shape, factors, dtype):
+    """sg_downscale_sum_masked: gain * block sum of where(a < 0, slope, 1) * x in one pass (the gradient of
+    upscale3d followed by a LeakyReLU mask, networks/ops.py:175-178 with :265-273), against the two-pass form and fp64;
+    and as the backward of the masked up-scale Function."""
+    from saragan_amd import functional as F
+    n, c, d, h, w = shape
+    x = rnd(shape, 81, dtype)
+    a = rnd(shape, 82, dtype)
+    xg, ag = cl(x, dtype), cl(a, dtype)
+    bits = F.sign_words(ag)
+    got = F._Down.apply(xg, 0.125, None, factors, bits, 0.2)
+    m = torch.where(a.double() < 0, 0.2, 1.0)
+    ref = (x.double() * m).reshape(n, c, d // factors[0], factors[0], h // factors[1], factors[1], w // factors[2], factors[2]).sum(dim=(3, 5, 7)) * 0.125
+    close(got, ref, dtype, 'masked block sum')
+    two = F._Down.apply(F._BiasActBwd.apply(xg, bits, 0.2, False)[0], 0.125, None, factors)
+    close(got, two, dtype, 'one pass vs two passes')
+    # as the backward of y = M * up(g)
+    gsm = cl(rnd(tuple(ref.shape), 83, dtype), dtype).requires_grad_(True)
+    up = F._Up.apply(gsm, 0.125, bits, 0.2, factors)
+    (gg,) = torch.autograd.grad(up, gsm, xg)
+    close(gg, ref, dtype, 'gradient of the masked up-scale')
+
+
 def test_conv_64_to_32_split_over_input_channels(sg_env):
     """The 64 -> 32 channel 3x3x3 bf16 layers run as two sliding-halo passes over 32 input channels each, f32 partial
     sums in sg_conv_epilogue.workspace (sg_conv3d_fwd_workspace).  Same inputs through the split path, through the

@@ -339,6 +339,48 @@ def _masked_in(ctx_info):
     return ctx_info is not None and ctx_info.all_premask()
 
 
+class BackInfo:
+    """The same bookkeeping one order up.  `t = M * conv(x)` (a data-gradient conv with a LeakyReLU mask in its epilogue,
+    created while the gradient penalty's first backward builds its graph) has the backward gy -> M * gy, a full pass over
+    the tensor.  Every Function that consumes `t` registers here (forward time); consumers that are able to return
+    M * (their gradient) from their own kernel -- a conv's mask epilogue -- register as `premask`.  If all of them did,
+    they do, and the producer skips its pass (decided at backward time, when all consumers are known).  Functions of this
+    module are the only consumers of such tensors; all of them call _note_consumer on their tensor inputs."""
+
+    def __init__(self, bits, slope):
+        self.bits, self.slope = bits, float(slope)
+        self.n_consumers = 0
+        self.n_premask = 0
+        self._decision = None
+
+    def all_premask(self):
+        # decided once, by whoever asks first (a consumer's backward runs before the producer's): the backward itself
+        # hands the tensor to further Functions (the weight gradient of the double backward), which must not change
+        # what the consumers that already ran were told
+        if self._decision is None:
+            self._decision = self.n_consumers > 0 and self.n_consumers == self.n_premask
+        return self._decision
+
+
+_NO_BACK_PREMASK = bool(int(os.environ.get('SARAGAN_NO_BACK_PREMASK', '0')))   # diagnostic: always the separate mask pass
+
+
+def _note_consumer(t, premask=False):
+    info = getattr(t, '_sg_back', None) if t is not None else None
+    if info is not None and info._decision is None:
+        info.n_consumers += 1
+        if premask and not _NO_BACK_PREMASK:
+            info.n_premask += 1
+    return info
+
+
+def _note_all(*args):
+    """A Function without a mask epilogue consuming the output of a masked conv: counted, never pre-masking."""
+    for a in args:
+        if isinstance(a, torch.Tensor):
+            _note_consumer(a)
+
+
 class _Conv(torch.autograd.Function):
     """Plain conv3d / dense (networks/ops.py:139-150) or, with flip, its data gradient; `mask_bits` (sign words
     of a tensor shaped like y) fuses a LeakyReLU backward into the epilogue (y *= where(bit, mask_slope, 1))."""
@@ -347,18 +389,27 @@ class _Conv(torch.autograd.Function):
     def forward(ctx, x, w, coef, flip, ups, in_info=None, mask_bits=None, mask_slope=0.0):
         ctx.save_for_backward(x, w, mask_bits)
         ctx.coef, ctx.flip, ctx.ups, ctx.in_info, ctx.mask_slope = coef, flip, ups, in_info, mask_slope
+        # my backward returns conv'(gy) for x: with a mask epilogue if x is a masked conv's output (see BackInfo)
+        ctx.x_back = _note_consumer(x, premask=not ups)
         y, _, _ = raw_conv(x, w, coef, flip, ups, mask_bits=mask_bits, mask_slope=mask_slope)
+        ctx.out_back = None
+        if mask_bits is not None:
+            ctx.out_back = y._sg_back = BackInfo(mask_bits, mask_slope)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, w, mask_bits = ctx.saved_tensors
-        if mask_bits is not None:     # y = M * conv(x): pull the (linear) mask back onto the incoming gradient
+        if mask_bits is not None and not (ctx.out_back is not None and ctx.out_back.all_premask()):
+            # y = M * conv(x): pull the (linear) mask back onto the incoming gradient -- unless every consumer of y
+            # already did so in the kernel that produced its share of gy
             gy, _ = _BiasActBwd.apply(gy, mask_bits, ctx.mask_slope, False)
         gx = gw = None
         k = tuple(w.shape[:3]) if w.dim() == 5 else (1, 1, 1)
         if ctx.needs_input_grad[0]:
-            if _masked_in(ctx.in_info) and not ctx.ups:
+            if ctx.x_back is not None and ctx.x_back.all_premask() and not ctx.ups:
+                gx = _Conv.apply(gy, w, ctx.coef, not ctx.flip, False, None, ctx.x_back.bits, ctx.x_back.slope)
+            elif _masked_in(ctx.in_info) and not ctx.ups:
                 gx = _Conv.apply(gy, w, ctx.coef, not ctx.flip, False, None, ctx.in_info.bits, ctx.in_info.slope)
             else:
                 gx = _Conv.apply(gy, w, ctx.coef, not ctx.flip, False)
@@ -378,6 +429,7 @@ class _Conv(torch.autograd.Function):
 class _Wgrad(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, dy, k, coef, ups, want_db):
+        _note_all(x, dy, k, coef, ups, want_db)
         ctx.save_for_backward(x, dy)
         ctx.k, ctx.coef, ctx.ups = k, coef, ups
         dw, db = raw_wgrad(x, dy, k, coef, ups, want_db)
@@ -405,6 +457,7 @@ class _ConvBiasAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, coef, ups, act, slope, pixel_norm, eps, out_info=None, in_info=None):
+        _note_all(x, w, b, coef, ups, act, slope, pixel_norm, eps, out_info, in_info)
         y, scale, signs = raw_conv(x, w, coef, False, ups, bias=b, act=act, slope=slope, pixel_norm=pixel_norm,
                                    eps=eps, want_scale=True, want_signs=act and not _NO_SIGN_WORDS)
         if out_info is not None:
@@ -464,6 +517,7 @@ class _ConvBiasActPool(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, coef, slope, in_info=None):
+        _note_all(x, w, b, coef, slope, in_info)
         res = raw_conv(x, w, coef, False, False, bias=b, act=True, slope=slope, want_signs=True, pool=True)
         if res is None:
             raise _lib.SgError('pool fusion not available for this layer')
@@ -513,6 +567,7 @@ class _BiasActBwd(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, dy, y, slope, want_db):
+        _note_all(dy, y, slope, want_db)
         dx, db = raw_bias_act_bwd(dy, y, slope, True, want_db)
         ctx.save_for_backward(y)
         ctx.slope = slope
@@ -531,6 +586,7 @@ class _BiasActBwd(torch.autograd.Function):
 class _BiasAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, b, act, slope):
+        _note_all(x, b, act, slope)
         lib = _lib.load()
         _req_cuda(x, b)
         x = ndhwc(x)
@@ -557,6 +613,7 @@ class _BiasAct(torch.autograd.Function):
 class _PixelNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, eps):
+        _note_all(x, eps)
         lib = _lib.load()
         _req_cuda(x)
         x = ndhwc(x)
@@ -580,6 +637,7 @@ class _PixelNormBwd(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, gy, y, scale):
+        _note_all(gy, y, scale)
         lib = _lib.load()
         gy, y = ndhwc(gy), ndhwc(y)
         n, c, d, h, w = _dims(gy)
@@ -599,6 +657,7 @@ class _PnActBwd(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, gy, y, scale, signs, slope, want_db):
+        _note_all(gy, y, scale, signs, slope, want_db)
         lib = _lib.load()
         gy, y = ndhwc(gy), ndhwc(y)
         n, c, d, h, w = _dims(gy)
@@ -629,6 +688,7 @@ class _Up(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gain, mask_bits=None, mask_slope=0.0, factors=(2, 2, 2)):
+        _note_all(x)
         lib = _lib.load()
         _req_cuda(x, mask_bits)
         x = ndhwc(x)
@@ -655,6 +715,7 @@ class _Down(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gain, in_info=None, factors=(2, 2, 2), mask_bits=None, mask_slope=0.0):
+        _note_all(x)
         lib = _lib.load()
         _req_cuda(x)
         x = ndhwc(x)
@@ -688,6 +749,7 @@ class _TriUp(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, adjoint):
+        _note_all(x, adjoint)
         lib = _lib.load()
         _req_cuda(x)
         x = ndhwc(x)
@@ -712,6 +774,7 @@ class _Axpby(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b, wa, wb):
+        _note_all(a, b, wa, wb)
         lib = _lib.load()
         _req_cuda(a, b)
         a = ndhwc(a)
@@ -737,6 +800,7 @@ class _Axpby(torch.autograd.Function):
 class _AddNoise(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, stddev, seed, offset):
+        _note_all(x, stddev, seed, offset)
         lib = _lib.load()
         _req_cuda(x)
         x = ndhwc(x)
@@ -755,6 +819,7 @@ class _SumsqKeepW(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, g):
+        _note_all(g)
         lib = _lib.load()
         _req_cuda(g)
         g = ndhwc(g)
@@ -830,6 +895,7 @@ class _MinibatchStddev(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, group_size):
+        _note_all(x, group_size)
         lib = _lib.load()
         _req_cuda(x)
         x = ndhwc(x)

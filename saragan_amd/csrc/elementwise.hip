@@ -25,6 +25,16 @@ struct Piece {
     *reinterpret_cast<u32x4*>(p) = raw;
     SG_STORE16_GUARD(raw);
   }
+  // non-temporal form for write-dominated streams (the masked up-scale writes 8x what it reads: 3.8-4.0 -> 4.3-6.4 TB/s,
+  // tools/ew_roofline.py; read-dominated kernels gain a few per cent at most and the whole step nothing measurable)
+  __device__ __forceinline__ void store_nt(T* p) const {
+    u32x4 raw;
+    T* t = reinterpret_cast<T*>(&raw);
+#pragma unroll
+    for (int e = 0; e < E; ++e) t[e] = sg_traits<T>::from_f(v[e]);
+    __builtin_nontemporal_store(raw, reinterpret_cast<u32x4*>(p));
+    SG_STORE16_GUARD(raw);
+  }
 };
 
 // sign words (include/saragan_hip.h): the E <= 8 channels of one 16-byte piece starting at channel c0 (c0 % E == 0)
@@ -451,7 +461,7 @@ __global__ __launch_bounds__(256) void upscale2x_rows_kernel(const T* __restrict
             const float v = pc[j].v[e] * gain;
             pc[j].v[e] = ((sg[j] >> e) & 1u) ? v * mask_slope : v;
           }
-          pc[j].store(yrow + (int64_t)i * E);
+          pc[j].store_nt(yrow + (int64_t)i * E);
         }
       }
     }

@@ -529,6 +529,55 @@ def test_masked_block_sum_is_the_gradient_of_the_masked_upscale(shape, factors, 
     close(gg, ref, dtype, 'gradient of the masked up-scale')
 
 
+@pytest.mark.parametrize('dtype', DT)
+def test_premasked_double_backward_equals_separate_mask_passes(dtype, monkeypatch):
+    """Gradient-penalty style second-order gradients through three conv + LeakyReLU layers wired the way the network
+    code wires them (functional.ActInfo: each layer's mask applied by the next layer's data-gradient conv), once with
+    the double backward's mask pull-backs fused into the consumers' conv epilogues (functional.BackInfo) and once as
+    separate passes: same kernels otherwise, so the weight gradients agree to rounding of the intermediate tensors."""
+    from saragan_amd import functional as F
+    n, sp, chans = 2, (4, 8, 8), (8, 16, 16, 8)
+    x0 = cl(rnd((n, chans[0], *sp), 91, dtype), dtype)
+    ws = [rnd((3, 3, 3, chans[i], chans[i + 1]), 92 + i, torch.float32).to(dev()) for i in range(3)]
+    bs = [(rnd((chans[i + 1],), 96 + i, torch.float32) * 0.2).to(dev()) for i in range(3)]
+
+    passes = []
+    real_bwd = F.raw_bias_act_bwd
+
+    def counting(*a, **k):
+        passes[-1] += 1
+        return real_bwd(*a, **k)
+    monkeypatch.setattr(F, 'raw_bias_act_bwd', counting)
+
+    def second_order(no_premask):
+        monkeypatch.setattr(F, '_NO_BACK_PREMASK', no_premask)
+        passes.append(0)
+        x = x0.clone().requires_grad_(True)
+        wv = [w.clone().requires_grad_(True) for w in ws]
+        bv = [b.clone().requires_grad_(True) for b in bs]
+        h, info = x, None
+        for i in range(3):
+            out = F.ActInfo(0.2)
+            if info is not None:
+                info.consume(True)          # my data-gradient conv applies the previous layer's mask
+            h = F.conv3d(h, wv[i], 0.1, bias=bv[i], act=True, slope=0.2, out_info=out, in_info=info)
+            info = out
+        info.consume(False)
+        with F.skip_param_grads(wv + bv):
+            (gx,) = torch.autograd.grad(h.float().sum(), x, create_graph=True)
+        pen = (gx.float() ** 2).sum()
+        return [g.float() for g in torch.autograd.grad(pen, wv)]
+
+    fused = second_order(False)
+    plain = second_order(True)
+    assert passes[0] < passes[1], passes        # the fused run really skipped mask passes
+    for i, (a, b) in enumerate(zip(fused, plain)):
+        scale = float(b.abs().max())
+        assert scale > 0
+        tol = 2e-5 if dtype == torch.float32 else 2e-2       # bf16: the fused path skips a bf16 rounding of the masked tensor
+        assert float((a - b).abs().max()) <= tol * scale, (i, float((a - b).abs().max()), scale)
+
+
 def test_conv_64_to_32_split_over_input_channels(sg_env):
     """The 64 -> 32 channel 3x3x3 bf16 layers run as two sliding-halo passes over 32 input channels each, f32 partial
     sums in sg_conv_epilogue.workspace (sg_conv3d_fwd_workspace).  Same inputs through the split path, through the

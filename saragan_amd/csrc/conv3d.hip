@@ -2538,7 +2538,7 @@ __global__ __launch_bounds__(256) void pw_fwd_small_cin_kernel(ConvFwdArgs a, in
     T* t = reinterpret_cast<T*>(&raw);
 #pragma unroll
     for (int e = 0; e < E; ++e) t[e] = sg_traits<T>::from_f(o[e]);
-    *reinterpret_cast<u32x4*>(y + v * a.cout + c0) = raw;
+    __builtin_nontemporal_store(raw, reinterpret_cast<u32x4*>(y + v * a.cout + c0));   // write-dominated stream
     SG_STORE16_GUARD(raw);
   }
 }

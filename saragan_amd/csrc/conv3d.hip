@@ -2142,6 +2142,7 @@ __global__ __launch_bounds__(512) void conv_fwd5_kernel(ConvFwdArgs a) {
   constexpr int TAPS = 27, ES = 2, EPP = 8, NFRAG = TAPS * 2, HF = (NFRAG + 1) / 2;
   constexpr uint32_t DEAD = 0x80000000u;             // byte offset beyond every buffer: loads return 0, stores drop
   constexpr bool SIGN = (EPI & SG_EP_SIGN) != 0, MASK = (EPI & SG_EP_MASK) != 0, PN = (EPI & SG_EP_PN) != 0;
+  constexpr bool POOL = (EPI & SG_EP_POOL) != 0;     // y: the 1 x 2 x 2 (H x W) block means, [n, D, H/2, W/2, cout] (pool == 2)
   const sg_tile_geom& g = a.g;                       // TN = 1, TW = 32, 256 voxels, TH even (host-checked)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2205,7 +2206,7 @@ __global__ __launch_bounds__(512) void conv_fwd5_kernel(ConvFwdArgs a) {
     crd[k] = row < hv ? (hw | (hh_ << 8) | (hd << 16)) : 0x7F7F7F7F;   // 0x7F7F7F7F: beyond the image, the lane stays idle
   }
   const int64_t svox = (int64_t)D * H * W;
-  const int64_t xsb = svox * cin * ES, ysb = svox * cout * ES, wsb = svox * ntile * 4, psb = svox * 4;
+  const int64_t xsb = svox * cin * ES, ysb = (POOL ? svox >> 2 : svox) * cout * ES, wsb = svox * ntile * 4, psb = svox * 4;
   auto rsrc_of = [&](const void* base, int64_t sample_bytes, int n0) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(base)) + n0 * sample_bytes, 0,
                                              (int)sample_bytes, 0x00020000);
@@ -2254,6 +2255,7 @@ __global__ __launch_bounds__(512) void conv_fwd5_kernel(ConvFwdArgs a) {
   int kE = 0;
   __amdgpu_buffer_rsrc_t ryE, rsE, rmE, rpE;
   uint32_t vox[2];                                                 // my two output voxels within the sample; DEAD: outside
+  uint32_t pvox = DEAD;                                            // POOL: the pooled voxel my lane writes (even w only)
   auto enter_tile_E = [&]() {
     const sg_tile_origin o = sg_tile_of(g, (uint32_t)(first + (2 * kE + grp) * per_x));
     ryE = rsrc_of(a.y, ysb, o.n0);
@@ -2265,6 +2267,10 @@ __global__ __launch_bounds__(512) void conv_fwd5_kernel(ConvFwdArgs a) {
       const int tc = tcoord[mt];
       const int d = o.d0 + (tc >> 16), h = o.h0 + ((tc >> 8) & 255), w = o.w0 + (tc & 255);
       vox[mt] = (d < D && h < H && w < W) ? (uint32_t)((d * H + h) * W + w) : DEAD;
+      // H and W are even (host-checked) and M tile 0 sits on an even row: an even-w lane inside the volume has all
+      // four voxels of its block inside
+      if (POOL && mt == 0)
+        pvox = (vox[0] != DEAD && !(r & 1)) ? (uint32_t)((d * (H >> 1) + (h >> 1)) * (W >> 1) + (w >> 1)) : DEAD;
     }
   };
   // LeakyReLU sign words of E's tile (masked epilogue), requested when E enters the tile: ncg phases before their use
@@ -2357,15 +2363,43 @@ __global__ __launch_bounds__(512) void conv_fwd5_kernel(ConvFwdArgs a) {
             __builtin_amdgcn_raw_buffer_store_b32(sw2[0] | sw2[1], rsE, (ok && hh == 0) ? (vox[mt] * (uint32_t)ntile + nt0 + nt) * 4u : DEAD, 0, 0);
           }
           if (MASK) sg_apply_sign_word(acc[mt][nt], mbn[mt][nt], hh, a.mask_slope);
+          if constexpr (!POOL) {
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {   // 16 contiguous bytes per lane (see sg_store_tile_row_bf16)
-            const uint32_t a0 = sg_pack_bf16(acc[mt][nt][8 * j + 0], acc[mt][nt][8 * j + 1]), a1 = sg_pack_bf16(acc[mt][nt][8 * j + 2], acc[mt][nt][8 * j + 3]);
-            const uint32_t b0 = sg_pack_bf16(acc[mt][nt][8 * j + 4], acc[mt][nt][8 * j + 5]), b1 = sg_pack_bf16(acc[mt][nt][8 * j + 6], acc[mt][nt][8 * j + 7]);
+            for (int j = 0; j < 2; ++j) {   // 16 contiguous bytes per lane (see sg_store_tile_row_bf16)
+              const uint32_t a0 = sg_pack_bf16(acc[mt][nt][8 * j + 0], acc[mt][nt][8 * j + 1]), a1 = sg_pack_bf16(acc[mt][nt][8 * j + 2], acc[mt][nt][8 * j + 3]);
+              const uint32_t b0 = sg_pack_bf16(acc[mt][nt][8 * j + 4], acc[mt][nt][8 * j + 5]), b1 = sg_pack_bf16(acc[mt][nt][8 * j + 6], acc[mt][nt][8 * j + 7]);
+              const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+              const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+              u32x4 out;
+              out[0] = s0[0]; out[1] = s1[0]; out[2] = s0[1]; out[3] = s1[1];
+              __builtin_amdgcn_raw_buffer_store_b128(out, ryE, ok ? (vox[mt] * (uint32_t)cout + (uint32_t)((nt0 + nt) * 32 + 16 * j + 8 * hh)) * 2u : DEAD, 0, 0);
+              SG_STORE16_GUARD(out);
+            }
+          }
+        }
+      }
+      if constexpr (POOL) {
+        // fused downscale3d, first stage, for this kernel's tile: the wave's two M tiles are H neighbours (a lane-local
+        // add), W neighbours are adjacent lanes (one DPP exchange); the D pairs (other waves) are pooled by
+        // sg_downscale_sum(2,1,1) on the quarter-size tensor.  See the sliding-halo kernel's pool epilogue.
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          float sp[16];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) {
+            const float t = acc[0][nt][i] + acc[1][nt][i];
+            const float u = __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(t), 0xB1, 0xF, 0xF, true));
+            sp[i] = (t + u) * 0.25f;
+          }
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const uint32_t a0 = sg_pack_bf16(sp[8 * j + 0], sp[8 * j + 1]), a1 = sg_pack_bf16(sp[8 * j + 2], sp[8 * j + 3]);
+            const uint32_t b0 = sg_pack_bf16(sp[8 * j + 4], sp[8 * j + 5]), b1 = sg_pack_bf16(sp[8 * j + 6], sp[8 * j + 7]);
             const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
             const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
             u32x4 out;
             out[0] = s0[0]; out[1] = s1[0]; out[2] = s0[1]; out[3] = s1[1];
-            __builtin_amdgcn_raw_buffer_store_b128(out, ryE, ok ? (vox[mt] * (uint32_t)cout + (uint32_t)((nt0 + nt) * 32 + 16 * j + 8 * hh)) * 2u : DEAD, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(out, ryE, pvox != DEAD ? (pvox * (uint32_t)cout + (uint32_t)((nt0 + nt) * 32 + 16 * j + 8 * hh)) * 2u : DEAD, 0, 0);
             SG_STORE16_GUARD(out);
           }
         }
@@ -2429,7 +2463,8 @@ static int launch_fwd5_inst(const ConvFwdArgs& a, unsigned gx, unsigned gy, size
 static int launch_fwd5(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used) {
   *used = false;
   if (s->upsample_in || s->kd != 3 || s->kh != 3 || s->kw != 3 || a.os == 2 || a.tap_d || a.tap_h || a.tap_w) return SG_OK;
-  if ((s->cin % 16) != 0 || (s->cout % 64) != 0 || a.pool) return SG_OK;
+  if ((s->cin % 16) != 0 || (s->cout % 64) != 0 || a.pool == 1) return SG_OK;
+  if (a.pool && ((s->h | s->w) & 1 || a.pixel_norm || a.mask_bits)) return SG_OK;   // whole 1 x 2 x 2 blocks, plain epilogue
   if (a.pixel_norm && (a.mask_bits || a.ntile != 2)) return SG_OK;   // pixel norm needs all channels in one block
   if (a.mask_bits && a.sign_out) return SG_OK;
   a.g = sg_make_geom(s, 256, /*prefer_w32=*/true);
@@ -2456,10 +2491,13 @@ static int launch_fwd5(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, b
   a.ntiles = (int)ntiles;
   a.vec_in = 1;
   a.vec_out = 1;
-  const int epi = (a.sign_out ? SG_EP_SIGN : 0) | (a.mask_bits ? SG_EP_MASK : 0) | (a.pixel_norm ? SG_EP_PN : 0);
+  const int epi = (a.sign_out ? SG_EP_SIGN : 0) | (a.mask_bits ? SG_EP_MASK : 0) | (a.pixel_norm ? SG_EP_PN : 0) |
+                  (a.pool ? SG_EP_POOL : 0);
   int rc = SG_OK;
   switch (epi) {
     case 0: rc = launch_fwd5_inst<0>(a, (unsigned)gx, (unsigned)ny, lds, st); break;
+    case SG_EP_POOL: rc = launch_fwd5_inst<SG_EP_POOL>(a, (unsigned)gx, (unsigned)ny, lds, st); break;
+    case SG_EP_SIGN | SG_EP_POOL: rc = launch_fwd5_inst<SG_EP_SIGN | SG_EP_POOL>(a, (unsigned)gx, (unsigned)ny, lds, st); break;
     case SG_EP_SIGN: rc = launch_fwd5_inst<SG_EP_SIGN>(a, (unsigned)gx, (unsigned)ny, lds, st); break;
     case SG_EP_MASK: rc = launch_fwd5_inst<SG_EP_MASK>(a, (unsigned)gx, (unsigned)ny, lds, st); break;
     case SG_EP_PN: rc = launch_fwd5_inst<SG_EP_PN>(a, (unsigned)gx, (unsigned)ny, lds, st); break;
@@ -2720,7 +2758,7 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
   a.eps = ep ? ep->eps : 0.f;
   a.tap_d = ep ? ep->tap_off[0] : 0; a.tap_h = ep ? ep->tap_off[1] : 0; a.tap_w = ep ? ep->tap_off[2] : 0;
   a.pool = ep ? ep->pool : 0;
-  if (a.pool != 0 && a.pool != 1) return SG_EINVAL;
+  if (a.pool < 0 || a.pool > 2) return SG_EINVAL;
   a.xcs = s->cin; a.xco = 0; a.addend = nullptr;
   a.os = (ep && ep->out_scale == 2) ? 2 : 1;
   a.oa = ep ? ep->out_off[0] : 0; a.ob = ep ? ep->out_off[1] : 0; a.oc = ep ? ep->out_off[2] : 0;
@@ -2750,8 +2788,16 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     prof.done(rc);
     return rc;
   }
-  if (a.pool && (subpixel || dt != SG_BF16 || sg_cfg().fwd_v1 || sg_cfg().fwd_no_v3 || sg_cfg().fwd_no_v3s ||
-                 (s->cin * 2) % 16 != 0 || a.pixel_norm)) return SG_EUNSUPPORTED;
+  if (a.pool && (subpixel || dt != SG_BF16 || sg_cfg().fwd_v1 || (s->cin * 2) % 16 != 0 || a.pixel_norm ||
+                 (a.pool == 1 && (sg_cfg().fwd_no_v3 || sg_cfg().fwd_no_v3s)) || (a.pool == 2 && sg_cfg().fwd_no_v5)))
+    return SG_EUNSUPPORTED;
+  if (a.pool == 2) {   // H x W pooling: the streamed kernel's tile (two H rows per wave)
+    bool used = false;
+    rc = launch_fwd5(a, s, hs, &used);
+    if (rc == SG_OK && !used) rc = SG_EUNSUPPORTED;
+    prof.done(rc);
+    return rc;
+  }
   if (!sg_cfg().fwd_no_pw && !a.pool) {   // streaming kernels for the 1x1x1 layers with <= 4 channels on one side
     bool used = false;
     rc = dt == SG_BF16 ? launch_pw_fwd<bf16_t>(a, s, hs, &used) : launch_pw_fwd<float>(a, s, hs, &used);

@@ -188,8 +188,9 @@ def _raw_upconv_subpixel(x, w, coef, bias, act, slope, pixel_norm, eps, want_sca
 def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel_norm=False, eps=1e-8,
              want_scale=False, mask_bits=None, mask_slope=0.0, want_signs=False, pool=False):
     """y = epilogue(conv3d(x, coef*w)) with w in DHWIO; `flip` selects the data-gradient weights.
-    Returns (y, pixel-norm scale or None, sign words of y or None).  pool: y is the 2 x 1 x 2 (D x H x W) block mean of
-    the output, [n,cout,d/2,h,w/2] (sg_conv_epilogue.pool); returns None if no kernel of the build fuses it here."""
+    Returns (y, pixel-norm scale or None, sign words of y or None).  pool (sg_conv_epilogue.pool): 1 -- y is the
+    2 x 1 x 2 (D x H x W) block mean of the output, [n,cout,d/2,h,w/2]; 2 -- the 1 x 2 x 2 block mean, [n,cout,d,h/2,w/2];
+    returns None if no kernel of the build fuses it here."""
     lib = _lib.load()
     _req_cuda(x, w, bias)
     x = ndhwc(x)
@@ -212,9 +213,10 @@ def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel
     dt = _dt(x)
     st = _stream()
     wp = _packed(w, coef, flip, shp, dt, lib, st)
-    if pool and ((d | wd) & 1 or x.dim() != 5):
+    pool = int(pool)
+    if pool and (((d | wd) if pool == 1 else (h | wd)) & 1 or x.dim() != 5):
         return None
-    y = _empty_like_shape(x, cout, (d // 2, h, wd // 2) if pool else (d, h, wd))
+    y = _empty_like_shape(x, cout, {0: (d, h, wd), 1: (d // 2, h, wd // 2), 2: (d, h // 2, wd // 2)}[pool])
     _check_signs(mask_bits, n * d * h * wd, cout)
     signs = _empty_signs(x.device, n, d, h, wd, cout) if want_signs else None
     scale = None
@@ -223,7 +225,7 @@ def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel
     b32 = bias.detach().contiguous().float() if bias is not None else None
     ep = ConvEpilogue(_ptr(b32), 1 if act else 0, float(slope), 1 if pixel_norm else 0, float(eps), _ptr(scale),
                       _ptr(mask_bits), float(mask_slope), _ptr(signs))
-    ep.pool = 1 if pool else 0
+    ep.pool = pool
     ws_bytes = lib.sg_conv3d_fwd_workspace(C.byref(shp), dt)
     if ws_bytes and not pool:      # scratch for the library's two-pass (K-split) path of this layer
         ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
@@ -407,14 +409,14 @@ class _Conv(torch.autograd.Function):
         gx = gw = None
         k = tuple(w.shape[:3]) if w.dim() == 5 else (1, 1, 1)
         if ctx.needs_input_grad[0]:
-            if ctx.x_back is not None and ctx.x_back.all_premask() and not ctx.ups:
+            if ctx.ups:
+                gx = _upconv_dgrad(gy, w, ctx.coef, not ctx.flip)
+            elif ctx.x_back is not None and ctx.x_back.all_premask():
                 gx = _Conv.apply(gy, w, ctx.coef, not ctx.flip, False, None, ctx.x_back.bits, ctx.x_back.slope)
-            elif _masked_in(ctx.in_info) and not ctx.ups:
+            elif _masked_in(ctx.in_info):
                 gx = _Conv.apply(gy, w, ctx.coef, not ctx.flip, False, None, ctx.in_info.bits, ctx.in_info.slope)
             else:
                 gx = _Conv.apply(gy, w, ctx.coef, not ctx.flip, False)
-            if ctx.ups:
-                gx = _Down.apply(gx, 1.0)
         if _wants(ctx, 1, w.data_ptr()):
             if ctx.flip:
                 if ctx.ups:
@@ -488,12 +490,12 @@ class _ConvBiasAct(torch.autograd.Function):
             g, gb = _BiasActBwd.apply(g, signs if signs is not None else y.detach(), slope, want_db)
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            if _masked_in(ctx.in_info) and not ups:
+            if ups:
+                gx = _upconv_dgrad(g, w, coef, True)
+            elif _masked_in(ctx.in_info):
                 gx = _Conv.apply(g, w, coef, True, False, None, ctx.in_info.bits, ctx.in_info.slope)
             else:
                 gx = _Conv.apply(g, w, coef, True, False)
-            if ups:
-                gx = _Down.apply(gx, 1.0)
         db_from_wgrad = want_db and gb is None
         if _wants(ctx, 1, w.data_ptr()):
             k = tuple(w.shape[:3]) if w.dim() == 5 else (1, 1, 1)
@@ -506,6 +508,7 @@ class _ConvBiasAct(torch.autograd.Function):
         return gx, gw, (gb if want_db else None), None, None, None, None, None, None, None, None
 
 
+_NO_LERP_ALIAS = bool(int(os.environ.get('SARAGAN_NO_LERP_ALIAS', '0')))   # diagnostic: alpha = 0 through sg_axpby
 _NO_POOL_FUSION = bool(int(os.environ.get('SARAGAN_NO_POOL_FUSION', '0')))   # diagnostic: conv and downscale3d apart
 
 
@@ -518,11 +521,12 @@ class _ConvBiasActPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, coef, slope, in_info=None):
         _note_all(x, w, b, coef, slope, in_info)
-        res = raw_conv(x, w, coef, False, False, bias=b, act=True, slope=slope, want_signs=True, pool=True)
+        mode = _pool_mode(x, w.shape[:3], x.shape[1], w.shape[-1]) if w.dim() == 5 else 0
+        res = raw_conv(x, w, coef, False, False, bias=b, act=True, slope=slope, want_signs=True, pool=mode) if mode else None
         if res is None:
             raise _lib.SgError('pool fusion not available for this layer')
         ydw, _, signs = res
-        y = _Down.apply(ydw, 0.5, None, (1, 2, 1))
+        y = _Down.apply(ydw, 0.5, None, _POOL_REST[mode])
         ctx.save_for_backward(x, w, signs)
         ctx.cfg = (coef, slope)
         ctx.has_b = b is not None
@@ -550,15 +554,44 @@ class _ConvBiasActPool(torch.autograd.Function):
         return gx, gw, (gb if want_db else None), None, None, None
 
 
+def _pool_mode(x, k, cin, cout):
+    """Which sg_conv_epilogue.pool mode may fuse the 2x2x2 pooling of this convolution's output (0: none), from the
+    shape; the library has the last word (SG_EUNSUPPORTED -> raw_conv returns None)."""
+    if _NO_POOL_FUSION or x.dim() != 5 or x.dtype != torch.bfloat16 or tuple(k) != (3, 3, 3):
+        return 0
+    n, _, d, h, wd = x.shape
+    if (d | h | wd) & 1 or wd % 32:
+        return 0
+    nvox = n * d * h * wd
+    if cin <= 32 and cin % 8 == 0 and cout % 32 == 0 and d >= 4 and nvox >= (1 << 20):
+        return 1        # sliding-halo kernel: D x W pairs in the epilogue
+    if cin % 16 == 0 and cout % 64 == 0 and nvox >= (1 << 18):
+        return 2        # streamed ping-pong kernel: H x W pairs
+    return 0
+
+
+_POOL_REST = {1: (1, 2, 1), 2: (2, 1, 1)}     # the pairs left to sg_downscale_sum after the epilogue's block means
+
+
+def _upconv_dgrad(g, w, coef, flip):
+    """Gradient of conv3d(upscale3d(x)) (pgan/generator.py:33-34) for x: the 2x2x2 block SUM of the data gradient.  When
+    nothing differentiates this backward again, the sliding-halo kernel pools 2 x 1 x 2 in its epilogue
+    (sg_conv_epilogue.pool) and the full-resolution data gradient -- cin x the fine volume -- is never written."""
+    if not torch.is_grad_enabled() and w.dim() == 5:
+        cin, cout = (w.shape[4], w.shape[3]) if flip else (w.shape[3], w.shape[4])
+        mode = _pool_mode(g, w.shape[:3], cin, cout)
+        if mode:
+            res = raw_conv(g, w, coef, flip, False, pool=mode)
+            if res is not None:      # means over four voxels; the remaining pairs and the factor back to a sum follow
+                return _Down.apply(res[0], 4.0, None, _POOL_REST[mode])
+    return _Down.apply(_Conv.apply(g, w, coef, flip, False), 1.0)
+
+
 def pool_fusion_available(x, w, bias, slope):
     """Whether conv3d + bias + LeakyReLU + downscale3d of this layer runs as _ConvBiasActPool (bf16, 3x3x3, <= 32 input
     channels, 32-wide rows, whole 32-channel output tiles: sg_conv_epilogue.pool).  Decided from the shape; the library
     has the last word (SG_EUNSUPPORTED)."""
-    if _NO_POOL_FUSION or x.dim() != 5 or x.dtype != torch.bfloat16 or w.dim() != 5:
-        return False
-    n, cin, d, h, wd = x.shape
-    return (tuple(w.shape[:3]) == (3, 3, 3) and cin <= 32 and cin % 8 == 0 and w.shape[-1] % 32 == 0 and wd % 32 == 0 and
-            d >= 4 and d % 2 == 0 and h % 2 == 0 and n * d * h * wd >= (1 << 20))
+    return w.dim() == 5 and _pool_mode(x, w.shape[:3], x.shape[1] if x.dim() == 5 else 0, w.shape[-1]) != 0
 
 
 class _BiasActBwd(torch.autograd.Function):
@@ -797,6 +830,22 @@ class _Axpby(torch.autograd.Function):
         return ga, gb, None, None
 
 
+class _Select(torch.autograd.Function):
+    """lerp with weights exactly (0, 1): the stabilising half of every phase runs the fade-in graph with alpha = 0
+    (pgan/generator.py:100-101, pgan/discriminator.py:105), where 0*a + 1*b is b bit for bit (finite a).  No pass over
+    the tensors: the output aliases b, b's gradient aliases the incoming one, a's gradient is zeros (the faded-out
+    branch still gets its zero gradients, as tf.gradients gives them)."""
+
+    @staticmethod
+    def forward(ctx, dead, live):
+        _note_all(dead, live)
+        return live.view_as(live)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (torch.zeros_like(g) if ctx.needs_input_grad[0] else None), g
+
+
 class _AddNoise(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, stddev, seed, offset):
@@ -878,6 +927,10 @@ def upscale_trilinear2x(x):
 
 
 def lerp(a, b, wa, wb):
+    if float(wa) == 0.0 and float(wb) == 1.0 and b is not None and not _NO_LERP_ALIAS:
+        if a.shape != b.shape or a.dtype != b.dtype:
+            raise ValueError('lerp operands differ in shape or dtype')
+        return _Select.apply(a, b)
     return _Axpby.apply(a, b, wa, wb)
 
 

@@ -659,3 +659,104 @@ def test_trilinear_up2x_and_adjoint(shape, dtype):
     if all(s % 2 == 0 for s in shape[2:]):
         dn = TF.interpolate(x, scale_factor=0.5, mode='trilinear', align_corners=False)
         close(F.downscale2x(cl(x, dtype)), dn, dtype, 'trilinear down == 2x2x2 mean')
+
+
+def test_upconv_data_gradient_pooled_in_the_conv_epilogue(monkeypatch):
+    """Gradient of conv3d(upscale3d(x)) for x (pgan/generator.py:33-34): the block sum of the data gradient, pooled
+    2 x 1 x 2 inside the sliding-halo kernel when the backward is not differentiated again, against the oracle's
+    autograd and against the unfused product path (conv, then sg_downscale_sum)."""
+    from saragan_amd import functional as F
+    dtype = torch.bfloat16
+    n, cin, cout, sp = 4, 64, 32, (4, 64, 128)           # fine volume 8 x 128 x 256: 2^20 voxels, 512 tile columns
+    x = rnd((n, cin, *sp), 71, dtype)
+    w = rnd((3, 3, 3, cin, cout), 72, dtype)
+    coef = O.runtime_coef(w.shape, 'leaky_relu', 0.2)
+    wq = (w * coef).to(dtype).double() / coef
+    xr = x.clone().requires_grad_(True)
+    yr = O.conv3d(O.upscale3d(xr), wq, 'leaky_relu', 0.2)
+    gy = rnd(tuple(yr.shape), 73, dtype)
+    (gxr,) = torch.autograd.grad(yr, [xr], gy)
+    xg = cl(x, dtype).requires_grad_(True)
+    wg = w.float().to(dev())
+    calls = []
+    real = F.raw_conv
+
+    def spy(*a, **kw):
+        calls.append(bool(kw.get('pool')))
+        return real(*a, **kw)
+    monkeypatch.setattr(F, 'raw_conv', spy)
+    yg = F.conv3d(xg, wg, coef, upsample_in=True)
+    (gxg,) = torch.autograd.grad(yg, [xg], cl(gy, dtype))
+    assert calls[-1] is True, 'the pooled epilogue was not used'
+    _mostly_close(gxg, gxr, 1e-2, 1e-2, 'dx (pooled)')
+    monkeypatch.setattr(F, '_NO_POOL_FUSION', True)
+    yg2 = F.conv3d(xg, wg, coef, upsample_in=True)
+    (gxu,) = torch.autograd.grad(yg2, [xg], cl(gy, dtype))
+    assert calls[-1] is False
+    _mostly_close(gxu, gxr, 1e-2, 1e-2, 'dx (unfused)')
+    # differentiated again (create_graph): the unfused, differentiable path
+    monkeypatch.setattr(F, '_NO_POOL_FUSION', False)
+    yg3 = F.conv3d(xg, wg, coef, upsample_in=True)
+    (gxd,) = torch.autograd.grad(yg3, [xg], cl(gy, dtype).requires_grad_(True), create_graph=True)
+    assert calls[-1] is False and gxd.requires_grad
+    _mostly_close(gxd, gxr, 1e-2, 1e-2, 'dx (create_graph)')
+
+
+@pytest.mark.parametrize('dtype', DT)
+def test_lerp_with_alpha_zero_is_an_alias(dtype):
+    """alpha = 0 (the stabilising half of a phase): lerp returns b bit for bit without a pass, the faded-out operand
+    gets zeros, the live one the incoming gradient (pgan/generator.py:100-101, pgan/discriminator.py:105)."""
+    from saragan_amd import functional as F
+    a = cl(rnd((2, 8, 3, 4, 5), 81, dtype), dtype).requires_grad_(True)
+    b = cl(rnd((2, 8, 3, 4, 5), 82, dtype), dtype).requires_grad_(True)
+    g = cl(rnd((2, 8, 3, 4, 5), 83, dtype), dtype)
+    out = F.lerp(a, b * 1.0, 0.0, 1.0)
+    ref = F._Axpby.apply(a, b, 0.0, 1.0)
+    assert torch.equal(out, ref) and torch.equal(out, b)
+    ga, gb = torch.autograd.grad(out, [a, b], g)
+    assert torch.equal(gb, g) and float(ga.abs().max()) == 0.0 and ga.shape == a.shape
+    # any other weight pair goes through sg_axpby
+    out2 = F.lerp(a, b, 0.25, 0.75)
+    close(out2, 0.25 * a.double() + 0.75 * b.double(), dtype, 'lerp')
+
+
+def test_conv_epilogue_fused_downscale_hw_pairs():
+    """The same fusion for layers with more than 32 input channels (pgan/discriminator.py:33-44 at the lower
+    resolutions): the streamed kernel pools H x W pairs (sg_conv_epilogue.pool = 2), sg_downscale_sum(2,1,1) the D pairs."""
+    from saragan_amd import functional as F
+    dtype = torch.bfloat16
+    n, cin, cout, sp = 2, 48, 64, (8, 128, 128)
+    x = rnd((n, cin, *sp), 91, dtype)
+    w = rnd((3, 3, 3, cin, cout), 92, dtype)
+    b = rnd((cout,), 93, torch.float32) * 0.3
+    coef = O.runtime_coef(w.shape, 'leaky_relu', 0.2)
+    wq = (w * coef).to(dtype).double() / coef
+    xr = x.clone().requires_grad_(True)
+    wr = wq.clone().requires_grad_(True)
+    br = b.double().clone().requires_grad_(True)
+    yr = O.downscale3d(O.act(O.apply_bias(O.conv3d(xr, wr, 'leaky_relu', 0.2), br), 'leaky_relu', 0.2))
+    xg = cl(x, dtype).requires_grad_(True)
+    wg = w.float().to(dev()).requires_grad_(True)
+    bg = b.float().to(dev()).requires_grad_(True)
+    assert F._pool_mode(xg, w.shape[:3], cin, cout) == 2
+    res = F.raw_conv(xg.detach(), wg.detach(), coef, False, bias=bg.detach(), act=True, want_signs=True, pool=2)
+    assert res is not None and tuple(res[0].shape) == (n, cout, 8, 64, 64), 'the H x W pooled epilogue did not engage'
+    full, _, signs_full = F.raw_conv(xg.detach(), wg.detach(), coef, False, bias=bg.detach(), act=True, want_signs=True)
+    assert torch.equal(res[2], signs_full), 'sign words of the pooled launch differ from the plain one'
+    yg = F.conv3d_act_pool(xg, wg, coef, bg, 0.2)
+    assert tuple(yg.shape) == (n, cout, 4, 64, 64)
+    close(yg, yr, dtype, 'fused conv + bias + lrelu + downscale (H x W pairs)')
+    gy = rnd(tuple(yr.shape), 94, dtype)
+    gxr, gwr, gbr = torch.autograd.grad(yr, [xr, wr, br], gy)
+    gxg, gwg, gbg = torch.autograd.grad(yg, [xg, wg, bg], cl(gy, dtype))
+    _mostly_close(gxg, gxr, 1e-2, 1e-2, 'dx')
+    _mostly_close(gwg, gwr, 2e-3, 4e-3, 'dw')
+    _mostly_close(gbg, gbr, 2e-3, 4e-3, 'db')
+    # ragged extent in W (even, not a multiple of 32) and odd D: still whole H x W blocks
+    x2 = cl(rnd((4, 64, 5, 64, 96), 95, dtype), dtype)
+    w2 = rnd((3, 3, 3, 64, 128), 96, dtype).float().to(dev())
+    r2 = F.raw_conv(x2, w2, 0.05, False, pool=2)
+    assert r2 is not None
+    f2 = F.raw_conv(x2, w2, 0.05, False)[0].float()
+    ref2 = torch.nn.functional.avg_pool3d(f2, (1, 2, 2))
+    assert float((r2[0].float() - ref2).abs().max()) <= 1e-2 * float(ref2.abs().max())

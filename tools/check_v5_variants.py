@@ -68,6 +68,24 @@ def main():
             if worst > 2e-2 or (not engaged and 'pn' not in name and cin % 16 == 0 and cout % 64 == 0):
                 ok = False
                 print('   ** MISMATCH / not engaged')
+        # H x W pooled epilogue (sg_conv_epilogue.pool = 2) against the block mean of the plain launch
+        if (sp[1] | sp[2]) % 2 == 0:
+            for name, kw in {'pool': dict(), 'pool+bias+act+signs': dict(bias=b, act=True, want_signs=True)}.items():
+                os.environ['SG_FWD_NO_V5'] = '0'
+                lib.sg_config_reload()
+                res = F.raw_conv(x, w, coef, False, pool=2, **kw)
+                full = F.raw_conv(x, w, coef, False, **kw)
+                if res is None:
+                    print(f'n{n} {cin}->{cout} {sp} {name}: not fused  ** FAILED')
+                    ok = False
+                    continue
+                ref = torch.nn.functional.avg_pool3d(full[0].float(), (1, 2, 2))
+                d = float((res[0].float() - ref).abs().max() / ref.abs().max())
+                sg = 0.0 if res[2] is None else float((res[2] != full[2]).float().mean())
+                print(f'n{n} {cin}->{cout} {sp} {name}: err {d:.2e}; signs differ {sg:.1e}')
+                if not d <= 1e-2 or sg > 0:
+                    ok = False
+                    print('   ** MISMATCH')
     os.environ['SG_FWD_NO_V5'] = '0'
     lib.sg_config_reload()
     print('OK' if ok else 'FAILED')

@@ -96,6 +96,11 @@ typedef struct {
    * entry).  NULL: such layers run as one pass of the streamed kernel.  sg_conv3d_fwd_workspace() gives the size. */
   void* workspace;
   size_t workspace_bytes;
+  /* 0: x is one NDHWC tensor of cin channels.  32: x is cin / 32 separate NDHWC tensors of 32 channels each, one after
+   * the other (what sg_upscale_nn_planes writes).  The two passes of a 64 -> 32 layer (see workspace) then read whole
+   * 64-byte rows instead of one half of every 128-byte row -- a half row costs the whole line from HBM.  Only that
+   * path reads the layout: anything else returns SG_EUNSUPPORTED. */
+  int32_t x_plane_channels;
 } sg_conv_epilogue;
 
 /* Sign words of an NDHWC tensor t[nvox][c]: uint32 words[nvox][ceil(c/32)], bit j of word (v, k) = (t[v][32k+j] < 0),
@@ -168,9 +173,14 @@ int sg_downscale2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int3
 /* The same two operations with a factor of 1 or 2 PER DIMENSION (fd, fh, fw): (1,2,2) are upscale2d / downscale2d of the
  * 2-D tree on D == 1 tensors (SURFGAN_2D/networks/ops.py:176-231); (1,2,1) finishes a D x W-pooled convolution output.
  * sg_upscale_nn: x [n,d,h,w,c] -> y [n,d*fd,h*fh,w*fw,c], optional sign-word mask of a tensor shaped like y.
+ * sg_upscale_nn_planes: the same values, y written as c / plane_channels separate NDHWC tensors of plane_channels
+ * channels each, back to back (sg_conv_epilogue.x_plane_channels; 16-byte channel pieces, rows of >= 128 pieces).
  * sg_downscale_sum: x [n,d,h,w,c] (INPUT extent, divisible by the factors) -> y [n,d/fd,h/fh,w/fw,c] = gain * block sum. */
 int sg_upscale_nn(const void* x, void* y, const void* mask_bits, float mask_slope, int32_t n, int32_t d, int32_t h,
                   int32_t w, int32_t c, int32_t fd, int32_t fh, int32_t fw, float gain, sg_dtype dt, sg_stream_t st);
+int sg_upscale_nn_planes(const void* x, void* y, const void* mask_bits, float mask_slope, int32_t n, int32_t d, int32_t h,
+                         int32_t w, int32_t c, int32_t fd, int32_t fh, int32_t fw, float gain, int32_t plane_channels,
+                         sg_dtype dt, sg_stream_t st);
 int sg_downscale_sum(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c, int32_t fd,
                      int32_t fh, int32_t fw, float gain, sg_dtype dt, sg_stream_t st);
 /* The same over M * x, M = where(sign bit, mask_slope, 1) from sign words shaped like x [n*d*h*w][ceil(c/32)]: the

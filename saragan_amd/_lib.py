@@ -24,7 +24,7 @@ class ConvEpilogue(C.Structure):
                 ('eps', C.c_float), ('pn_scale', C.c_void_p), ('mask_bits', C.c_void_p), ('mask_slope', C.c_float),
                 ('sign_out', C.c_void_p), ('out_scale', C.c_int32), ('out_off', C.c_int32 * 3),
                 ('tap_off', C.c_int32 * 3), ('pool', C.c_int32), ('workspace', C.c_void_p),
-                ('workspace_bytes', C.c_size_t)]
+                ('workspace_bytes', C.c_size_t), ('x_plane_channels', C.c_int32)]
 
     def __init__(self, *args, **kw):
         super().__init__(C.sizeof(type(self)), *args, **kw)
@@ -62,6 +62,7 @@ SIGNATURES = {
     'sg_upscale2x_masked': (C.c_int, [_p, _p, _p, _f, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
     'sg_downscale2x': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
     'sg_upscale_nn': (C.c_int, [_p, _p, _p, _f, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
+    'sg_upscale_nn_planes': (C.c_int, [_p, _p, _p, _f, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _i32, C.c_int, _p]),
     'sg_downscale_sum': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
     'sg_downscale_sum_masked': (C.c_int, [_p, _p, _f, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
     'sg_trilinear_up2x': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, C.c_int, _p]),

@@ -2804,6 +2804,11 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     if (rc != SG_OK || used) { prof.done(rc); return rc; }
   }
   const bool v2 = ((s->cin * es) % 16 == 0) && !sg_cfg().fwd_v1;
+  const int xpl = ep ? ep->x_plane_channels : 0;      // x as separate 32-channel tensors: the K-split path only
+  if (xpl != 0 && (xpl != 32 || s->upsample_in || a.pool || !(v2 && !sg_cfg().fwd_no_v3 && (!a.pixel_norm || a.ntile == 1)))) {
+    prof.done(xpl != 32 ? SG_EINVAL : SG_EUNSUPPORTED);
+    return xpl != 32 ? SG_EINVAL : SG_EUNSUPPORTED;
+  }
   if (v2 && !sg_cfg().fwd_no_v3 && (!a.pixel_norm || a.ntile == 1)) {
     bool used = false;
     rc = SG_OK;
@@ -2822,6 +2827,11 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
       p1.xco = 0; p1.y = ep->workspace; p1.bias = nullptr; p1.act = 0; p1.mask_bits = nullptr; p1.sign_out = nullptr;
       p1.pixel_norm = 0; p1.pn_scale = nullptr;
       p2.xco = 32; p2.addend = reinterpret_cast<const float*>(ep->workspace);
+      if (xpl) {   // the halves are two tensors of 32 channels: whole rows
+        p1.xcs = p2.xcs = 32;
+        p2.xco = 0;
+        p2.x = reinterpret_cast<const char*>(a.x) + (size_t)s->n * s->d * s->h * s->w * 64;
+      }
       p2.wp = reinterpret_cast<const char*>(a.wp) + (size_t)2 * a.taps * a.ntile * 1024;   // chunks 2, 3 of the packed image
       bool u1 = false, u2 = false;
       rc = launch_fwd3s<2, 1>(p1, &sh, hs, &u1);
@@ -2834,6 +2844,7 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
       }
       if (rc != SG_OK) { prof.done(rc); return rc; }
     }
+    if (xpl) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }
     if (dt == SG_BF16 && k333 && !sg_cfg().fwd_no_v3s) {   // sliding-halo variant where its tile fits
       if (a.nchunk == 2) rc = launch_fwd3s<2>(a, s, hs, &used);
       else if (a.nchunk == 1) rc = launch_fwd3s<1>(a, s, hs, &used);

@@ -424,9 +424,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void upscale2x_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int d, int h, int w,
                                                              int c, int sd, int sh, int sw, float gain,
                                                              const uint32_t* __restrict__ mask_bits, float mask_slope,
-                                                             int64_t nrows) {
+                                                             int64_t nrows, int pc, int64_t plane_stride) {
+  // pc < c: y is written as c / pc separate NDHWC tensors of pc channels each, plane_stride elements apart
+  // (sg_upscale_nn_planes); pc == c: the ordinary layout
   constexpr int E = Piece<T>::E;
-  const int P = c / E, nw = (c + 31) >> 5;
+  const int P = c / E, nw = (c + 31) >> 5, PP = pc / E;
   const int OD = d << sd, OH = h << sh, OW = w << sw;
   const int per_row = OW * P;
   for (int64_t row = blockIdx.x; row < nrows; row += gridDim.x) {
@@ -435,12 +437,12 @@ __global__ __launch_bounds__(256) void upscale2x_rows_kernel(const T* __restrict
     const int od = (int)(q % OD);
     const int64_t nn = q / OD;
     const T* xrow = x + (((nn * d + (od >> sd)) * h + (oh >> sh)) * (int64_t)w) * c;
-    T* yrow = y + row * (int64_t)OW * c;
+    T* yrow = y + row * (int64_t)OW * pc;
     const uint32_t* mrow = mask_bits ? mask_bits + row * (int64_t)OW * nw : nullptr;
     // four pieces per thread and trip, every load issued before the first store (a 128-voxel row of 64 channels is
     // exactly one trip): one piece per trip left the kernel at 3.7 of 6.3 TB/s
     for (int i0 = threadIdx.x; i0 < per_row; i0 += 256 * 4) {
-      Piece<T> pc[4];
+      Piece<T> pcs[4];
       uint32_t sg[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(256) void upscale2x_rows_kernel(const T* __restrict
         sg[j] = 0u;
         if (i < per_row) {
           const int ow = i / P, p = i - ow * P;
-          pc[j].load(xrow + (int64_t)(ow >> sw) * c + p * E);
+          pcs[j].load(xrow + (int64_t)(ow >> sw) * c + p * E);
           if (mrow) sg[j] = mrow[ow * nw + ((p * E) >> 5)] >> ((p * E) & 31);
         }
       }
@@ -458,10 +460,11 @@ __global__ __launch_bounds__(256) void upscale2x_rows_kernel(const T* __restrict
         if (i < per_row) {
 #pragma unroll
           for (int e = 0; e < E; ++e) {
-            const float v = pc[j].v[e] * gain;
-            pc[j].v[e] = ((sg[j] >> e) & 1u) ? v * mask_slope : v;
+            const float v = pcs[j].v[e] * gain;
+            pcs[j].v[e] = ((sg[j] >> e) & 1u) ? v * mask_slope : v;
           }
-          pc[j].store_nt(yrow + (int64_t)i * E);
+          const int ow = i / P, p = i - ow * P, pl = p / PP;
+          pcs[j].store_nt(yrow + pl * plane_stride + (int64_t)ow * pc + (p - pl * PP) * E);
         }
       }
     }
@@ -978,23 +981,27 @@ extern "C" int sg_pixel_norm_act_bwd(const void* dy, const void* y, const float*
 
 static int sg_factor_shift(int32_t f) { return f == 1 ? 0 : (f == 2 ? 1 : -1); }
 
-extern "C" int sg_upscale_nn(const void* x, void* y, const void* mask_bits, float mask_slope, int32_t n, int32_t d,
-                             int32_t h, int32_t w, int32_t c, int32_t fd, int32_t fh, int32_t fw, float gain,
-                             sg_dtype dt, sg_stream_t st) {
+static int upscale_nn_impl(const void* x, void* y, const void* mask_bits, float mask_slope, int32_t n, int32_t d,
+                           int32_t h, int32_t w, int32_t c, int32_t fd, int32_t fh, int32_t fw, float gain,
+                           int32_t plane_channels, sg_dtype dt, sg_stream_t st) {
   const int sd = sg_factor_shift(fd), sh = sg_factor_shift(fh), sw = sg_factor_shift(fw);
   if (!x || !y || n < 1 || d < 1 || h < 1 || w < 1 || c < 1 || sd < 0 || sh < 0 || sw < 0) return SG_EINVAL;
   hipStream_t hs = sg_st(st);
   const int E = dt == SG_BF16 ? 8 : 4;
   const bool vec = (c % E == 0) && sg_aligned16(x) && sg_aligned16(y);
+  const bool planes = plane_channels != c;
+  if (planes && (plane_channels < E || plane_channels % E != 0 || c % plane_channels != 0)) return SG_EINVAL;
   if (vec && (w << sw) * (c / E) >= 128) {   // enough pieces per output row to fill a block
     const int64_t nrows = (int64_t)n * (d << sd) * (h << sh);
     const int rb = (int)(nrows < 16384 ? nrows : 16384);
-#define LR(T) hipLaunchKernelGGL((upscale2x_rows_kernel<T>), dim3(rb), dim3(256), 0, hs, (const T*)x, (T*)y, d, h, w, c, sd, sh, sw, gain, (const uint32_t*)mask_bits, mask_slope, nrows)
+    const int64_t plane_stride = nrows * (w << sw) * plane_channels;
+#define LR(T) hipLaunchKernelGGL((upscale2x_rows_kernel<T>), dim3(rb), dim3(256), 0, hs, (const T*)x, (T*)y, d, h, w, c, sd, sh, sw, gain, (const uint32_t*)mask_bits, mask_slope, nrows, (int)plane_channels, plane_stride)
     SG_DISPATCH(dt, LR(bf16_t), LR(float));
 #undef LR
     SG_LAUNCH_CHECK();
     return SG_OK;
   }
+  if (planes) return SG_EUNSUPPORTED;   // only the row-wise kernel writes separate planes
   const int64_t items = (int64_t)n * (d << sd) * (h << sh) * (w << sw) * (vec ? c / E : c);
   const int blocks = grid_for(items, 256, 4096);
 #define L(T, V) hipLaunchKernelGGL((upscale2x_kernel<T, V>), dim3(blocks), dim3(256), 0, hs, (const T*)x, (T*)y, n, d, h, w, c, sd, sh, sw, gain, (const uint32_t*)mask_bits, mask_slope)
@@ -1003,6 +1010,18 @@ extern "C" int sg_upscale_nn(const void* x, void* y, const void* mask_bits, floa
 #undef L
   SG_LAUNCH_CHECK();
   return SG_OK;
+}
+
+extern "C" int sg_upscale_nn(const void* x, void* y, const void* mask_bits, float mask_slope, int32_t n, int32_t d,
+                             int32_t h, int32_t w, int32_t c, int32_t fd, int32_t fh, int32_t fw, float gain,
+                             sg_dtype dt, sg_stream_t st) {
+  return upscale_nn_impl(x, y, mask_bits, mask_slope, n, d, h, w, c, fd, fh, fw, gain, c, dt, st);
+}
+
+extern "C" int sg_upscale_nn_planes(const void* x, void* y, const void* mask_bits, float mask_slope, int32_t n, int32_t d,
+                                    int32_t h, int32_t w, int32_t c, int32_t fd, int32_t fh, int32_t fw, float gain,
+                                    int32_t plane_channels, sg_dtype dt, sg_stream_t st) {
+  return upscale_nn_impl(x, y, mask_bits, mask_slope, n, d, h, w, c, fd, fh, fw, gain, plane_channels, dt, st);
 }
 
 extern "C" int sg_upscale2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,

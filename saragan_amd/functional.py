@@ -538,6 +538,12 @@ class _ConvBiasActPool(torch.autograd.Function):
     def backward(ctx, gy):
         x, w, signs = ctx.saved_tensors
         coef, slope = ctx.cfg
+        want_db = ctx.has_b and _wants(ctx, 2, ctx.b_ptr)
+        if not torch.is_grad_enabled() and not _NO_PLANES:
+            res = _pooled_backward_planes(gy, x, w, signs, coef, slope, ctx.in_info, ctx.needs_input_grad[0],
+                                          _wants(ctx, 1, w.data_ptr()), want_db)
+            if res is not None:
+                return res[0], res[1], (res[2] if want_db else None), None, None, None
         g = _Up.apply(gy, 0.125, signs, slope, (2, 2, 2))      # d(downscale3d) * LeakyReLU mask, full resolution
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
@@ -545,13 +551,68 @@ class _ConvBiasActPool(torch.autograd.Function):
                 gx = _Conv.apply(g, w, coef, True, False, None, ctx.in_info.bits, ctx.in_info.slope)
             else:
                 gx = _Conv.apply(g, w, coef, True, False)
-        want_db = ctx.has_b and _wants(ctx, 2, ctx.b_ptr)
         if _wants(ctx, 1, w.data_ptr()):
             gw, gb = _Wgrad.apply(x, g, tuple(w.shape[:3]), coef, False, want_db)
             gw = gw.reshape(w.shape)
         elif want_db:
             _, gb = raw_bias_act_bwd(g, None, 0.0, want_dx=False, want_db=True)
         return gx, gw, (gb if want_db else None), None, None, None
+
+
+_NO_PLANES = bool(int(os.environ.get('SARAGAN_NO_PLANES', '0')))   # diagnostic: the 64-channel gradient as one tensor
+
+
+def _pooled_backward_planes(gy, x, w, signs, coef, slope, in_info, want_gx, want_gw, want_db):
+    """Backward of _ConvBiasActPool for a 64-channel layer when nothing differentiates it again: the masked, up-scaled
+    gradient (64 channels at full resolution, the largest tensor of the backward pass) is written as two 32-channel
+    tensors (sg_upscale_nn_planes).  The data gradient -- a 64 -> 32 convolution, two passes over 32 input channels each
+    with f32 partial sums -- then reads whole 64-byte rows (sg_conv_epilogue.x_plane_channels) where the interleaved
+    layout made it fetch every 128-byte line twice, and the weight gradient is one 32-channel launch per tensor.
+    Returns (gx, gw, gb) or None when the layer is not of that shape / the library declines."""
+    if gy.dtype != torch.bfloat16 or w.dim() != 5 or tuple(w.shape[:3]) != (3, 3, 3) or w.shape[4] != 64 or w.shape[3] != 32:
+        return None
+    lib = _lib.load()
+    gy = ndhwc(gy)
+    n, cout, dc, hc, wc = _dims(gy)
+    d, h, wd = 2 * dc, 2 * hc, 2 * wc
+    dt, st = _dt(gy), _stream()
+    k = (3, 3, 3)
+    shp = _shape(n, d, h, wd, 64, 32, k, False)
+    ws_bytes = lib.sg_conv3d_fwd_workspace(C.byref(shp), dt)
+    if not ws_bytes or signs is None:
+        return None
+    _check_signs(signs, n * d * h * wd, 64)
+    planes = torch.empty((2, n, d, h, wd, 32), device=gy.device, dtype=gy.dtype)
+    rc = lib.sg_upscale_nn_planes(_ptr(gy), _ptr(planes), _ptr(signs), float(slope), n, dc, hc, wc, 64, 2, 2, 2, 0.125, 32,
+                                  dt, st)
+    if rc == _lib.SG_EUNSUPPORTED:
+        return None
+    check(rc, 'sg_upscale_nn_planes')
+    gx = gw = gb = None
+    if want_gx:
+        wp = _packed(w, coef, True, shp, dt, lib, st)
+        gx = _empty_like_shape(gy, 32, (d, h, wd))
+        masked = _masked_in(in_info)
+        ep = ConvEpilogue(None, 0, 0.0, 0, 1e-8, None, _ptr(in_info.bits) if masked else None,
+                          float(in_info.slope) if masked else 0.0, None)
+        if masked:
+            _check_signs(in_info.bits, n * d * h * wd, 32)
+        ws = torch.empty(ws_bytes, device=gy.device, dtype=torch.uint8)
+        ep.workspace, ep.workspace_bytes, ep.x_plane_channels = ws.data_ptr(), ws_bytes, 32
+        rc = lib.sg_conv3d_fwd(_ptr(planes), _ptr(wp), _ptr(gx), C.byref(shp), C.byref(ep), dt, st)
+        if rc == _lib.SG_EUNSUPPORTED:
+            return None
+        check(rc, 'sg_conv3d_fwd (planes)')
+    if want_gw or want_db:
+        halves = [planes[i].permute(0, 4, 1, 2, 3) for i in range(2)]       # [n,32,d,h,w], channels last
+        if want_gw:
+            parts = [raw_wgrad(x, g, k, coef, False, want_db) for g in halves]
+            gw = torch.cat([p[0] for p in parts], dim=4).reshape(w.shape)
+            if want_db:
+                gb = torch.cat([p[1] for p in parts])
+        else:
+            gb = torch.cat([raw_bias_act_bwd(g, None, 0.0, want_dx=False, want_db=True)[1] for g in halves])
+    return gx, gw, gb
 
 
 def _pool_mode(x, k, cin, cout):

@@ -465,7 +465,7 @@ def _mostly_close(got, ref, rt, at_scale, what, max_bad=1e-3):
     assert float(err.max()) <= 20 * at_scale * scale + 1e-12, (what, float(err.max()), scale)
 
 
-def test_conv_epilogue_fused_downscale():
+def test_conv_epilogue_fused_downscale(monkeypatch):
     """downscale3d(leaky_relu(conv3d(x) + b)) with the pooling fused into the sliding-halo kernel's epilogue
     (sg_conv_epilogue.pool + sg_downscale_sum(1,2,1)) against O.downscale3d(O.act(...)): forward, first-order gradients
     and the gradient-penalty style second-order gradient (pgan/discriminator.py:33-44, loss.py:133-140)."""
@@ -502,6 +502,22 @@ def test_conv_epilogue_fused_downscale():
     _mostly_close(g2g, g2r, 2e-2, 2e-2, 'second-order dw', max_bad=5e-3)
     # requests no kernel fuses (f32 storage) are refused, not mis-computed
     assert F.raw_conv(xg.float(), wg, coef, False, bias=bg, act=True, want_signs=True, pool=True) is None
+    # a backward nothing differentiates again writes the up-scaled 64-channel gradient as two 32-channel tensors
+    # (sg_upscale_nn_planes, sg_conv_epilogue.x_plane_channels): same gradients, bit for bit the same data gradient
+    took = []
+    real = F._pooled_backward_planes
+
+    def spy(*a, **kw):
+        r = real(*a, **kw)
+        took.append(r is not None)
+        return r
+    monkeypatch.setattr(F, '_pooled_backward_planes', spy)
+    yp = F.conv3d_act_pool(xg, wg, coef, bg, 0.2)
+    gxp, gwp, gbp = torch.autograd.grad(yp, [xg, wg, bg], cl(gy, dtype))
+    assert took == [True], 'the two-tensor layout was not used'
+    assert torch.equal(gxp, gxg.detach()), 'data gradient differs between the layouts'
+    _mostly_close(gwp, gwr, 2e-3, 4e-3, 'dw (planes)')
+    _mostly_close(gbp, gbr, 2e-3, 4e-3, 'db (planes)')
 
 
 @pytest.mark.parametrize('dtype', DT)

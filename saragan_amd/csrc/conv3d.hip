@@ -2525,50 +2525,74 @@ __device__ __forceinline__ float sg_packed_w(const char* wp, int ntile, int cin_
   return sg_traits<T>::to_f(*reinterpret_cast<const T*>(frag + ((cout_c & 31) + 32 * hh) * 16 + e * ES));
 }
 
-// cin <= 4: y[v][c] = epilogue(sum_j x[v][j] * w[j][c] + b[c]); thread owns one 16-byte piece of couts (fixed)
-template <typename T>
+// cin <= 4: y[v][c] = epilogue(sum_j x[v][j] * w[j][c] + b[c]); thread owns one 16-byte piece of couts (fixed).
+// The stream is write-dominated (cout x the input bytes), so what matters is that nothing sits between two stores:
+// CIN is a template parameter (no per-channel branches around the loads), loads are clamped instead of predicated,
+// the next trip's input and mask word are requested before this trip's arithmetic, and the sign word of a 32-channel
+// group is assembled by DPP exchanges within the quad instead of LDS shuffles.
+template <typename T, int CIN>
 __global__ __launch_bounds__(256) void pw_fwd_small_cin_kernel(ConvFwdArgs a, int64_t nvox) {
   constexpr int E = 16 / (int)sizeof(T);
   const int P = a.cout / E;                     // pieces per voxel, divides 256
   const int p = threadIdx.x % P;
   const int c0 = p * E;
   const char* wp = reinterpret_cast<const char*>(a.wp);
-  float w[4][E], b[E];
+  float w[CIN][E], b[E];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < CIN; ++j)
 #pragma unroll
-    for (int e = 0; e < E; ++e) w[j][e] = j < a.cin ? sg_packed_w<T>(wp, a.ntile, j, c0 + e) : 0.f;
+    for (int e = 0; e < E; ++e) w[j][e] = sg_packed_w<T>(wp, a.ntile, j, c0 + e);
 #pragma unroll
   for (int e = 0; e < E; ++e) b[e] = a.bias ? a.bias[c0 + e] : 0.f;
   const T* x = reinterpret_cast<const T*>(a.x);
   T* y = reinterpret_cast<T*>(a.y);
   const int rows = 256 / P;
   const int tpw = P < 32 / E ? P : 32 / E;      // threads per 32-channel sign word (adjacent lanes; powers of two)
-  const int64_t nv_pad = (nvox + rows - 1) / rows * rows;   // whole waves stay in the loop for the shuffles
-  for (int64_t v = (int64_t)blockIdx.x * rows + threadIdx.x / P; v < nv_pad; v += (int64_t)gridDim.x * rows) {
-    const bool live = v < nvox;
-    float xv[4];
+  const int64_t nv_pad = (nvox + rows - 1) / rows * rows;   // whole waves stay in the loop for the exchanges
+  const int64_t stride = (int64_t)gridDim.x * rows;
+  const float slope = a.act ? a.slope : 1.f;    // max(t, 1 * t) = t
+  const bool masked = a.mask_bits != nullptr, signs = a.sign_out != nullptr;
+  const int wsel = c0 >> 5, wsh = c0 & 31, psh = (p % tpw) * E;
+  auto fetch = [&](int64_t v, float (&xv)[CIN], uint32_t& mw) {
+    const int64_t vc = v < nvox ? v : nvox - 1;               // clamped: dead lanes read the last voxel, store nothing
 #pragma unroll
-    for (int j = 0; j < 4; ++j) xv[j] = (live && j < a.cin) ? sg_traits<T>::to_f(x[v * a.cin + j]) : 0.f;
+    for (int j = 0; j < CIN; ++j) xv[j] = sg_traits<T>::to_f(x[vc * CIN + j]);
+    mw = masked ? a.mask_bits[vc * a.ntile + wsel] >> wsh : 0u;
+  };
+  int64_t v = (int64_t)blockIdx.x * rows + threadIdx.x / P;
+  float xn[CIN];
+  uint32_t mwn = 0u;
+  if (v < nv_pad) fetch(v, xn, mwn);
+  for (; v < nv_pad; v += stride) {
+    float xv[CIN];
+#pragma unroll
+    for (int j = 0; j < CIN; ++j) xv[j] = xn[j];
+    const uint32_t mw = mwn;
+    if (v + stride < nv_pad) fetch(v + stride, xn, mwn);
+    const bool live = v < nvox;
     float o[E];
     uint32_t neg = 0u;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       float t = b[e];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) t = fmaf(xv[j], w[j][e], t);
-      if (a.act) t = fmaxf(t, t * a.slope);
+      for (int j = 0; j < CIN; ++j) t = fmaf(xv[j], w[j][e], t);
+      t = fmaxf(t, t * slope);
       neg |= (t < 0.f ? 1u : 0u) << e;
       o[e] = t;
     }
-    if (a.sign_out != nullptr) {                // the TPW threads of a word are adjacent lanes
-      uint32_t wbits = neg << ((p % tpw) * E);
-      for (int sh = 1; sh < tpw; sh <<= 1) wbits |= (uint32_t)__shfl_xor((int)wbits, sh);
-      if (live && p % tpw == 0) a.sign_out[v * a.ntile + (c0 >> 5)] = wbits;
+    if (signs) {                                // the TPW threads of a word are adjacent lanes
+      uint32_t wbits = neg << psh;
+      if (tpw == 4) {
+        wbits |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wbits, 0xB1, 0xF, 0xF, true);   // lane ^ 1
+        wbits |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wbits, 0x4E, 0xF, 0xF, true);   // lane ^ 2
+      } else {
+        for (int sh = 1; sh < tpw; sh <<= 1) wbits |= (uint32_t)__shfl_xor((int)wbits, sh);
+      }
+      if (live && p % tpw == 0) a.sign_out[v * a.ntile + wsel] = wbits;
     }
     if (!live) continue;
-    if (a.mask_bits != nullptr) {
-      const uint32_t mw = a.mask_bits[v * a.ntile + (c0 >> 5)] >> (c0 & 31);
+    if (masked) {
 #pragma unroll
       for (int e = 0; e < E; ++e) o[e] = ((mw >> e) & 1u) ? o[e] * a.mask_slope : o[e];
     }
@@ -2597,11 +2621,27 @@ __global__ __launch_bounds__(256) void pw_fwd_small_cout_kernel(ConvFwdArgs a, i
   T* y = reinterpret_cast<T*>(a.y);
   const int rows = 256 / P;
   const int64_t nv_pad = (nvox + rows - 1) / rows * rows;   // whole waves stay in the loop for the shuffles
-  for (int64_t v = (int64_t)blockIdx.x * rows + threadIdx.x / P; v < nv_pad; v += (int64_t)gridDim.x * rows) {
+  // four ADJACENT voxel groups per block and trip, every load issued before the first reduction (one 16-byte load per
+  // lane and trip: 4.9 TB/s; four groups a grid stride apart: slower than one)
+  constexpr int U = 4;
+  const int64_t nv_pad4 = (nvox + U * rows - 1) / (U * rows) * (U * rows);
+  for (int64_t vb = (int64_t)blockIdx.x * U * rows + threadIdx.x / P; vb < nv_pad4; vb += (int64_t)gridDim.x * U * rows) {
+    u32x4 rawu[U];
+    uint32_t mwu[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t v = vb + u * rows;
+      rawu[u] = v < nvox ? *reinterpret_cast<const u32x4*>(x + v * a.cin + p * E) : u32x4{0u, 0u, 0u, 0u};
+      mwu[u] = (v < nvox && p == 0 && a.mask_bits) ? a.mask_bits[v] : 0u;   // cout <= 4: one word per voxel
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+    const int64_t v = vb + u * rows;
+    if (v >= nv_pad) break;                     // uniform per block: nv_pad is a multiple of the block's rows
     const bool live = v < nvox;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    if (live) {
-      u32x4 raw = *reinterpret_cast<const u32x4*>(x + v * a.cin + p * E);
+    {
+      const u32x4 raw = rawu[u];
       const T* t = reinterpret_cast<const T*>(&raw);
 #pragma unroll
       for (int e = 0; e < E; ++e) {
@@ -2615,7 +2655,7 @@ __global__ __launch_bounds__(256) void pw_fwd_small_cout_kernel(ConvFwdArgs a, i
       for (int c = 0; c < 4; ++c) s[c] += __shfl_xor(s[c], sh);
     if (live && p == 0) {
       uint32_t neg = 0u;
-      const uint32_t mw = a.mask_bits ? a.mask_bits[v] : 0u;   // cout <= 4: one word per voxel
+      const uint32_t mw = mwu[u];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         if (c < a.cout) {
@@ -2627,6 +2667,7 @@ __global__ __launch_bounds__(256) void pw_fwd_small_cout_kernel(ConvFwdArgs a, i
         }
       }
       if (a.sign_out != nullptr) a.sign_out[v] = neg;
+    }
     }
   }
 }
@@ -2714,7 +2755,12 @@ static int launch_pw_fwd(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st,
     int64_t nb = (nvox + rows - 1) / rows;
     if (nb > 8192) nb = 8192;
     SG_KNAME("pw_fwd_small_cin<%s>", sg_tname<T>());
-    hipLaunchKernelGGL(pw_fwd_small_cin_kernel<T>, dim3((unsigned)nb), dim3(256), 0, st, a, nvox);
+    switch (s->cin) {
+      case 1: hipLaunchKernelGGL((pw_fwd_small_cin_kernel<T, 1>), dim3((unsigned)nb), dim3(256), 0, st, a, nvox); break;
+      case 2: hipLaunchKernelGGL((pw_fwd_small_cin_kernel<T, 2>), dim3((unsigned)nb), dim3(256), 0, st, a, nvox); break;
+      case 3: hipLaunchKernelGGL((pw_fwd_small_cin_kernel<T, 3>), dim3((unsigned)nb), dim3(256), 0, st, a, nvox); break;
+      default: hipLaunchKernelGGL((pw_fwd_small_cin_kernel<T, 4>), dim3((unsigned)nb), dim3(256), 0, st, a, nvox); break;
+    }
     SG_LAUNCH_CHECK();
     *used = true;
   } else if (s->cout <= 4 && s->cin % E == 0 && (s->cin / E) <= 64 && ((s->cin / E) & (s->cin / E - 1)) == 0) {

@@ -40,6 +40,7 @@ struct sg_config {
   int fwd3_gx, fwd3_no_lean;                 // SG_FWD3_GX (0 = automatic), SG_FWD3_NO_LEAN
   int fwd4_gx, fwd4_no_lean, fwd4_no_wres;   // SG_FWD4_GX (0 = automatic), SG_FWD4_NO_LEAN, SG_FWD4_NO_WRES
   int wgrad_v1, wgrad_no_v3, wgrad_no_lean;  // SG_WGRAD_V1, SG_WGRAD_NO_V3, SG_WGRAD_NO_LEAN
+  int wgrad_v1_blocks;                       // SG_WGRAD_V1_BLOCKS: block target of the generic weight-gradient kernel (0: default)
   int dbg_flags;                             // SG_DBG_FLAGS
 };
 const sg_config& sg_cfg();

@@ -2053,6 +2053,9 @@ static int launch_fwd4(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, b
   if (sg_cfg().fwd4_gx > 0) gx = sg_cfg().fwd4_gx;   // tools shrink the grid to reach this kernel with small tensors
   if (gx < 8 || (gx & 7)) return SG_EINVAL;
   if (ntiles >= (1 << 24) || ntiles < 2 * gx) return SG_OK;
+  // one tile per wave group leaves nothing to overlap: on the 512 -> 512 (1,3,3) layers of the 2x8x8 level at batch 64
+  // (32 tiles, 16 blocks in x) the weight-stationary kernel is faster, 92 against 123 us
+  if (KD == 1 && ntiles < 4 * gx) return SG_OK;
   // per-lane halo offsets are relative to the tile's first sample: only TN samples have to fit 31 bits
   if ((int64_t)g.TN * s->d * s->h * s->w * (int64_t)s->cin * (int64_t)sizeof(T) >= (1ll << 31)) return SG_OK;
   const int hv = g.TN * g.HD * g.HH * g.HW;

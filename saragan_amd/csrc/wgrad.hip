@@ -194,8 +194,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_partial_kernel(const T* __restri
   // four voxel rows per trip: the loads are independent, and one 16-byte load per lane per trip left the memory
   // system mostly idle (2.4 TB/s)
   constexpr int U = 4;
-  const int64_t step = (int64_t)gridDim.x * rows;
-  for (int64_t v0 = (int64_t)blockIdx.x * rows + rr; v0 < nvox; v0 += U * step) {
+  const int64_t step = rows;                     // the four rows of a trip are adjacent voxel groups (one contiguous stretch)
+  for (int64_t v0 = (int64_t)blockIdx.x * U * rows + rr; v0 < nvox; v0 += (int64_t)gridDim.x * U * rows) {
     u32x4 raw[U];
     float sv[U][4];
 #pragma unroll
@@ -299,7 +299,9 @@ static int launch_wgrad(WgradArgs& a, const sg_conv_shape* s, hipStream_t st) {
   auto kern = conv_wgrad_kernel<T, BM>;
   SG_ALLOW_160K_LDS(kern);
   const int pairs = a.ciT * a.coT;
-  int P = sg_cdiv(768, pairs);
+  // blocks per (ci, co) pair: two blocks per CU in ONE wave of blocks.  768 (three per CU) was measured slower on the
+  // 512 -> 512 layers of the 2x8x8 level, 229 against 179 us at batch 64: the third block of a CU runs as a tail.
+  int P = sg_cdiv(sg_cfg().wgrad_v1_blocks > 0 ? sg_cfg().wgrad_v1_blocks : 512, pairs);
   if (P > a.ntiles) P = a.ntiles;
   if (P < 1) P = 1;
   for (int tap0 = 0; tap0 < a.taps; tap0 += 4 * WG_MAXT) {

@@ -508,7 +508,6 @@ class _ConvBiasAct(torch.autograd.Function):
         return gx, gw, (gb if want_db else None), None, None, None, None, None, None, None, None
 
 
-_NO_LERP_ALIAS = bool(int(os.environ.get('SARAGAN_NO_LERP_ALIAS', '0')))   # diagnostic: alpha = 0 through sg_axpby
 _NO_POOL_FUSION = bool(int(os.environ.get('SARAGAN_NO_POOL_FUSION', '0')))   # diagnostic: conv and downscale3d apart
 
 
@@ -891,22 +890,6 @@ class _Axpby(torch.autograd.Function):
         return ga, gb, None, None
 
 
-class _Select(torch.autograd.Function):
-    """lerp with weights exactly (0, 1): the stabilising half of every phase runs the fade-in graph with alpha = 0
-    (pgan/generator.py:100-101, pgan/discriminator.py:105), where 0*a + 1*b is b bit for bit (finite a).  No pass over
-    the tensors: the output aliases b, b's gradient aliases the incoming one, a's gradient is zeros (the faded-out
-    branch still gets its zero gradients, as tf.gradients gives them)."""
-
-    @staticmethod
-    def forward(ctx, dead, live):
-        _note_all(dead, live)
-        return live.view_as(live)
-
-    @staticmethod
-    def backward(ctx, g):
-        return (torch.zeros_like(g) if ctx.needs_input_grad[0] else None), g
-
-
 class _AddNoise(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, stddev, seed, offset):
@@ -988,10 +971,6 @@ def upscale_trilinear2x(x):
 
 
 def lerp(a, b, wa, wb):
-    if float(wa) == 0.0 and float(wb) == 1.0 and b is not None and not _NO_LERP_ALIAS:
-        if a.shape != b.shape or a.dtype != b.dtype:
-            raise ValueError('lerp operands differ in shape or dtype')
-        return _Select.apply(a, b)
     return _Axpby.apply(a, b, wa, wb)
 
 

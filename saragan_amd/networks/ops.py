@@ -6,6 +6,7 @@ handles so that the reference's sequence `conv3d -> apply_bias -> act -> pixel_n
 and `upscale3d -> conv3d` (pgan/generator.py:49-57) collapse into ONE kernel launch while the network code
 keeps the reference's op-by-op structure.  Any other consumer materialises the handle.
 """
+import os
 import numpy as np
 import torch
 
@@ -342,9 +343,19 @@ def minibatch_stddev_layer(x, group_size=4):
     return F.minibatch_stddev(_val(x), group_size)
 
 
+_NO_LERP_PRUNE = bool(int(os.environ.get('SARAGAN_NO_LERP_PRUNE', '0')))   # diagnostic: alpha = 0 / 1 through sg_axpby
+
+
 def lerp(a, b, alpha):
-    """alpha * a + (1 - alpha) * b: the fade-in of pgan/generator.py:100-101 and pgan/discriminator.py:105."""
+    """alpha * a + (1 - alpha) * b: the fade-in of pgan/generator.py:100-101 and pgan/discriminator.py:105.
+    The stabilising half of every phase runs this graph with alpha = 0 exactly (and a mixing phase starts at exactly 1):
+    0 * a + 1 * b is b bit for bit (finite a) and every gradient into the faded-out branch is zero, so that branch is
+    pruned here -- its value is never materialised (the lazy from_rgb / to_rgb of the previous phase does not run), and
+    its variables keep the zeros their slice of the flat gradient buffer is cleared to (optimization.StepGraph._backward),
+    which is what tf.gradients delivers for them."""
     alpha = float(alpha)
+    if not _NO_LERP_PRUNE and (alpha == 0.0 or alpha == 1.0):
+        return _val(b) if alpha == 0.0 else _val(a)
     return F.lerp(_val(a), _val(b), alpha, 1.0 - alpha)
 
 

@@ -719,21 +719,25 @@ def test_upconv_data_gradient_pooled_in_the_conv_epilogue(monkeypatch):
 
 
 @pytest.mark.parametrize('dtype', DT)
-def test_lerp_with_alpha_zero_is_an_alias(dtype):
-    """alpha = 0 (the stabilising half of a phase): lerp returns b bit for bit without a pass, the faded-out operand
-    gets zeros, the live one the incoming gradient (pgan/generator.py:100-101, pgan/discriminator.py:105)."""
+def test_lerp_with_alpha_zero_or_one_prunes_the_faded_branch(dtype):
+    """alpha = 0 (the stabilising half of a phase) / alpha = 1: networks.ops.lerp returns the live operand bit for bit
+    without a pass over the tensors and without a graph edge to the other one (pgan/generator.py:100-101,
+    pgan/discriminator.py:105); any other alpha goes through sg_axpby."""
     from saragan_amd import functional as F
+    from saragan_amd.networks import ops
     a = cl(rnd((2, 8, 3, 4, 5), 81, dtype), dtype).requires_grad_(True)
     b = cl(rnd((2, 8, 3, 4, 5), 82, dtype), dtype).requires_grad_(True)
     g = cl(rnd((2, 8, 3, 4, 5), 83, dtype), dtype)
-    out = F.lerp(a, b * 1.0, 0.0, 1.0)
-    ref = F._Axpby.apply(a, b, 0.0, 1.0)
-    assert torch.equal(out, ref) and torch.equal(out, b)
-    ga, gb = torch.autograd.grad(out, [a, b], g)
-    assert torch.equal(gb, g) and float(ga.abs().max()) == 0.0 and ga.shape == a.shape
-    # any other weight pair goes through sg_axpby
-    out2 = F.lerp(a, b, 0.25, 0.75)
+    for alpha, live, dead in ((0.0, b, a), (1.0, a, b)):
+        out = ops.lerp(a * 1.0, b * 1.0, alpha)
+        assert torch.equal(out, F.lerp(a, b, alpha, 1.0 - alpha)) and torch.equal(out, live)
+        gl, gd = torch.autograd.grad(out, [live, dead], g, allow_unused=True)
+        assert torch.equal(gl, g) and gd is None
+    out2 = ops.lerp(a, b, 0.25)
     close(out2, 0.25 * a.double() + 0.75 * b.double(), dtype, 'lerp')
+    ga, gb = torch.autograd.grad(out2, [a, b], g)
+    close(ga, 0.25 * g.double(), dtype, 'd lerp / da')
+    close(gb, 0.75 * g.double(), dtype, 'd lerp / db')
 
 
 def test_conv_epilogue_fused_downscale_hw_pairs():

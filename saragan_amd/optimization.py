@@ -288,10 +288,11 @@ class StepGraph:
             p.grad = flat['grad'][o:o + cnt].view(p.shape)
         loss = out['gen_loss'] if tr['net'] == 'generator' else out['disc_loss']
         dist = tr['optimizer'].distributed
-        if dist is not None:
-            dist.begin(flat['grad'], ranges, params)
         other = 'discriminator/' if tr['net'] == 'generator' else 'generator/'
         link = getattr(out['gen_loss'], 'sg_link', None) if 'gen_loss' in out else None
+        if dist is not None:
+            roots = [link[0]] if (link is not None and tr['net'] == 'generator') else [loss]
+            dist.begin(flat['grad'], ranges, params, roots if getattr(dist, 'world_size', 1) > 1 else None)
         with F.skip_param_grads(p for _, p in self.store.trainable(other)):   # e.g. D's weights under the G loss
             if link is None:
                 torch.autograd.backward(loss, inputs=params, retain_graph=retain)

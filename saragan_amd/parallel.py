@@ -38,6 +38,24 @@ def rank():
     return dist.get_rank() if dist.is_initialized() else 0
 
 
+def reachable_leaves(roots):
+    """ids of the leaf tensors whose AccumulateGrad node is reachable from the grad_fn of any of `roots`."""
+    seen, out = set(), set()
+    stack = [r.grad_fn for r in roots if r is not None and r.grad_fn is not None]
+    while stack:
+        fn = stack.pop()
+        if fn in seen:
+            continue
+        seen.add(fn)
+        var = getattr(fn, 'variable', None)
+        if var is not None:
+            out.add(id(var))
+        for nxt, _ in fn.next_functions:
+            if nxt is not None:
+                stack.append(nxt)
+    return out
+
+
 class GradientAllReducer:
     """Sums contiguous slices ("buckets") of a flat gradient buffer across ranks, overlapping with backward.
 
@@ -84,13 +102,21 @@ class GradientAllReducer:
         self._buckets = buckets
         self._flat = flat_grad
 
-    def begin(self, flat_grad, ranges, params):
+    def begin(self, flat_grad, ranges, params, roots=None):
+        """roots: the tensors backward starts from.  Parameters the graph below them does not reach (the faded-out
+        branch of a stabilising phase, networks.ops.lerp) never fire their hook: they are counted as done here, so
+        that their bucket goes out as soon as its live parameters are ready instead of waiting for finish()."""
         self._plan(flat_grad, ranges, params)
         for b in self._buckets:
             b['left'] = b['params']
             b['launched'] = False
         self._handles = []
         self._armed = True
+        if roots is not None:
+            reach = reachable_leaves(roots)
+            for p in params:
+                if id(p) not in reach:
+                    self._hook(p)
 
     def _launch(self, b):
         b['launched'] = True

@@ -55,6 +55,23 @@ def _worker(rank, world, port, q):
         torch.autograd.backward(loss, inputs=params)
         red.finish()
         out[trial] = {k: store.vars[k].grad.clone().numpy() for k in active}
+    # a parameter the loss does not reach (the faded-out branch of a stabilising phase): begin(roots=...) counts it as
+    # done, every bucket is launched by the hooks (none left to finish()), its gradient stays the cleared zeros
+    params = [store.vars[k] for k in names]
+    offs = flat['offsets']
+    ranges = [(offs[k][0], (offs[k][1] + 3) // 4 * 4) for k in names]
+    flat['grad'].zero_()
+    for p_, k in zip(params, names):
+        o, n = offs[k]
+        p_.grad = flat['grad'][o:o + n].view(p_.shape)
+    x = torch.full((1,), float(rank + 1))
+    loss = sum((p_ * (i + 1)).sum() for i, p_ in enumerate(params) if names[i] != 'generator/a/bias') * x
+    red.begin(flat['grad'], ranges, params, roots=[loss])
+    torch.autograd.backward(loss, inputs=params)
+    early = all(b['launched'] for b in red._buckets)
+    red.finish()
+    out[2] = {k: store.vars[k].grad.clone().numpy() for k in names}
+    out['early'] = early
     q.put((rank, same, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -80,3 +97,7 @@ def test_allreduce_and_broadcast_world2():
             want = (i + 1) * (1 + 2)                       # d/dp sum over ranks of (i+1) * p * (rank+1)
             for r in res:
                 np.testing.assert_allclose(r[2][trial][k], want)
+    for r in res:
+        assert r[2]['early'], 'a bucket waited for finish() although its only missing parameter is unreachable'
+        for i, k in enumerate(res[0][2][2]):
+            np.testing.assert_allclose(r[2][2][k], 0.0 if k == 'generator/a/bias' else (i + 1) * (1 + 2))

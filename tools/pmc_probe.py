@@ -94,6 +94,11 @@ def main():
         twice(f'wgrad+dbias {name}', 'conv_wgrad', vox * (cin + cout) * 2 + 27 * cin * cout * 4, flops,
               lambda: _lib.check(lib.sg_conv3d_wgrad_bias(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), 1.0,
                                                           ws.data_ptr(), wsb, C.byref(shp), dt, st)))
+        if fws_bytes and cin == 64:   # the same layer reading x as two 32-channel tensors (sg_conv_epilogue.x_plane_channels)
+            ep_pl = ConvEpilogue(None, 0, 0.2, 0, 1e-8, None, bits.data_ptr(), 0.2, None)
+            ep_pl.workspace, ep_pl.workspace_bytes, ep_pl.x_plane_channels = fws.data_ptr(), fws_bytes, 32
+            twice(f'fwd mask_bits, x as two 32-channel tensors {name}', 'conv_fwd', vox * (cin + cout) * 2 + vox * nw * 4 + 27 * cin * cout * 2, flops,
+                  lambda: _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep_pl), dt, st)), per_call)
         if cin <= 32 and cout % 32 == 0:      # the fused first stage of downscale3d (sg_conv_epilogue.pool)
             yp = torch.empty(n, d // 2, h, w // 2, cout, device=dev, dtype=torch.bfloat16)
             ep_pool = ConvEpilogue(bias.data_ptr(), 1, 0.2, 0, 1e-8, None, None, 0.0, sout.data_ptr())

@@ -437,6 +437,9 @@ def main():
                config=dict(workload=f"BASELINE configs[{args.config - 1}]: pgan '{args.size}' phase {args.phase} G+D step, "
                                     f"{'volumes' if args.dims == 3 else 'images'} {'x'.join(str(v) for v in sh[2:])}, "
                                     f"{args.loss}-gp, simultaneous, alpha {args.alpha}",
+                           fade_branch=('pruned: alpha is exactly 0 or 1, results identical (DESIGN.md 4.5; '
+                                        'SARAGAN_NO_LERP_PRUNE=1 runs it)') if (float(args.alpha) in (0.0, 1.0) and
+                                        not int(os.environ.get('SARAGAN_NO_LERP_PRUNE', '0'))) else 'computed',
                            local_batch=args.batch, global_batch=args.batch * world, latent_dim=args.latent,
                            parallelism=f'dp{world}', collective=comm, step_gflop_per_volume=round(step_gf, 1),
                            step_mfma_tflops=round(value * step_gf / 1e3 / world, 2),

@@ -159,6 +159,13 @@ int sg_pixel_norm_bwd(const void* dy, const void* y, const float* scale, void* d
 int sg_pixel_norm_act_bwd(const void* dy, const void* y, const float* scale, const void* y_sign_words, float slope,
                           void* dz, float* dbias, void* workspace, int64_t nvox, int32_t c, sg_dtype dt,
                           sg_stream_t st);
+/* The same when dy is the data gradient of a pointwise convolution to cs <= 4 channels (to_rgb of the stage's output,
+ * pgan/generator.py:13-16,96-97): dy[v][c] = sum_j g_small[v][j] * w_small[j][c] is formed in registers from
+ * g_small [nvox][cs] and w_small [cs][c] (f32, the values the forward multiplied with) instead of being written and read
+ * back.  c a multiple of the 16-byte piece, c <= 512 (bf16) / 256 (f32); otherwise SG_EUNSUPPORTED. */
+int sg_pixel_norm_act_bwd_pw(const void* g_small, int32_t cs, const float* w_small, const void* y, const float* scale,
+                             const void* y_sign_words, float slope, void* dz, float* dbias, void* workspace,
+                             int64_t nvox, int32_t c, sg_dtype dt, sg_stream_t st);
 /* y[n,2d,2h,2w,c] = gain * x[n,d,h,w,c] nearest-neighbour    (upscale3d / avg_unpool3d, ops.py:250-262) */
 int sg_upscale2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
                  float gain, sg_dtype dt, sg_stream_t st);

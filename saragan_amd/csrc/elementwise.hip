@@ -236,15 +236,26 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __re
 // pixel norm: a team of TP lanes (power of two <= 64) owns one voxel; KP pieces per lane (1 up to 512 bf16 channels,
 // else 4) and U voxels per loop trip: the loads of all U voxels are issued before the first reduction, which is what
 // the kernel needs to keep enough bytes in flight (one voxel per trip reached 2.8 of 6.3 TB/s).
-template <typename T, bool BWD, int KP, int U>
+template <typename T, bool BWD, int KP, int U, int CS = 0>
 __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a, const T* __restrict__ yv,
                                                          const float* __restrict__ scale_in, T* __restrict__ out,
                                                          float* __restrict__ scale_out, int64_t nvox, int c, int tp,
                                                          float eps, const uint32_t* __restrict__ words = nullptr,
-                                                         float slope = 0.f, float* __restrict__ part = nullptr) {
+                                                         float slope = 0.f, float* __restrict__ part = nullptr,
+                                                         const float* __restrict__ wsm = nullptr) {
   // BWD with `words`: the LeakyReLU backward of the layer (mask from its sign words) is applied to the result and
   // `part` receives per-block channel sums (the bias gradient): pixel_norm(act(z + b)) differentiated in one pass.
+  // CS > 0 (KP == 1): the incoming gradient is not a tensor but the product of a CS-channel tensor `a` [nvox][CS] with
+  // wsm [CS][c] -- the data gradient of a pointwise convolution to CS channels (to_rgb), formed in registers.
   constexpr int E = Piece<T>::E;
+  float wreg[CS > 0 ? CS : 1][E];
+  if constexpr (CS > 0) {
+    const int p0 = threadIdx.x % tp;
+#pragma unroll
+    for (int j = 0; j < CS; ++j)
+#pragma unroll
+      for (int e = 0; e < E; ++e) wreg[j][e] = p0 * E + e < c ? wsm[j * c + p0 * E + e] : 0.f;
+  }
   __shared__ float red[BWD ? 256 * E : 1];
   const int P = c / E;
   const int lane_t = threadIdx.x % tp;
@@ -261,17 +272,22 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a
     Piece<T> pa[U][KP], py[U][KP];
     float s[U], scv[U];
     uint32_t sw[U][KP];
+    float gsv[U][CS > 0 ? CS : 1];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t v = v0 + u * vstride;
       s[u] = 0.f;
       scv[u] = 0.f;
+      if constexpr (CS > 0) {
+#pragma unroll
+        for (int j = 0; j < CS; ++j) gsv[u][j] = v < nvox ? sg_traits<T>::to_f(a[v * CS + j]) : 0.f;
+      }
 #pragma unroll
       for (int k = 0; k < KP; ++k) {
         const int p = lane_t + k * tp;
         sw[u][k] = 0u;
         if (v < nvox && p < P) {
-          pa[u][k].load(a + v * c + (int64_t)p * E);
+          if constexpr (CS == 0) pa[u][k].load(a + v * c + (int64_t)p * E);
           if (BWD) {
             py[u][k].load(yv + v * c + (int64_t)p * E);
             if (words) sw[u][k] = piece_signs(words, v, nw, p * E);
@@ -283,6 +299,15 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t v = v0 + u * vstride;
+      if constexpr (CS > 0) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          float t = 0.f;
+#pragma unroll
+          for (int j = 0; j < CS; ++j) t = fmaf(gsv[u][j], wreg[j][e], t);
+          pa[u][0].v[e] = t;
+        }
+      }
 #pragma unroll
       for (int k = 0; k < KP; ++k) {
         const int p = lane_t + k * tp;
@@ -971,6 +996,33 @@ extern "C" int sg_pixel_norm_act_bwd(const void* dy, const void* y, const float*
                   else hipLaunchKernelGGL((pixel_norm_kernel<T, true, 4, 1>), dim3(blocks), dim3(256), 0, hs, (const T*)dy, (const T*)y, scale, (T*)dz, (float*)nullptr, nvox, c, tp, 0.f, (const uint32_t*)y_sign_words, slope, part); } while (0)
   SG_DISPATCH(dt, L(bf16_t), L(float));
 #undef L
+  SG_LAUNCH_CHECK();
+  if (dbias) {
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 31) / 32), dim3(1024), 0, hs, part, dbias, blocks, c);
+    SG_LAUNCH_CHECK();
+  }
+  return SG_OK;
+}
+
+extern "C" int sg_pixel_norm_act_bwd_pw(const void* g_small, int32_t cs, const float* w_small, const void* y, const float* scale,
+                                        const void* y_sign_words, float slope, void* dz, float* dbias, void* workspace,
+                                        int64_t nvox, int32_t c, sg_dtype dt, sg_stream_t st) {
+  if (!g_small || !w_small || !y || !scale || !y_sign_words || !dz || nvox < 1 || c < 1 || cs < 1 || cs > 4) return SG_EINVAL;
+  if (dbias && !workspace) return SG_EINVAL;
+  hipStream_t hs = sg_st(st);
+  const int E = dt == SG_BF16 ? 8 : 4;
+  const int P = c / E;
+  if ((c % E) != 0 || P > 64 || !sg_aligned16(dz) || !sg_aligned16(y)) return SG_EUNSUPPORTED;
+  const int tp = team_size(P);
+  if (P > tp) return SG_EUNSUPPORTED;
+  const int teams = 256 / tp;
+  const int blocks = grid_for(nvox, teams, kBwdBlocks);
+  float* part = dbias ? reinterpret_cast<float*>(workspace) : nullptr;
+#define LC(T, CSV) hipLaunchKernelGGL((pixel_norm_kernel<T, true, 1, 2, CSV>), dim3(blocks), dim3(256), 0, hs, (const T*)g_small, (const T*)y, scale, (T*)dz, (float*)nullptr, nvox, c, tp, 0.f, (const uint32_t*)y_sign_words, slope, part, w_small)
+#define L(T) do { switch (cs) { case 1: LC(T, 1); break; case 2: LC(T, 2); break; case 3: LC(T, 3); break; default: LC(T, 4); break; } } while (0)
+  SG_DISPATCH(dt, L(bf16_t), L(float));
+#undef L
+#undef LC
   SG_LAUNCH_CHECK();
   if (dbias) {
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 31) / 32), dim3(1024), 0, hs, part, dbias, blocks, c);

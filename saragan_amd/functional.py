@@ -508,6 +508,99 @@ class _ConvBiasAct(torch.autograd.Function):
         return gx, gw, (gb if want_db else None), None, None, None, None, None, None, None, None
 
 
+_NO_RGB_FUSION = bool(int(os.environ.get('SARAGAN_NO_RGB_FUSION', '0')))   # diagnostic: to_rgb's data gradient as a tensor
+
+
+def _rgb_matrix(w_rgb, coef, dtype):
+    """[cs][c] f32: the values to_rgb's forward multiplied with (coef * w rounded to the compute dtype, as the packed
+    weight image holds them), for sg_pixel_norm_act_bwd_pw.  Cached like the packed images."""
+    key = ('rgbmat', w_rgb.data_ptr(), w_rgb._version, float(coef), dtype)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None:
+        return hit[0]
+    m = (w_rgb.detach().reshape(w_rgb.shape[-2], w_rgb.shape[-1]).float() * float(coef)).to(dtype).float().t().contiguous()
+    _PACK_CACHE[key] = (m, w_rgb)
+    return m
+
+
+class _ConvPnActToRgb(torch.autograd.Function):
+    """One generator stage's tail, y = pixel_norm(leaky_relu(conv3d(x) + b)) followed by img = to_rgb(y)
+    (pgan/generator.py:33-45,96-97), as one node with both outputs.  Forward is the two launches it would be anyway.
+    Backward, when y has no other consumer (the last block: only to_rgb reads it): to_rgb's data gradient -- c channels
+    at full resolution, the largest tensor of G's backward -- is never written; sg_pixel_norm_act_bwd_pw forms it in
+    registers from the 1-channel image gradient inside the pixel-norm / LeakyReLU backward pass.  Once-differentiable,
+    like _PnActBwd."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, coef, ups, slope, eps, in_info, w_rgb, b_rgb, coef_rgb):
+        _note_all(x, w, b, w_rgb, b_rgb)
+        y, scale, signs = raw_conv(x, w, coef, False, ups, bias=b, act=True, slope=slope, pixel_norm=True, eps=eps,
+                                   want_scale=True, want_signs=True)
+        img, _, _ = raw_conv(y, w_rgb, coef_rgb, False, False, bias=b_rgb)
+        ctx.save_for_backward(x, w, y, scale, signs, w_rgb)
+        ctx.cfg = (coef, ups, slope, coef_rgb)
+        ctx.in_info = in_info
+        ctx.ptrs = (w.data_ptr(), b.data_ptr() if b is not None else 0, w_rgb.data_ptr(),
+                    b_rgb.data_ptr() if b_rgb is not None else 0)
+        ctx.has_b, ctx.has_b_rgb = b is not None, b_rgb is not None
+        ctx.set_materialize_grads(False)
+        return img, y
+
+    @staticmethod
+    def backward(ctx, g_img, g_y):
+        if torch.is_grad_enabled():
+            raise NotImplementedError('second-order gradient through pixel_norm is not part of the pgan step')
+        x, w, y, scale, signs, w_rgb = ctx.saved_tensors
+        coef, ups, slope, coef_rgb = ctx.cfg
+        lib = _lib.load()
+        n, c, d, h, wd = _dims(y)
+        nvox = n * d * h * wd
+        want_db = ctx.has_b and _wants(ctx, 2, ctx.ptrs[1])
+        gw_rgb = gb_rgb = None
+        if g_img is not None:
+            g_img = ndhwc(g_img)
+            want_db_rgb = ctx.has_b_rgb and _wants(ctx, 9, ctx.ptrs[3])
+            if _wants(ctx, 8, ctx.ptrs[2]):
+                gw_rgb, gb_rgb = raw_wgrad(y, g_img, (1, 1, 1), coef_rgb, False, want_db_rgb)
+                gw_rgb = gw_rgb.reshape(w_rgb.shape)
+            elif want_db_rgb:
+                _, gb_rgb = raw_bias_act_bwd(g_img, None, 0.0, want_dx=False, want_db=True)
+        if g_img is None and g_y is None:
+            return (None,) * 11
+        g = gb = None
+        cs = w_rgb.shape[-1]
+        if g_img is not None and g_y is None and not _NO_RGB_FUSION and cs <= 4:
+            g = torch.empty_like(y)
+            gb = torch.empty(c, device=y.device, dtype=torch.float32) if want_db else None
+            ws = torch.empty(lib.sg_bias_act_bwd_workspace(c), device=y.device, dtype=torch.uint8) if want_db else None
+            rc = lib.sg_pixel_norm_act_bwd_pw(_ptr(g_img), cs, _ptr(_rgb_matrix(w_rgb, coef_rgb, y.dtype)), _ptr(y), _ptr(scale),
+                                              _ptr(signs), float(slope), _ptr(g), _ptr(gb), _ptr(ws), nvox, c, _dt(y), _stream())
+            if rc == _lib.SG_EUNSUPPORTED:
+                g = None
+            else:
+                check(rc, 'sg_pixel_norm_act_bwd_pw')
+        if g is None:       # y has other consumers (or the library declined): the gradient for y as a tensor
+            gy = raw_conv(g_img, w_rgb, coef_rgb, True, False)[0] if g_img is not None else None
+            if g_y is not None:
+                gy = ndhwc(g_y) if gy is None else gy + g_y
+            g, gb = _PnActBwd.apply(gy, y, scale, signs, slope, want_db)
+            if not want_db:
+                gb = None
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            if ups:
+                gx = _upconv_dgrad(g, w, coef, True)
+            elif _masked_in(ctx.in_info):
+                gx = raw_conv(g, w, coef, True, False, mask_bits=ctx.in_info.bits, mask_slope=ctx.in_info.slope)[0]
+            else:
+                gx = raw_conv(g, w, coef, True, False)[0]
+        if _wants(ctx, 1, ctx.ptrs[0]):
+            k = tuple(w.shape[:3]) if w.dim() == 5 else (1, 1, 1)
+            gw, _ = raw_wgrad(x, g, k, coef, ups, False)
+            gw = gw.reshape(w.shape)
+        return gx, gw, gb, None, None, None, None, None, gw_rgb, gb_rgb, None
+
+
 _NO_POOL_FUSION = bool(int(os.environ.get('SARAGAN_NO_POOL_FUSION', '0')))   # diagnostic: conv and downscale3d apart
 
 
@@ -944,6 +1037,11 @@ def conv3d(x, w, coef=1.0, bias=None, act=False, slope=0.2, pixel_norm=False, ep
     y = _Conv.apply(x, w, coef, False, upsample_in, in_info)
     y = _BiasAct.apply(y, bias, act, slope)
     return _PixelNorm.apply(y, eps) if pixel_norm else y
+
+
+def conv3d_pn_to_rgb(x, w, coef, bias, ups, slope, eps, in_info, w_rgb, coef_rgb, bias_rgb):
+    """(img, y): y = pixel_norm(leaky_relu(conv3d(x) + bias)), img = conv3d(y, w_rgb) + bias_rgb, one autograd node."""
+    return _ConvPnActToRgb.apply(x, w, bias, coef, ups, slope, eps, in_info, w_rgb, bias_rgb, coef_rgb)
 
 
 def conv3d_act_pool(x, w, coef, bias, slope, in_info=None):

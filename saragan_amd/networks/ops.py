@@ -63,6 +63,31 @@ class _LazyConv:
         return self._v
 
 
+class _LazyRgbTail(_LazyConv):
+    """to_rgb applied to a generator stage that has not been materialised yet (conv -> bias -> LeakyReLU -> pixel_norm):
+    evaluated together with it as one autograd node (functional._ConvPnActToRgb), whose backward never writes to_rgb's
+    full-resolution data gradient.  The stage's own handle receives its value too, so later consumers reuse it."""
+
+    def __init__(self, prod, w, coef):
+        super().__init__(None, w, coef, False)
+        self.prod = prod
+
+    @property
+    def shape(self):
+        return torch.Size((self.prod.shape[0], self.w.shape[-1], *self.prod.shape[2:]))
+
+    def value(self):
+        if self._v is None:
+            p = self.prod
+            if p._v is None and not self.act and not self.pn:
+                self._v, p._v = F.conv3d_pn_to_rgb(p.x, p.w, p.coef, p.bias, p.ups, p.slope, p.eps, p.in_info,
+                                                   self.w, self.coef, self.bias)
+            else:      # the stage was materialised by another consumer first, or the tail grew an epilogue of its own
+                self._v = F.conv3d(p.value(), self.w, self.coef, bias=self.bias, act=self.act, slope=self.slope,
+                                   pixel_norm=self.pn, eps=self.eps)
+        return self._v
+
+
 def _consume(x, premask=False):
     """Materialises a handle for one consumer and returns (tensor, ActInfo-or-None).  `premask` says that this
     consumer applies the producer's LeakyReLU-backward mask inside its own backward kernel (F.ActInfo)."""
@@ -209,6 +234,10 @@ def conv3d(x, fmaps, kernel, activation, param=None, lrmul=1):
     """networks/ops.py:147-150."""
     ups = isinstance(x, _LazyUp) and x._v is None
     cin = x.shape[1]
+    if (tuple(kernel) == (1, 1, 1) and fmaps <= 4 and type(x) is _LazyConv and x._v is None and x.stage == 3 and x.act and
+            x.pn and x.x.dtype == compute_dtype() and not F._NO_RGB_FUSION):
+        w = get_weight([*kernel, cin, fmaps], activation, param=param, lrmul=lrmul)
+        return _LazyRgbTail(x, w.var, w.coef)
     if ups:
         xin, in_info = x.x, None
     else:

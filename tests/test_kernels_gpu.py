@@ -780,3 +780,72 @@ def test_conv_epilogue_fused_downscale_hw_pairs():
     f2 = F.raw_conv(x2, w2, 0.05, False)[0].float()
     ref2 = torch.nn.functional.avg_pool3d(f2, (1, 2, 2))
     assert float((r2[0].float() - ref2).abs().max()) <= 1e-2 * float(ref2.abs().max())
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('ups', [False, True])
+def test_generator_tail_with_to_rgb_as_one_node(dtype, ups):
+    """y = pixel_norm(leaky_relu(conv3d(x) + b)), img = to_rgb(y) (pgan/generator.py:33-45,96-97) as one autograd node:
+    when only img is used, to_rgb's full-resolution data gradient is formed inside the pixel-norm backward
+    (sg_pixel_norm_act_bwd_pw); when y has another consumer, it is a tensor as before.  Both against the oracle."""
+    from saragan_amd import functional as F
+    n, cin, c, sp = 2, 16, 32, (3, 6, 8)
+    x = rnd((n, cin, *sp), 101, dtype)
+    w = rnd((3, 3, 3, cin, c), 102, dtype)
+    b = rnd((c,), 103, torch.float32) * 0.3
+    wr = rnd((1, 1, 1, c, 1), 104, dtype)
+    br = rnd((1,), 105, torch.float32) * 0.3
+    coef = O.runtime_coef(w.shape, 'leaky_relu', 0.2)
+    coef_r = O.runtime_coef(wr.shape, 'linear', None)
+    wq = (w * coef).to(dtype).double() / coef
+    wrq = (wr * coef_r).to(dtype).double() / coef_r
+    leaves = [t.clone().requires_grad_(True) for t in (x, wq, b.double(), wrq, br.double())]
+    xr, w_r, b_r, wr_r, br_r = leaves
+    xin = O.upscale3d(xr) if ups else xr
+    y_r = O.pixel_norm(O.act(O.apply_bias(O.conv3d(xin, w_r, 'leaky_relu', 0.2), b_r), 'leaky_relu', 0.2))
+    img_r = O.apply_bias(O.conv3d(y_r, wr_r, 'linear', None), br_r)
+    gl = [cl(x, dtype).requires_grad_(True)] + [t.float().to(dev()).requires_grad_(True) for t in (w, b, wr, br)]
+    xg, wg, bg, wrg, brg = gl
+    img, y = F.conv3d_pn_to_rgb(xg, wg, coef, bg, ups, 0.2, 1e-8, None, wrg, coef_r, brg)
+    # bf16: y is rounded before to_rgb reads it
+    close(y, y_r, dtype, 'y')
+    close(img, img_r, dtype, 'img')
+    g_img = rnd(tuple(img_r.shape), 106, dtype)
+    ref = torch.autograd.grad(img_r, leaves, g_img, retain_graph=True)
+    got = torch.autograd.grad(img, gl, cl(g_img, dtype), retain_graph=True)
+    rt, at = (2e-3, 2e-3) if dtype == torch.float32 else (2e-2, 2e-2)
+    for name, a, r in zip(('dx', 'dw', 'db', 'dw_rgb', 'db_rgb'), got, ref):
+        _mostly_close(a, r, rt, at, name + ' (fused)')
+    # y consumed elsewhere too: gradients of img and y add up
+    g_y = rnd(tuple(y_r.shape), 107, dtype)
+    ref2 = torch.autograd.grad([img_r, y_r], leaves, [g_img, g_y])
+    got2 = torch.autograd.grad([img, y], gl, [cl(g_img, dtype), cl(g_y, dtype)])
+    for name, a, r in zip(('dx', 'dw', 'db', 'dw_rgb', 'db_rgb'), got2, ref2):
+        _mostly_close(a, r, rt, at, name + ' (y also used)')
+
+
+def test_generator_uses_the_fused_tail(monkeypatch):
+    """networks.ops: to_rgb of an unmaterialised generator stage becomes the one-node tail; a stage that another
+    consumer materialised first falls back to the plain pointwise convolution."""
+    from saragan_amd import functional as F
+    from saragan_amd import varstore
+    from saragan_amd.networks import ops
+    calls = []
+    real = F.conv3d_pn_to_rgb
+    monkeypatch.setattr(F, 'conv3d_pn_to_rgb', lambda *a: (calls.append(1), real(*a))[1])
+    store = varstore.VariableStore(dev(), seed=3)
+    monkeypatch.setitem(varstore.COMPUTE_DTYPE, 'dtype', torch.bfloat16)
+    with varstore.use_store(store):
+        x = cl(rnd((2, 16, 2, 8, 8), 111, torch.bfloat16), torch.bfloat16)
+        with varstore.variable_scope('g'):
+            with varstore.variable_scope('c1'):
+                h = ops.pixel_norm(ops.act(ops.apply_bias(ops.conv3d(x, 32, (3, 3, 3), 'leaky_relu', 0.2)), 'leaky_relu', 0.2))
+            with varstore.variable_scope('rgb'):
+                img = ops.materialize(ops.to_rgb(h, 1))
+            assert calls == [1] and tuple(img.shape) == (2, 1, 2, 8, 8)
+            # the stage's handle now holds its value: a second consumer reuses it
+            again = ops.materialize(h)
+            with varstore.variable_scope('rgb', reuse=True):
+                img2 = ops.materialize(ops.to_rgb(h, 1))
+            assert calls == [1] and tuple(again.shape) == (2, 32, 2, 8, 8)
+            assert torch.equal(img, img2)

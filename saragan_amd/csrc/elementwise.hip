@@ -444,8 +444,9 @@ __global__ void upscale2x_kernel(const T* __restrict__ x, T* __restrict__ y, int
 }
 
 // Row-wise variant for the vector case: one block per output row (n, od, oh) -- scalar index arithmetic once per
-// block instead of 64-bit divisions per 16-byte piece (the flat kernel reached 3 TB/s).
-template <typename T>
+// block instead of 64-bit divisions per 16-byte piece (the flat kernel reached 3 TB/s).  HP = 2 (H is doubled): a block
+// writes the PAIR of output rows (oh, oh + 1) that share one source row from a single read of it.
+template <typename T, int HP>
 __global__ __launch_bounds__(256) void upscale2x_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int d, int h, int w,
                                                              int c, int sd, int sh, int sw, float gain,
                                                              const uint32_t* __restrict__ mask_bits, float mask_slope,
@@ -456,7 +457,9 @@ __global__ __launch_bounds__(256) void upscale2x_rows_kernel(const T* __restrict
   const int P = c / E, nw = (c + 31) >> 5, PP = pc / E;
   const int OD = d << sd, OH = h << sh, OW = w << sw;
   const int per_row = OW * P;
-  for (int64_t row = blockIdx.x; row < nrows; row += gridDim.x) {
+  const int64_t ngroups = nrows / HP;            // HP == 2: OH is even, rows pair up within a (n, od) slab
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t row = grp * HP;
     const int oh = (int)(row % OH);
     const int64_t q = row / OH;
     const int od = (int)(q % OD);
@@ -468,28 +471,36 @@ __global__ __launch_bounds__(256) void upscale2x_rows_kernel(const T* __restrict
     // exactly one trip): one piece per trip left the kernel at 3.7 of 6.3 TB/s
     for (int i0 = threadIdx.x; i0 < per_row; i0 += 256 * 4) {
       Piece<T> pcs[4];
-      uint32_t sg[4];
+      uint32_t sg[HP][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int i = i0 + 256 * j;
-        sg[j] = 0u;
+#pragma unroll
+        for (int r = 0; r < HP; ++r) sg[r][j] = 0u;
         if (i < per_row) {
           const int ow = i / P, p = i - ow * P;
           pcs[j].load(xrow + (int64_t)(ow >> sw) * c + p * E);
-          if (mrow) sg[j] = mrow[ow * nw + ((p * E) >> 5)] >> ((p * E) & 31);
+          if (mrow) {
+#pragma unroll
+            for (int r = 0; r < HP; ++r) sg[r][j] = mrow[((int64_t)r * OW + ow) * nw + ((p * E) >> 5)] >> ((p * E) & 31);
+          }
         }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int i = i0 + 256 * j;
         if (i < per_row) {
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            const float v = pcs[j].v[e] * gain;
-            pcs[j].v[e] = ((sg[j] >> e) & 1u) ? v * mask_slope : v;
-          }
           const int ow = i / P, p = i - ow * P, pl = p / PP;
-          pcs[j].store_nt(yrow + pl * plane_stride + (int64_t)ow * pc + (p - pl * PP) * E);
+#pragma unroll
+          for (int r = 0; r < HP; ++r) {
+            Piece<T> o;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+              const float v = pcs[j].v[e] * gain;
+              o.v[e] = ((sg[r][j] >> e) & 1u) ? v * mask_slope : v;
+            }
+            o.store_nt(yrow + pl * plane_stride + ((int64_t)r * OW + ow) * pc + (p - pl * PP) * E);
+          }
         }
       }
     }
@@ -1047,7 +1058,8 @@ static int upscale_nn_impl(const void* x, void* y, const void* mask_bits, float 
     const int64_t nrows = (int64_t)n * (d << sd) * (h << sh);
     const int rb = (int)(nrows < 16384 ? nrows : 16384);
     const int64_t plane_stride = nrows * (w << sw) * plane_channels;
-#define LR(T) hipLaunchKernelGGL((upscale2x_rows_kernel<T>), dim3(rb), dim3(256), 0, hs, (const T*)x, (T*)y, d, h, w, c, sd, sh, sw, gain, (const uint32_t*)mask_bits, mask_slope, nrows, (int)plane_channels, plane_stride)
+#define LR(T) do { if (sh == 1) hipLaunchKernelGGL((upscale2x_rows_kernel<T, 2>), dim3(rb), dim3(256), 0, hs, (const T*)x, (T*)y, d, h, w, c, sd, sh, sw, gain, (const uint32_t*)mask_bits, mask_slope, nrows, (int)plane_channels, plane_stride); \
+                   else hipLaunchKernelGGL((upscale2x_rows_kernel<T, 1>), dim3(rb), dim3(256), 0, hs, (const T*)x, (T*)y, d, h, w, c, sd, sh, sw, gain, (const uint32_t*)mask_bits, mask_slope, nrows, (int)plane_channels, plane_stride); } while (0)
     SG_DISPATCH(dt, LR(bf16_t), LR(float));
 #undef LR
     SG_LAUNCH_CHECK();

@@ -606,9 +606,11 @@ _NO_POOL_FUSION = bool(int(os.environ.get('SARAGAN_NO_POOL_FUSION', '0')))   # d
 
 class _ConvBiasActPool(torch.autograd.Function):
     """downscale3d(leaky_relu(conv3d(x) + b)) (one discriminator block's tail, pgan/discriminator.py:33-44) without the
-    full-resolution activation: the convolution's epilogue writes the 2 x 1 x 2 block means (sg_conv_epilogue.pool) and
-    the sign words, sg_downscale_sum(1,2,1) pools the H pairs.  Backward: the pooled gradient goes up through ONE
-    masked nearest-x2 (gain 1/8, this layer's sign words), then the usual data / weight gradients."""
+    full-resolution activation: the convolution's epilogue writes the means of 2 x 1 x 2 blocks (sg_conv_epilogue.pool = 1,
+    layers with <= 32 input channels) or 1 x 2 x 2 blocks (pool = 2) and the sign words; sg_downscale_sum pools the pairs
+    that are left.  Backward: the pooled gradient goes up through ONE masked nearest-x2 (gain 1/8, this layer's sign
+    words) -- written as two 32-channel tensors when the layer has 64 outputs and nothing differentiates the backward
+    again (_pooled_backward_planes) -- then the usual data / weight gradients."""
 
     @staticmethod
     def forward(ctx, x, w, b, coef, slope, in_info=None):

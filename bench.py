@@ -266,13 +266,37 @@ def pmc_traffic(entry, dtype):
     return None
 
 
+class Stopwatch:
+    """Wall time of a region bracketed by barrier + synchronize, cross-checked against a pair of HIP events on the compute
+    stream.  The two agree to ~0.1 % on a healthy host; some boxes of the pool have a host clock that runs slow for seconds
+    at a time (a leg of identical steps read 17 % "faster" than the kernels' own GPU time allows), so the LONGER of the
+    two is the duration every rate in this file is computed from."""
+
+    def __init__(self, barrier):
+        self.barrier = barrier
+
+    def __enter__(self):
+        self.barrier()
+        self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+        self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        self.e1.record()
+        self.barrier()
+        self.wall = time.perf_counter() - self.t0
+        self.e1.synchronize()
+        self.gpu = self.e0.elapsed_time(self.e1) * 1e-3
+        self.seconds = max(self.wall, self.gpu)
+        return False
+
+
 def timed_steps(step, nsteps, barrier):
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(nsteps):
-        step(i)
-    barrier()
-    return time.perf_counter() - t0
+    with Stopwatch(barrier) as sw:
+        for i in range(nsteps):
+            step(i)
+    return sw.seconds
 
 
 def loader_leg(args, cfg, device, nsteps, barrier):
@@ -378,11 +402,11 @@ def main():
         for o_ in cfg['optimizers']:
             o_.distributed.exposed_ms()       # forget the warm-up steps
     lib.sg_prof_enable(1)
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + ncal + i)
-    barrier()
-    dt = time.perf_counter() - t0
+    with Stopwatch(lambda: None) as sw:      # the barrier before is the one above; the one after follows
+        for i in range(args.steps):
+            step(args.warmup + ncal + i)
+        barrier()
+    dt = sw.seconds
     if world > 1:      # all-reduce time left exposed behind backward, per step (G + D), this rank
         comm['exposed_allreduce_ms_per_step'] = round(sum(sum(o_.distributed.exposed_ms()) for o_ in cfg['optimizers']) / args.steps, 3)
         comm['bucket_mib'] = cfg['optimizers'][0].distributed.bucket_elems * 4 >> 20
@@ -440,6 +464,7 @@ def main():
                            fade_branch=('pruned: alpha is exactly 0 or 1, results identical (DESIGN.md 4.5; '
                                         'SARAGAN_NO_LERP_PRUNE=1 runs it)') if (float(args.alpha) in (0.0, 1.0) and
                                         not int(os.environ.get('SARAGAN_NO_LERP_PRUNE', '0'))) else 'computed',
+                           timed_region_s=dict(wall=round(sw.wall, 4), hip_events=round(sw.gpu, 4)),
                            local_batch=args.batch, global_batch=args.batch * world, latent_dim=args.latent,
                            parallelism=f'dp{world}', collective=comm, step_gflop_per_volume=round(step_gf, 1),
                            step_mfma_tflops=round(value * step_gf / 1e3 / world, 2),
@@ -451,6 +476,21 @@ def main():
     if world == 1 and args.config == 3 and not args.no_extras:
         extras = {}
         extras['loader_in_loop'] = loader_leg(args, cfg, device, max(3, args.steps), barrier)
+        if float(args.alpha) in (0.0, 1.0):
+            # the same step with the faded-out lerp branch computed as the reference's graph does (it contributes exact
+            # zeros: DESIGN.md 4.5); `value` is measured with the branch pruned
+            from saragan_amd.networks import ops as _ops
+            prune, _ops._NO_LERP_PRUNE = _ops._NO_LERP_PRUNE, True
+            try:
+                for i in range(3):
+                    step(i)
+                nf = max(3, args.steps // 2)
+                dtf = timed_steps(step, nf, barrier)
+            finally:
+                _ops._NO_LERP_PRUNE = prune
+            extras['fade_branch_computed'] = dict(value=round(args.batch * nf / dtf, 3), ms_per_step=round(dtf / nf * 1e3, 3),
+                                                  steps=nf, note='alpha = 0 through sg_axpby and the previous phase\'s '
+                                                  'from_rgb / to_rgb, forward and backward (SARAGAN_NO_LERP_PRUNE=1)')
         # the same workload in fp32 storage / f32-input MFMA (the reference's arithmetic, ops.py:147-150)
         del cfg, sess, batches
         from saragan_amd import functional as F

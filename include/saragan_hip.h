@@ -134,6 +134,13 @@ int sg_conv3d_wgrad(const void* x, const void* dy, float* dw_dhwio, float coef, 
 int sg_conv3d_wgrad_bias(const void* x, const void* dy, float* dw_dhwio, float* dbias, float coef, void* workspace,
                          size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st);
 
+/* Whole backward of a pointwise convolution FROM cin <= 4 channels (from_rgb, pgan/discriminator.py:9-12) in one pass over
+ * dy: dw, dbias as sg_conv3d_wgrad_bias, and dx[n,d,h,w,cin] = sum_c dy[..,c] * w_mat[j][c] (w_mat: [cin][cout] f32, the
+ * values the forward multiplied with).  Other shapes: SG_EUNSUPPORTED (run sg_conv3d_fwd + sg_conv3d_wgrad_bias). */
+int sg_conv3d_pw_bwd(const void* x, const void* dy, const float* w_mat, float* dw_dhwio, float* dbias, void* dx,
+                     float coef, void* workspace, size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt,
+                     sg_stream_t st);
+
 /* ---- elementwise / reductions over NDHWC -------------------------------------------------------- */
 /* y = act(x + bias[c])                       (apply_bias + act, networks/ops.py:130-136,185-192) */
 int sg_bias_act_fwd(const void* x, const float* bias, void* y, int64_t nvox, int32_t c, int32_t act,

@@ -180,11 +180,19 @@ static int conv_shape_ok_w(const sg_conv_shape* s) {
 template <typename T>
 __global__ __launch_bounds__(256) void pw_wgrad_partial_kernel(const T* __restrict__ small, const T* __restrict__ big,
                                                                float* __restrict__ part, int64_t nvox, int cs, int cb,
-                                                               int ones_extra) {
+                                                               int ones_extra, T* __restrict__ dsmall = nullptr,
+                                                               const float* __restrict__ wsm = nullptr) {
+  // dsmall (optional, [nvox][cs]): the data gradient for the small side from the same read of `big` (= dy),
+  // dsmall[v][j] = sum_c big[v][c] * wsm[j][c] (sg_conv3d_pw_bwd)
   constexpr int E = 16 / (int)sizeof(T);
   __shared__ float red[256 * E];
   const int P = cb / E, rows = 256 / P;
   const int p = threadIdx.x % P, rr = threadIdx.x / P;
+  float wreg[4][E];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < E; ++e) wreg[j][e] = (dsmall != nullptr && j < cs) ? wsm[j * cb + p * E + e] : 0.f;
   float s[5][E];   // row cs (when ones_extra): the big side's plain column sums (bias gradient)
 #pragma unroll
   for (int j = 0; j < 5; ++j)
@@ -222,6 +230,19 @@ __global__ __launch_bounds__(256) void pw_wgrad_partial_kernel(const T* __restri
       if (ones_extra) {   // dead rows were loaded as zeros
 #pragma unroll
         for (int e = 0; e < E; ++e) s[4][e] += bv[e];
+      }
+      if (dsmall != nullptr) {   // uniform; the P lanes of a voxel are adjacent and run the same trips
+        const int64_t v = v0 + u * step;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j < cs) {
+            float dsum = 0.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) dsum = fmaf(bv[e], wreg[j][e], dsum);
+            for (int sh = 1; sh < P; sh <<= 1) dsum += __shfl_xor(dsum, sh);
+            if (p == 0 && v < nvox) dsmall[v * cs + j] = sg_traits<T>::from_f(dsum);
+          }
+        }
       }
     }
   }
@@ -1225,8 +1246,10 @@ extern "C" int sg_conv3d_wgrad(const void* x, const void* dy, float* dw, float c
   return sg_conv3d_wgrad_bias(x, dy, dw, nullptr, coef, workspace, workspace_bytes, s, dt, st);
 }
 
-extern "C" int sg_conv3d_wgrad_bias(const void* x, const void* dy, float* dw, float* dbias, float coef, void* workspace,
-                                    size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st) {
+// pw_dx / pw_wmat: sg_conv3d_pw_bwd's extra output and operand (pointwise layers from <= 4 input channels only)
+static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbias, float coef, void* workspace,
+                           size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st, void* pw_dx,
+                           const float* pw_wmat) {
   if (!conv_shape_ok_w(s) || !x || !dy || !dw || !workspace) return SG_EINVAL;
   if (!sg_aligned16(x) || !sg_aligned16(dy) || !sg_aligned16(workspace)) return SG_EALIGN;
   const size_t need = sg_conv3d_wgrad_workspace(s, dt);
@@ -1248,12 +1271,13 @@ extern "C" int sg_conv3d_wgrad_bias(const void* x, const void* dy, float* dw, fl
       float* part = reinterpret_cast<float*>(workspace);
       const int ones = (dbias != nullptr && small_is_cin) ? 1 : 0;   // the big side is dy: its column sums are the bias gradient
       SG_KNAME("pw_wgrad_partial");
+      if (pw_dx && !small_is_cin) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }
       if (dt == SG_BF16)
         hipLaunchKernelGGL(pw_wgrad_partial_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, hs, (const bf16_t*)sm,
-                           (const bf16_t*)bg, part, nvox, cs, cb, ones);
+                           (const bf16_t*)bg, part, nvox, cs, cb, ones, (bf16_t*)pw_dx, pw_wmat);
       else
         hipLaunchKernelGGL(pw_wgrad_partial_kernel<float>, dim3((unsigned)nb), dim3(256), 0, hs, (const float*)sm,
-                           (const float*)bg, part, nvox, cs, cb, ones);
+                           (const float*)bg, part, nvox, cs, cb, ones, (float*)pw_dx, pw_wmat);
       hipLaunchKernelGGL(pw_wgrad_final_kernel, dim3((unsigned)(((cs + ones) * cb + 31) / 32)), dim3(256), 0, hs, part,
                          dw, coef, (int)nb, cs, cb, small_is_cin, ones ? dbias : nullptr);
       int e0 = (int)hipGetLastError();
@@ -1264,6 +1288,7 @@ extern "C" int sg_conv3d_wgrad_bias(const void* x, const void* dy, float* dw, fl
       return e0;
     }
   }
+  if (pw_dx) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }   // only the pointwise pass has the extra output
   const size_t tile_bytes = (size_t)(s->kd * s->kh * s->kw) * sg_cdiv(s->cin, 32) * sg_cdiv(s->cout, 32) * 4096;
   hipError_t e = hipMemsetAsync(workspace, 0, tile_bytes, hs);
   if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, (size_t)s->cout * sizeof(float), hs);
@@ -1306,4 +1331,17 @@ extern "C" int sg_conv3d_wgrad_bias(const void* x, const void* dy, float* dw, fl
                          (int64_t)s->n * s->d * s->h * s->w, s->cout, 0.f, dt, st);
   prof.done(rc);
   return rc;
+}
+
+extern "C" int sg_conv3d_wgrad_bias(const void* x, const void* dy, float* dw, float* dbias, float coef, void* workspace,
+                                    size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st) {
+  return wgrad_bias_impl(x, dy, dw, dbias, coef, workspace, workspace_bytes, s, dt, st, nullptr, nullptr);
+}
+
+extern "C" int sg_conv3d_pw_bwd(const void* x, const void* dy, const float* w_mat, float* dw, float* dbias, void* dx,
+                                float coef, void* workspace, size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt,
+                                sg_stream_t st) {
+  if (!dx || !w_mat) return SG_EINVAL;
+  if (!s || s->kd * s->kh * s->kw != 1 || s->cin > 4 || s->cin > s->cout || s->upsample_in) return SG_EUNSUPPORTED;
+  return wgrad_bias_impl(x, dy, dw, dbias, coef, workspace, workspace_bytes, s, dt, st, dx, w_mat);
 }

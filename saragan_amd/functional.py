@@ -489,6 +489,14 @@ class _ConvBiasAct(torch.autograd.Function):
         if act and not premasked and not fused_pn_act:
             g, gb = _BiasActBwd.apply(g, signs if signs is not None else y.detach(), slope, want_db)
         gx = gw = None
+        db_from_wgrad = want_db and gb is None
+        if (ctx.needs_input_grad[0] and _wants(ctx, 1, w.data_ptr()) and not torch.is_grad_enabled() and not ups and
+                not _masked_in(ctx.in_info) and w.dim() == 5 and x.dim() == 5 and tuple(w.shape[:3]) == (1, 1, 1) and w.shape[3] <= 4 and
+                not _NO_RGB_FUSION):
+            res = _pw_backward(x, g, w, coef, db_from_wgrad)      # from_rgb: one pass over its output gradient
+            if res is not None:
+                gx, gw, gb2 = res
+                return gx, gw, ((gb2 if db_from_wgrad else gb) if want_db else None), None, None, None, None, None, None, None, None
         if ctx.needs_input_grad[0]:
             if ups:
                 gx = _upconv_dgrad(g, w, coef, True)
@@ -496,7 +504,6 @@ class _ConvBiasAct(torch.autograd.Function):
                 gx = _Conv.apply(g, w, coef, True, False, None, ctx.in_info.bits, ctx.in_info.slope)
             else:
                 gx = _Conv.apply(g, w, coef, True, False)
-        db_from_wgrad = want_db and gb is None
         if _wants(ctx, 1, w.data_ptr()):
             k = tuple(w.shape[:3]) if w.dim() == 5 else (1, 1, 1)
             gw, gb2 = _Wgrad.apply(x, g, k, coef, ups, db_from_wgrad)
@@ -511,16 +518,42 @@ class _ConvBiasAct(torch.autograd.Function):
 _NO_RGB_FUSION = bool(int(os.environ.get('SARAGAN_NO_RGB_FUSION', '0')))   # diagnostic: to_rgb's data gradient as a tensor
 
 
-def _rgb_matrix(w_rgb, coef, dtype):
-    """[cs][c] f32: the values to_rgb's forward multiplied with (coef * w rounded to the compute dtype, as the packed
-    weight image holds them), for sg_pixel_norm_act_bwd_pw.  Cached like the packed images."""
-    key = ('rgbmat', w_rgb.data_ptr(), w_rgb._version, float(coef), dtype)
+def _rgb_matrix(w_rgb, coef, dtype, small_is_cin=False):
+    """[cs][c] f32 of a pointwise convolution between cs <= 4 and c channels: the values its forward multiplied with
+    (coef * w rounded to the compute dtype, as the packed weight image holds them), for sg_pixel_norm_act_bwd_pw (to_rgb:
+    cs = cout) and sg_conv3d_pw_bwd (from_rgb: cs = cin).  Cached like the packed images."""
+    key = ('rgbmat', w_rgb.data_ptr(), w_rgb._version, float(coef), dtype, small_is_cin)
     hit = _PACK_CACHE.get(key)
     if hit is not None:
         return hit[0]
-    m = (w_rgb.detach().reshape(w_rgb.shape[-2], w_rgb.shape[-1]).float() * float(coef)).to(dtype).float().t().contiguous()
+    m = (w_rgb.detach().reshape(w_rgb.shape[-2], w_rgb.shape[-1]).float() * float(coef)).to(dtype).float()
+    m = (m if small_is_cin else m.t()).contiguous()
     _PACK_CACHE[key] = (m, w_rgb)
     return m
+
+
+def _pw_backward(x, dy, w, coef, want_db):
+    """(gx, gw, gb) of a pointwise convolution from <= 4 input channels (from_rgb) in one pass over dy
+    (sg_conv3d_pw_bwd), or None where the library has no such pass."""
+    lib = _lib.load()
+    x, dy = ndhwc(x), ndhwc(dy)
+    n, cin, d, h, wd = _dims(x)
+    cout = dy.shape[1]
+    if x.dtype != dy.dtype or cin > 4 or cin > cout:
+        return None
+    shp = _shape(n, d, h, wd, cin, cout, (1, 1, 1), False)
+    dt = _dt(x)
+    ws_bytes = lib.sg_conv3d_wgrad_workspace(C.byref(shp), dt)
+    ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
+    dw = torch.empty((1, 1, 1, cin, cout), device=x.device, dtype=torch.float32)
+    db = torch.empty(cout, device=x.device, dtype=torch.float32) if want_db else None
+    gx = torch.empty_like(x)
+    rc = lib.sg_conv3d_pw_bwd(_ptr(x), _ptr(dy), _ptr(_rgb_matrix(w, coef, x.dtype, True)), _ptr(dw), _ptr(db), _ptr(gx),
+                              float(coef), _ptr(ws), ws_bytes, C.byref(shp), dt, _stream())
+    if rc == _lib.SG_EUNSUPPORTED:
+        return None
+    check(rc, 'sg_conv3d_pw_bwd')
+    return gx, dw.reshape(w.shape), db
 
 
 class _ConvPnActToRgb(torch.autograd.Function):

@@ -849,3 +849,38 @@ def test_generator_uses_the_fused_tail(monkeypatch):
                 img2 = ops.materialize(ops.to_rgb(h, 1))
             assert calls == [1] and tuple(again.shape) == (2, 32, 2, 8, 8)
             assert torch.equal(img, img2)
+
+
+@pytest.mark.parametrize('dtype', DT)
+@pytest.mark.parametrize('cin', [1, 3])
+def test_from_rgb_backward_in_one_pass(dtype, cin, monkeypatch):
+    """from_rgb (pointwise conv from 1 / 3 channels + bias + LeakyReLU, pgan/discriminator.py:9-12): when nothing
+    differentiates the backward again, data, weight and bias gradients come from ONE pass over the output gradient
+    (sg_conv3d_pw_bwd); against the oracle and against the separate kernels."""
+    from saragan_amd import functional as F
+    n, c, sp = 3, 32, (3, 6, 9)
+    x = rnd((n, cin, *sp), 121, dtype)
+    w = rnd((1, 1, 1, cin, c), 122, dtype)
+    b = rnd((c,), 123, torch.float32) * 0.3
+    coef = O.runtime_coef(w.shape, 'leaky_relu', 0.2)
+    wq = (w * coef).to(dtype).double() / coef
+    leaves = [t.clone().requires_grad_(True) for t in (x, wq, b.double())]
+    y_r = O.act(O.apply_bias(O.conv3d(leaves[0], leaves[1], 'leaky_relu', 0.2), leaves[2]), 'leaky_relu', 0.2)
+    gy = rnd(tuple(y_r.shape), 124, dtype)
+    ref = torch.autograd.grad(y_r, leaves, gy)
+    used = []
+    real = F._pw_backward
+    monkeypatch.setattr(F, '_pw_backward', lambda *a: (lambda r: (used.append(r is not None), r)[1])(real(*a)))
+    gl = [cl(x, dtype).requires_grad_(True), w.float().to(dev()).requires_grad_(True), b.float().to(dev()).requires_grad_(True)]
+    y = F.conv3d(gl[0], gl[1], coef, bias=gl[2], act=True, slope=0.2)
+    close(y, y_r, dtype, 'from_rgb')
+    got = torch.autograd.grad(y, gl, cl(gy, dtype), retain_graph=True)
+    assert used == [True], 'the one-pass backward was not used'
+    rt, at = (1e-4, 1e-4) if dtype == torch.float32 else (1e-2, 1e-2)
+    for name, a, r in zip(('dx', 'dw', 'db'), got, ref):
+        _mostly_close(a, r, rt, at, name)
+    monkeypatch.setattr(F, '_NO_RGB_FUSION', True)
+    sep = torch.autograd.grad(y, gl, cl(gy, dtype))
+    assert used == [True]
+    for name, a, r in zip(('dx', 'dw', 'db'), got, sep):
+        _mostly_close(a, r, rt, at, name + ' vs separate kernels')

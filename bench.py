@@ -266,6 +266,12 @@ def pmc_traffic(entry, dtype):
     return None
 
 
+def mark(what):
+    """SARAGAN_BENCH_MARK=1: wall-clock markers of the legs (tools/clock_trace.sh lines them up with rocm-smi samples)."""
+    if os.environ.get('SARAGAN_BENCH_MARK'):
+        print(f'MARK {time.time():.3f} {what}', flush=True)
+
+
 class Stopwatch:
     """Wall time of a region bracketed by barrier + synchronize, cross-checked against a pair of HIP events on the compute
     stream.  The two agree to ~0.1 % on a healthy host; some boxes of the pool have a host clock that runs slow for seconds
@@ -276,10 +282,12 @@ class Stopwatch:
         self.barrier = barrier
 
     def __enter__(self):
+        import torch        # not at module level: the launcher process must not initialise the GPU
         self.barrier()
         self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.e0.record()
         self.t0 = time.perf_counter()
+        mark('timed region begins')
         return self
 
     def __exit__(self, *exc):
@@ -289,6 +297,7 @@ class Stopwatch:
         self.e1.synchronize()
         self.gpu = self.e0.elapsed_time(self.e1) * 1e-3
         self.seconds = max(self.wall, self.gpu)
+        mark(f'timed region ends: wall {self.wall:.4f} s, events {self.gpu:.4f} s')
         return False
 
 
@@ -320,9 +329,10 @@ def loader_leg(args, cfg, device, nsteps, barrier):
         def step(i):
             sess.run(cfg['train'], feed_dict={ph: pf.next()})
             sess.run(cfg['ema_op'])
-        # as many untimed steps as the main leg ran before its timed region: after the seconds of GPU idle spent writing
-        # the files the chip boosts for a few hundred ms, and a short leg would read 15 % faster than the main one
-        for i in range(args.warmup + 2 + 3):
+        # ~2 s of untimed steps: after the second or two of GPU idle spent writing the files the board's power averaging
+        # lets the chip overshoot its sustained clocks, and a short leg would read up to 17 % faster than the main one
+        # (profiles/r02_clock_trace.txt)
+        for i in range(max(30, args.warmup + 5)):
             step(i)
         dt = timed_steps(step, nsteps, barrier)
         pf.close()

@@ -239,7 +239,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_partial_kernel(const T* __restri
             float dsum = 0.f;
 #pragma unroll
             for (int e = 0; e < E; ++e) dsum = fmaf(bv[e], wreg[j][e], dsum);
-            for (int sh = 1; sh < P; sh <<= 1) dsum += __shfl_xor(dsum, sh);
+            if (P == 4) {      // the voxel's four lanes are one quad: two DPP exchanges, no LDS round trip
+              dsum += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(dsum), 0xB1, 0xF, 0xF, true));
+              dsum += __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(dsum), 0x4E, 0xF, 0xF, true));
+            } else {
+              for (int sh = 1; sh < P; sh <<= 1) dsum += __shfl_xor(dsum, sh);
+            }
             if (p == 0 && v < nvox) dsmall[v * cs + j] = sg_traits<T>::from_f(dsum);
           }
         }

@@ -39,7 +39,6 @@ def main():
     for i in range(3):
         step(i)
     state = {}
-
     def side_stream():
         state['s'] = torch.cuda.Stream()
         with torch.cuda.stream(state['s']):
@@ -62,7 +61,29 @@ def main():
             sess.run(cfg['ema_op'])
         state['step'] = step2
 
-    for phase, prep in (('from start', None), ('after 2 s idle', lambda: time.sleep(2.0)),
+    import ctypes as C
+    from saragan_amd import _lib
+    lib = _lib.load()
+
+    def prof_on():          # as bench.py's timed loop: per-launch profiling armed, filtered to one (kind, shape)
+        lib.sg_prof_enable(1)
+        step(0)
+        torch.cuda.synchronize()
+        ents = (_lib.ProfEntry * 256)()
+        n_ent = C.c_int32(0)
+        lib.sg_prof_collect(ents, 256, C.byref(n_ent))
+        lib.sg_prof_enable(0)
+        dom = max((ents[i] for i in range(n_ent.value)), key=lambda e: e.total_ms)
+        state['dom'] = dom
+        lib.sg_prof_set_filter(dom.kind, C.byref(dom.shape))
+        lib.sg_prof_enable(1)
+
+    def prof_off():
+        lib.sg_prof_enable(0)
+        lib.sg_prof_set_filter(0, None)
+
+    for phase, prep in (('from start', None), ('profiling armed with a shape filter', prof_on), ('profiling off', prof_off),
+                        ('after 2 s idle', lambda: time.sleep(2.0)),
                         ('after creating a side stream', side_stream), ('after a pinned H2D copy', pinned_copy),
                         ('inputs by async H2D copies', feed_from_pinned), ('resident inputs again', lambda: state.pop('step'))):
         if prep:

@@ -518,6 +518,21 @@ def test_conv_epilogue_fused_downscale(monkeypatch):
     assert torch.equal(gxp, gxg.detach()), 'data gradient differs between the layouts'
     _mostly_close(gwp, gwr, 2e-3, 4e-3, 'dw (planes)')
     _mostly_close(gbp, gbr, 2e-3, 4e-3, 'db (planes)')
+    # ... also when the layer's input is a LeakyReLU output whose mask this data gradient applies in its epilogue
+    info = F.ActInfo(0.2)
+    info.bits = F.sign_words(cl(rnd((n, cin, *sp), 65, dtype), dtype))
+    info.consume(True)
+    signs = F.raw_conv(xg.detach(), wg.detach(), coef, False, bias=bg.detach(), act=True, want_signs=True)[2]
+    gyd = cl(gy, dtype)
+    with torch.no_grad():
+        res = real(gyd, xg.detach(), wg.detach(), signs, coef, 0.2, info, True, True, True)
+        assert res is not None
+        g_full = F._Up.apply(gyd, 0.125, signs, 0.2, (2, 2, 2))
+        gx_ref = F._Conv.apply(g_full, wg.detach(), coef, True, False, None, info.bits, info.slope)
+        gw_ref, gb_ref = F.raw_wgrad(xg.detach(), g_full, (3, 3, 3), coef, False, True)
+    assert torch.equal(res[0], gx_ref), 'masked data gradient differs between the layouts'
+    _mostly_close(res[1], gw_ref.reshape(res[1].shape), 1e-3, 1e-3, 'dw (planes vs one launch)')
+    _mostly_close(res[2], gb_ref, 1e-3, 1e-3, 'db (planes vs one launch)')
 
 
 @pytest.mark.parametrize('dtype', DT)

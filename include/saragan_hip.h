@@ -101,6 +101,14 @@ typedef struct {
    * 64-byte rows instead of one half of every 128-byte row -- a half row costs the whole line from HBM.  Only that
    * path reads the layout: anything else returns SG_EUNSUPPORTED. */
   int32_t x_plane_channels;
+  /* Pixel-norm backward in the epilogue of a DATA-GRADIENT convolution: the convolution's result is the gradient g for the
+   * output y = pixel_norm(leaky_relu(z + b)) of a generator stage (pgan/generator.py:33-45); with pn_bwd_y = y [n,d,h,w,cout]
+   * and pn_bwd_scale = the stage's rsqrt factor [n*d*h*w] the epilogue turns it into the gradient for z,
+   * mask_bits(y's sign words) * pn_bwd_scale * (g - y * mean_c(g * y)), before it is written (what sg_pixel_norm_act_bwd
+   * computes in a pass of its own).  Needs mask_bits, cout == 32, the sliding-halo kernel's shapes (bf16, 3x3x3,
+   * cin <= 32, w % 32 == 0), no bias / activation / pooling; otherwise SG_EUNSUPPORTED.  Both NULL: off. */
+  const void* pn_bwd_y;
+  const float* pn_bwd_scale;
 } sg_conv_epilogue;
 
 /* Sign words of an NDHWC tensor t[nvox][c]: uint32 words[nvox][ceil(c/32)], bit j of word (v, k) = (t[v][32k+j] < 0),

@@ -24,7 +24,8 @@ class ConvEpilogue(C.Structure):
                 ('eps', C.c_float), ('pn_scale', C.c_void_p), ('mask_bits', C.c_void_p), ('mask_slope', C.c_float),
                 ('sign_out', C.c_void_p), ('out_scale', C.c_int32), ('out_off', C.c_int32 * 3),
                 ('tap_off', C.c_int32 * 3), ('pool', C.c_int32), ('workspace', C.c_void_p),
-                ('workspace_bytes', C.c_size_t), ('x_plane_channels', C.c_int32)]
+                ('workspace_bytes', C.c_size_t), ('x_plane_channels', C.c_int32), ('pn_bwd_y', C.c_void_p),
+                ('pn_bwd_scale', C.c_void_p)]
 
     def __init__(self, *args, **kw):
         super().__init__(C.sizeof(type(self)), *args, **kw)

@@ -118,6 +118,8 @@ struct ConvFwdArgs {
   int tap_d, tap_h, tap_w;   // added to the tap index when addressing the halo (sub-pixel classes)
   int xcs, xco;              // sliding-halo kernel: channels per voxel of the x TENSOR and first channel of the slice convolved (K split)
   const float* addend;       // sliding-halo kernel, second K-split pass: the first pass's f32 partial sums [voxel][cout]
+  const void* pnb_y;         // sliding-halo kernel, pixel-norm backward epilogue: the stage's output y [voxel][cout] ...
+  const float* pnb_scale;    // ... and its per-voxel rsqrt factor (sg_conv_epilogue.pn_bwd_y / pn_bwd_scale)
   int pool;                  // 1: y is the D x W mean-pooled output [n, D/2, H, W/2, cout] (sliding-halo kernel only)
   int os, oa, ob, oc;        // output scatter: os == 2 writes voxel (2d+oa, 2h+ob, 2w+oc) of a [n,2D,2H,2W,cout] tensor
   unsigned long long* dbg;  // diagnostic time stamps (NULL in production)
@@ -1162,7 +1164,7 @@ struct sg_unrolled_ks2 {
 // Epilogue features of the sliding-halo kernel, compile-time: the off-phase of the generic (run-time flags) version
 // spent most of its ~4.3k cycles on scalar bookkeeping -- 200 spilled SGPRs (v_readlane), kernel arguments re-read
 // from memory behind s_waitcnt lgkmcnt(0), branches around features the launch did not use.
-enum : int { SG_EP_SIGN = 1, SG_EP_MASK = 2, SG_EP_PN = 4, SG_EP_POOL = 8 };
+enum : int { SG_EP_SIGN = 1, SG_EP_MASK = 2, SG_EP_PN = 4, SG_EP_POOL = 8, SG_EP_PNB = 16 };
 #ifndef SG_V3S_RING
 #define SG_V3S_RING 6   // fragment ring of the MFMA phase: reads run RING - 2 steps (of 1-2 MFMAs) ahead of their use
 #endif
@@ -1183,8 +1185,8 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   constexpr int RINGB = 4 * PB;
   constexpr uint32_t DEAD = 0x80000000u;             // byte offset beyond every buffer: loads return 0, stores drop
   constexpr bool SIGN = (EPI & SG_EP_SIGN) != 0, MASK = (EPI & SG_EP_MASK) != 0, PN = (EPI & SG_EP_PN) != 0,
-                 POOL = (EPI & SG_EP_POOL) != 0;
-  static_assert(!(PN && POOL) && !(KS == 1 && EPI != 0), "unsupported epilogue combination");
+                 POOL = (EPI & SG_EP_POOL) != 0, PNB = (EPI & SG_EP_PNB) != 0;
+  static_assert(!(PN && POOL) && !(KS == 1 && EPI != 0) && !(PNB && (PN || POOL || SIGN || KS != 0)), "unsupported epilogue combination");
   const sg_tile_geom& g = a.g;                       // TN=1, TD=2, TH=4, TW=32, HD=4, HH=6, HW=34 (host-checked)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1327,7 +1329,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   };
   // ---- output side (cursor E): per-column resources, validity and voxel origin
   Cur E{0, 0, 0, 0, 0};
-  __amdgpu_buffer_rsrc_t ryE, rsE, rmE, rpE;
+  __amdgpu_buffer_rsrc_t ryE, rsE, rmE, rpE, rbE, rqE;
   int colvoxE = 0;
   bool row_okE = false;
   auto enter_column_E = [&]() {
@@ -1338,6 +1340,10 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
     if (SIGN) rsE = rsrc_of(a.sign_out, wsb, E.n0);
     if (MASK) rmE = rsrc_of(a.mask_bits, wsb, E.n0);
     if (PN) rpE = rsrc_of(a.pn_scale, psb, E.n0);
+    if (PNB) {
+      rbE = rsrc_of(a.pnb_y, ysb, E.n0);
+      rqE = rsrc_of(a.pnb_scale, psb, E.n0);
+    }
   };
   // LeakyReLU sign words of E's tile (masked epilogue): requested at the END of an off-phase, like the halo planes, and
   // used in the next one.  Requested at the top of the off-phase that applies them, their latency (2-3k cycles under
@@ -1431,6 +1437,20 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
     if (MASK) asm volatile("" : "+v"(mb[0]), "+v"(mb[1]));
     // K-split second pass: the first pass's f32 partial sums of the tile about to be stored (held across the MFMA
     // phase they would not fit beside the accumulators, the planes in flight and the fragment ring)
+    // pixel-norm backward epilogue: the stage's output at my two voxels (2 x 16 bytes each: the row pieces the plain
+    // epilogue would store) and its rsqrt factor, requested here and used after the planes have been written
+    u32x4 yraw[PNB ? 2 : 1][PNB ? 2 : 1];
+    float pscale[2] = {0.f, 0.f};
+    if constexpr (PNB) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          yraw[mt][j] = __builtin_amdgcn_raw_buffer_load_b128(rbE, okE[mt] ? yvo[mt] + (uint32_t)((16 * j + 8 * hh) * 2) : DEAD,
+                                                              tile_vox * (uint32_t)(cout * ES), 0);
+        pscale[mt] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rqE, okE[mt] ? svo[mt] : DEAD, tile_vox * 4u, 0));
+      }
+    }
     f32x4 part[KS == 2 ? 2 : 1][KS == 2 ? 4 : 1];
     if constexpr (KS == 2) {
       const __amdgpu_buffer_rsrc_t ra = rsrc_of(a.addend, svox * cout * 4, E.n0);
@@ -1496,6 +1516,29 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
             const auto sw2 = __builtin_amdgcn_permlane32_swap(b, b, false, false);
             __builtin_amdgcn_raw_buffer_store_b32(sw2[0] | sw2[1], rsE, (okE[mt] && hh == 0) ? svo[mt] : DEAD,
                                                   tile_vox * (uint32_t)(ntile * 4), 0);
+          }
+          if constexpr (PNB) {
+            // d/dx of y = x * s, s = rsqrt(mean_c(x^2) + eps):  s * (g - y * mean_c(g * y)); the accumulator holds g.
+            // y arrives as the 16-byte row pieces of the store layout: undo the half-wave exchange of the store path
+            float yv[16];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const auto t0 = __builtin_amdgcn_permlane32_swap(yraw[mt][j][0], yraw[mt][j][2], false, false);
+              const auto t1 = __builtin_amdgcn_permlane32_swap(yraw[mt][j][1], yraw[mt][j][3], false, false);
+              const uint32_t pk[4] = {t0[0], t1[0], t0[1], t1[1]};     // channel pairs of acc[8j + 0..7]
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                yv[8 * j + 2 * k] = __uint_as_float(pk[k] << 16);
+                yv[8 * j + 2 * k + 1] = __uint_as_float(pk[k] & 0xFFFF0000u);
+              }
+            }
+            float dot = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dot = fmaf(acc[mt][i], yv[i], dot);
+            const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(dot), __float_as_uint(dot), false, false);
+            const float mean = (__uint_as_float(sw2[0]) + __uint_as_float(sw2[1])) * inv_c;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][i] = pscale[mt] * fmaf(-yv[i], mean, acc[mt][i]);
           }
           if (MASK && !(a.dbg_flags & 256)) sg_apply_sign_word(acc[mt], mb[mt], hh, a.mask_slope);
           if (!POOL) {
@@ -1628,6 +1671,8 @@ static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
   if (a.pool && ((s->d & 1) || (s->h & 1) || a.pixel_norm || a.mask_bits || KS != 0)) return SG_OK;
   if (a.pixel_norm && (a.mask_bits || KS == 1 || a.ntile != 1)) return SG_OK;
   if (a.mask_bits && a.sign_out) return SG_OK;
+  if (a.pnb_y && (KS != 0 || GC != 2 || a.ntile != 1 || !a.mask_bits || a.pixel_norm || a.pool || a.sign_out || a.bias || a.act ||
+                  !a.pnb_scale)) return SG_OK;
   a.g = sg_make_geom(s, 256, /*prefer_w32=*/true, /*td=*/2, /*th=*/4);
   const sg_tile_geom& g = a.g;
   if (g.TN != 1 || g.TD != 2 || g.TH != 4 || g.TW != 32 || g.HD != 4 || g.HH != 6 || g.HW != 34 || g.nTd < 2) return SG_OK;
@@ -1646,7 +1691,7 @@ static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
   a.vec_in = 1;
   a.vec_out = 1;
   const int epi = (a.sign_out ? SG_EP_SIGN : 0) | (a.mask_bits ? SG_EP_MASK : 0) | (a.pixel_norm ? SG_EP_PN : 0) |
-                  (a.pool ? SG_EP_POOL : 0);
+                  (a.pool ? SG_EP_POOL : 0) | (a.pnb_y ? SG_EP_PNB : 0);
   int rc = SG_OK;
   if constexpr (KS == 1) {
     if constexpr (GC == 2) { if (s->upsample_in) rc = launch_fwd3s_inst<GC, 1, 0, true>(a, (unsigned)gx, lds, st); else rc = launch_fwd3s_inst<GC, 1, 0>(a, (unsigned)gx, lds, st); }
@@ -1680,6 +1725,9 @@ static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
       case SG_EP_PN | SG_EP_SIGN: rc = launch_fwd3s_inst<GC, 0, SG_EP_PN | SG_EP_SIGN>(a, (unsigned)gx, lds, st); break;
       case SG_EP_SIGN | SG_EP_POOL: rc = launch_fwd3s_inst<GC, 0, SG_EP_SIGN | SG_EP_POOL>(a, (unsigned)gx, lds, st); break;
       case SG_EP_POOL: rc = launch_fwd3s_inst<GC, 0, SG_EP_POOL>(a, (unsigned)gx, lds, st); break;
+      case SG_EP_MASK | SG_EP_PNB:
+        if constexpr (GC == 2) { rc = launch_fwd3s_inst<GC, 0, SG_EP_MASK | SG_EP_PNB>(a, (unsigned)gx, lds, st); break; }
+        else return SG_OK;
       default: return SG_OK;
     }
   }
@@ -2808,6 +2856,9 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
   a.tap_d = ep ? ep->tap_off[0] : 0; a.tap_h = ep ? ep->tap_off[1] : 0; a.tap_w = ep ? ep->tap_off[2] : 0;
   a.pool = ep ? ep->pool : 0;
   if (a.pool < 0 || a.pool > 2) return SG_EINVAL;
+  a.pnb_y = ep ? ep->pn_bwd_y : nullptr;
+  a.pnb_scale = ep ? ep->pn_bwd_scale : nullptr;
+  if ((a.pnb_y != nullptr) != (a.pnb_scale != nullptr) || (a.pnb_y && !sg_aligned16(a.pnb_y))) return SG_EINVAL;
   a.xcs = s->cin; a.xco = 0; a.addend = nullptr;
   a.os = (ep && ep->out_scale == 2) ? 2 : 1;
   a.oa = ep ? ep->out_off[0] : 0; a.ob = ep ? ep->out_off[1] : 0; a.oc = ep ? ep->out_off[2] : 0;
@@ -2840,6 +2891,11 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
   if (a.pool && (subpixel || dt != SG_BF16 || sg_cfg().fwd_v1 || (s->cin * 2) % 16 != 0 || a.pixel_norm ||
                  (a.pool == 1 && (sg_cfg().fwd_no_v3 || sg_cfg().fwd_no_v3s)) || (a.pool == 2 && sg_cfg().fwd_no_v5)))
     return SG_EUNSUPPORTED;
+  // the pixel-norm backward epilogue exists in the sliding-halo kernel only
+  if (a.pnb_y && (subpixel || dt != SG_BF16 || sg_cfg().fwd_v1 || sg_cfg().fwd_no_v3 || sg_cfg().fwd_no_v3s || a.pool ||
+                  a.pixel_norm || (s->cin * 2) % 16 != 0 || s->kd != 3 || s->kh != 3 || s->kw != 3 || s->upsample_in ||
+                  (ep && ep->x_plane_channels)))
+    return SG_EUNSUPPORTED;
   if (a.pool == 2) {   // H x W pooling: the streamed kernel's tile (two H rows per wave)
     bool used = false;
     rc = launch_fwd5(a, s, hs, &used);
@@ -2847,7 +2903,7 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     prof.done(rc);
     return rc;
   }
-  if (!sg_cfg().fwd_no_pw && !a.pool) {   // streaming kernels for the 1x1x1 layers with <= 4 channels on one side
+  if (!sg_cfg().fwd_no_pw && !a.pool && !a.pnb_y) {   // streaming kernels for the 1x1x1 layers with <= 4 channels on one side
     bool used = false;
     rc = dt == SG_BF16 ? launch_pw_fwd<bf16_t>(a, s, hs, &used) : launch_pw_fwd<float>(a, s, hs, &used);
     if (rc != SG_OK || used) { prof.done(rc); return rc; }
@@ -2863,7 +2919,7 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     rc = SG_OK;
     const bool k333 = s->kd == 3 && s->kh == 3 && s->kw == 3, k133 = s->kd == 1 && s->kh == 3 && s->kw == 3;
     if (dt == SG_BF16 && k333 && !sg_cfg().fwd_no_v3s && !sg_cfg().fwd_no_ksplit && a.nchunk == 4 && a.ntile == 1 && s->cin == 64 &&
-        !a.pool && !(a.mask_bits && a.sign_out) && !(a.pixel_norm && a.mask_bits) && ep && ep->workspace &&
+        !a.pool && !a.pnb_y && !(a.mask_bits && a.sign_out) && !(a.pixel_norm && a.mask_bits) && ep && ep->workspace &&
         ep->workspace_bytes >= (size_t)s->n * s->d * s->h * s->w * (size_t)s->cout * 4 && sg_aligned16(ep->workspace)) {
       // K split: 64 input channels as two sliding-halo passes over 32 channels each (resident weights, a 64-byte
       // half of every 128-byte channel row fetched ONCE per pass) with the f32 partial sums in the caller's workspace.
@@ -2899,7 +2955,7 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
       else if (a.nchunk == 1) rc = launch_fwd3s<1>(a, s, hs, &used);
       if (rc != SG_OK || used) { prof.done(rc); return rc; }
     }
-    if (a.pool) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }   // only the sliding-halo kernel pools
+    if (a.pool || a.pnb_y) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }   // only the sliding-halo kernel has these
     if (dt == SG_BF16) {
       if (k333 && a.nchunk == 2) rc = launch_fwd3r<bf16_t, 2, 2, 3, 3, 3>(a, s, hs, &used);
       else if (k333 && a.nchunk == 1) rc = launch_fwd3r<bf16_t, 2, 1, 3, 3, 3>(a, s, hs, &used);

@@ -186,11 +186,13 @@ def _raw_upconv_subpixel(x, w, coef, bias, act, slope, pixel_norm, eps, want_sca
 
 
 def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel_norm=False, eps=1e-8,
-             want_scale=False, mask_bits=None, mask_slope=0.0, want_signs=False, pool=False):
+             want_scale=False, mask_bits=None, mask_slope=0.0, want_signs=False, pool=False, pn_bwd=None):
     """y = epilogue(conv3d(x, coef*w)) with w in DHWIO; `flip` selects the data-gradient weights.
     Returns (y, pixel-norm scale or None, sign words of y or None).  pool (sg_conv_epilogue.pool): 1 -- y is the
     2 x 1 x 2 (D x H x W) block mean of the output, [n,cout,d/2,h,w/2]; 2 -- the 1 x 2 x 2 block mean, [n,cout,d,h/2,w/2];
-    returns None if no kernel of the build fuses it here."""
+    returns None if no kernel of the build fuses it here.  pn_bwd = (y, scale) of a pixel-norm stage: the result is
+    pushed through that stage's backward in the epilogue (sg_conv_epilogue.pn_bwd_y; mask_bits = the stage's sign words);
+    None if no kernel does that for this layer."""
     lib = _lib.load()
     _req_cuda(x, w, bias)
     x = ndhwc(x)
@@ -226,12 +228,17 @@ def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel
     ep = ConvEpilogue(_ptr(b32), 1 if act else 0, float(slope), 1 if pixel_norm else 0, float(eps), _ptr(scale),
                       _ptr(mask_bits), float(mask_slope), _ptr(signs))
     ep.pool = pool
+    if pn_bwd is not None:
+        pn_y, pn_scale = ndhwc(pn_bwd[0]), pn_bwd[1]
+        if tuple(pn_y.shape) != tuple(y.shape) or pn_y.dtype != y.dtype or pn_scale.numel() != n * d * h * wd:
+            raise ValueError('pn_bwd: y / scale do not match the convolution output')
+        ep.pn_bwd_y, ep.pn_bwd_scale = pn_y.data_ptr(), pn_scale.data_ptr()
     ws_bytes = lib.sg_conv3d_fwd_workspace(C.byref(shp), dt)
     if ws_bytes and not pool:      # scratch for the library's two-pass (K-split) path of this layer
         ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
         ep.workspace, ep.workspace_bytes = ws.data_ptr(), ws_bytes
     rc = lib.sg_conv3d_fwd(_ptr(x), _ptr(wp), _ptr(y), C.byref(shp), C.byref(ep), dt, st)
-    if pool and rc == _lib.SG_EUNSUPPORTED:
+    if (pool or pn_bwd is not None) and rc == _lib.SG_EUNSUPPORTED:
         return None
     check(rc, 'sg_conv3d_fwd')
     return y, scale, signs
@@ -325,6 +332,8 @@ class ActInfo:
     def __init__(self, slope):
         self.slope = float(slope)
         self.bits = None          # sign words of `a`, written by the producing conv's epilogue
+        self.pn = None            # (y, scale) when the stage goes on through pixel_norm: y = pixel_norm(a); consumers that
+        #                           registered as premask then apply the pixel-norm backward as well (_dgrad_into)
         self.n_consumers = 0
         self.n_premask = 0
 
@@ -339,6 +348,35 @@ class ActInfo:
 
 def _masked_in(ctx_info):
     return ctx_info is not None and ctx_info.all_premask()
+
+
+_NO_PN_EPILOGUE = bool(int(os.environ.get('SARAGAN_NO_PN_EPILOGUE', '0')))   # diagnostic: pixel-norm backward as its own pass
+
+
+def pn_bwd_epilogue_available(prod_shape, kernel, fmaps, dtype):
+    """Whether the data gradient of conv3d(y, [*kernel, c, fmaps]) can apply the backward of the pixel-norm stage that
+    produced y in its epilogue (sg_conv_epilogue.pn_bwd_y: sliding-halo kernel, bf16, 3x3x3, 32 channels on both sides,
+    32-wide rows).  Decided from the shapes when the graph is built; a launch the library declines after all runs the two
+    passes inside the consumer (_dgrad_into)."""
+    if _NO_PN_EPILOGUE or dtype != torch.bfloat16 or len(prod_shape) != 5 or tuple(kernel) != (3, 3, 3):
+        return False
+    n, c, d, h, w = prod_shape
+    return c == 32 and fmaps == 32 and w % 32 == 0 and d >= 4 and n * ((h + 3) // 4 + 1) // 2 * (w // 32) >= 256
+
+
+def _dgrad_into(info, g, w, coef, flip):
+    """Data gradient of a convolution for an input that is the output of a stage whose backward this consumer has
+    registered to apply (ActInfo.all_premask): the LeakyReLU mask in the epilogue, and for a pixel-norm stage its whole
+    backward (sg_conv_epilogue.pn_bwd_y) -- the producer then skips its own pass."""
+    if info.pn is None:
+        return _Conv.apply(g, w, coef, flip, False, None, info.bits, info.slope)
+    if torch.is_grad_enabled():
+        raise NotImplementedError('second-order gradient through pixel_norm is not part of the pgan step')
+    res = raw_conv(g, w, coef, flip, mask_bits=info.bits, mask_slope=info.slope, pn_bwd=info.pn)
+    if res is not None:
+        return res[0]
+    gy = raw_conv(g, w, coef, flip)[0]          # the library declined (shape): the two passes, here
+    return _PnActBwd.apply(gy, info.pn[0], info.pn[1], info.bits, info.slope, False)[0]
 
 
 class BackInfo:
@@ -414,7 +452,7 @@ class _Conv(torch.autograd.Function):
             elif ctx.x_back is not None and ctx.x_back.all_premask():
                 gx = _Conv.apply(gy, w, ctx.coef, not ctx.flip, False, None, ctx.x_back.bits, ctx.x_back.slope)
             elif _masked_in(ctx.in_info):
-                gx = _Conv.apply(gy, w, ctx.coef, not ctx.flip, False, None, ctx.in_info.bits, ctx.in_info.slope)
+                gx = _dgrad_into(ctx.in_info, gy, w, ctx.coef, not ctx.flip)
             else:
                 gx = _Conv.apply(gy, w, ctx.coef, not ctx.flip, False)
         if _wants(ctx, 1, w.data_ptr()):
@@ -464,6 +502,7 @@ class _ConvBiasAct(torch.autograd.Function):
                                    eps=eps, want_scale=True, want_signs=act and not _NO_SIGN_WORDS)
         if out_info is not None:
             out_info.bits = signs
+            out_info.pn = (y, scale) if pixel_norm else None
         ctx.save_for_backward(x, w, y if (pixel_norm or (act and signs is None)) else None, scale, signs)
         ctx.cfg = (coef, ups, act, slope, pixel_norm)
         ctx.has_b = b is not None
@@ -479,7 +518,9 @@ class _ConvBiasAct(torch.autograd.Function):
         want_db = ctx.has_b and _wants(ctx, 2, ctx.b_ptr)
         gb = None
         fused_pn_act = pixel_norm and act and signs is not None
-        if fused_pn_act:
+        if fused_pn_act and _masked_in(ctx.out_info):
+            pass        # every consumer pushed its share of gy through this stage's backward already (_dgrad_into)
+        elif fused_pn_act:
             g, gb = _PnActBwd.apply(g, y.detach(), scale, signs, slope, want_db)
             if not want_db:
                 gb = None
@@ -501,7 +542,7 @@ class _ConvBiasAct(torch.autograd.Function):
             if ups:
                 gx = _upconv_dgrad(g, w, coef, True)
             elif _masked_in(ctx.in_info):
-                gx = _Conv.apply(g, w, coef, True, False, None, ctx.in_info.bits, ctx.in_info.slope)
+                gx = _dgrad_into(ctx.in_info, g, w, coef, True)
             else:
                 gx = _Conv.apply(g, w, coef, True, False)
         if _wants(ctx, 1, w.data_ptr()):
@@ -624,7 +665,7 @@ class _ConvPnActToRgb(torch.autograd.Function):
             if ups:
                 gx = _upconv_dgrad(g, w, coef, True)
             elif _masked_in(ctx.in_info):
-                gx = raw_conv(g, w, coef, True, False, mask_bits=ctx.in_info.bits, mask_slope=ctx.in_info.slope)[0]
+                gx = _dgrad_into(ctx.in_info, g, w, coef, True)
             else:
                 gx = raw_conv(g, w, coef, True, False)[0]
         if _wants(ctx, 1, ctx.ptrs[0]):
@@ -675,7 +716,7 @@ class _ConvBiasActPool(torch.autograd.Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             if _masked_in(ctx.in_info):
-                gx = _Conv.apply(g, w, coef, True, False, None, ctx.in_info.bits, ctx.in_info.slope)
+                gx = _dgrad_into(ctx.in_info, g, w, coef, True)
             else:
                 gx = _Conv.apply(g, w, coef, True, False)
         if _wants(ctx, 1, w.data_ptr()):

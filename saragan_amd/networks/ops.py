@@ -56,7 +56,7 @@ class _LazyConv:
 
     def value(self):
         if self._v is None:
-            out_info = self.act_info if (self.act and not self.pn) else None
+            out_info = self.act_info if self.act else None
             self._v = F.conv3d(self.x, self.w, self.coef, bias=self.bias, act=self.act, slope=self.slope,
                                pixel_norm=self.pn, eps=self.eps, upsample_in=self.ups, out_info=out_info,
                                in_info=self.in_info)
@@ -80,6 +80,7 @@ class _LazyRgbTail(_LazyConv):
         if self._v is None:
             p = self.prod
             if p._v is None and not self.act and not self.pn:
+                p.act_info = None      # this node applies the stage's backward itself: no consumer may register for it
                 self._v, p._v = F.conv3d_pn_to_rgb(p.x, p.w, p.coef, p.bias, p.ups, p.slope, p.eps, p.in_info,
                                                    self.w, self.coef, self.bias)
             else:      # the stage was materialised by another consumer first, or the tail grew an epilogue of its own
@@ -88,11 +89,14 @@ class _LazyRgbTail(_LazyConv):
         return self._v
 
 
-def _consume(x, premask=False):
+def _consume(x, premask=False, pn_ok=False):
     """Materialises a handle for one consumer and returns (tensor, ActInfo-or-None).  `premask` says that this
-    consumer applies the producer's LeakyReLU-backward mask inside its own backward kernel (F.ActInfo)."""
+    consumer applies the producer's LeakyReLU-backward mask inside its own backward kernel (F.ActInfo); for a stage that
+    goes on through pixel_norm it must also be able to apply that backward (`pn_ok`, F.pn_bwd_epilogue_available)."""
     if isinstance(x, _LazyConv):
-        info = x.act_info if (x.act and not x.pn) else None
+        info = x.act_info if x.act else None
+        if x.pn:
+            premask = premask and pn_ok
         if info is not None:
             info.consume(premask)
         return x.value(), (info if premask else None)
@@ -241,7 +245,8 @@ def conv3d(x, fmaps, kernel, activation, param=None, lrmul=1):
     if ups:
         xin, in_info = x.x, None
     else:
-        xin, in_info = _consume(x, premask=True)
+        pn_ok = isinstance(x, _LazyConv) and x.pn and F.pn_bwd_epilogue_available(tuple(x.shape), kernel, fmaps, compute_dtype())
+        xin, in_info = _consume(x, premask=True, pn_ok=pn_ok)
     w = get_weight([*kernel, cin, fmaps], activation, param=param, lrmul=lrmul)
     if xin.dtype != compute_dtype():
         xin, in_info = xin.to(compute_dtype()), None

@@ -899,3 +899,102 @@ def test_from_rgb_backward_in_one_pass(dtype, cin, monkeypatch):
     assert used == [True]
     for name, a, r in zip(('dx', 'dw', 'db'), got, sep):
         _mostly_close(a, r, rt, at, name + ' vs separate kernels')
+
+
+def test_pixel_norm_backward_in_the_data_gradient_epilogue():
+    """The data-gradient conv whose result is the gradient for a pixel-norm stage's output applies that stage's backward
+    (pixel norm + LeakyReLU mask) in its epilogue (sg_conv_epilogue.pn_bwd_y): against the two separate passes, conv then
+    sg_pixel_norm_act_bwd, which round the intermediate to bf16 once more, and against the oracle's arithmetic."""
+    from saragan_amd import functional as F
+    dtype = torch.bfloat16
+    n, c, sp = 2, 32, (6, 128, 256)
+    g = cl(rnd((n, c, *sp), 131, dtype), dtype)                    # gradient arriving at the NEXT conv's output
+    w = rnd((3, 3, 3, c, c), 132, dtype).float().to(dev())          # the next conv's weights (its data gradient: flip)
+    y = cl(rnd((n, c, *sp), 133, dtype), dtype)                    # the stage's output
+    scale = (torch.rand(n * sp[0] * sp[1] * sp[2], generator=torch.Generator().manual_seed(134)) + 0.5).to(dev())
+    signs = F.sign_words(cl(rnd((n, c, *sp), 135, dtype), dtype))
+    coef = 0.05
+    fused = F.raw_conv(g, w, coef, True, mask_bits=signs, mask_slope=0.2, pn_bwd=(y, scale))
+    assert fused is not None, 'the epilogue did not engage'
+    gy = F.raw_conv(g, w, coef, True)[0]
+    two, _ = F._PnActBwd.apply(gy, y, scale, signs, 0.2, False)
+    ref = gy.double()
+    yd = y.double()
+    exact = scale.double().view(n, 1, *sp) * (ref - yd * (ref * yd).mean(dim=1, keepdim=True))
+    exact = torch.where(F_bits(signs, n, c, sp), exact * 0.2, exact)
+    err_f = float((fused[0].double() - exact).abs().max() / exact.abs().max())
+    err_t = float((two.double() - exact).abs().max() / exact.abs().max())
+    assert err_f <= 1.5e-2 and err_t <= 1.5e-2, (err_f, err_t)
+    # refused where no kernel has the epilogue (f32 storage), not mis-computed
+    assert F.raw_conv(g.float(), w, coef, True, mask_bits=signs, mask_slope=0.2, pn_bwd=(y.float(), scale)) is None
+
+
+def F_bits(words, n, c, sp):
+    """bool [n,c,d,h,w]: bit (ch % 32) of sign word [n,d,h,w,ch // 32]."""
+    wv = words.view(n, *sp, (c + 31) // 32).long() & 0xFFFFFFFF
+    ch = torch.arange(c, device=words.device)
+    bits = (wv[..., ch // 32] >> (ch % 32)) & 1
+    return bits.permute(0, 4, 1, 2, 3).bool()
+
+
+def test_two_generator_stages_pixel_norm_backward_fused_into_the_data_gradient(monkeypatch):
+    """Two stacked generator stages through networks.ops (conv -> bias -> LeakyReLU -> pixel_norm, twice,
+    pgan/generator.py:33-45): the second conv registers for the first stage's backward and applies it in the epilogue of
+    its data gradient (sg_conv_epilogue.pn_bwd_y); the first stage skips its own pass and takes the bias gradient from
+    the weight-gradient kernel.  Every gradient against the oracle; and the same graph with the epilogue disabled."""
+    from saragan_amd import functional as F
+    from saragan_amd import varstore
+    from saragan_amd.networks import ops
+    dtype = torch.bfloat16
+    n, cin, c, sp = 2, 16, 32, (4, 128, 256)
+    x = rnd((n, cin, *sp), 141, dtype)
+    monkeypatch.setitem(varstore.COMPUTE_DTYPE, 'dtype', dtype)
+    used = []
+    real = F.raw_conv
+
+    def spy(*a, **kw):
+        r = real(*a, **kw)
+        if kw.get('pn_bwd') is not None:
+            used.append(r is not None)
+        return r
+    monkeypatch.setattr(F, 'raw_conv', spy)
+
+    def run(store):
+        xg = cl(x, dtype).requires_grad_(True)
+        with varstore.use_store(store), varstore.variable_scope('g'):
+            h = xg
+            for name in ('c1', 'c2'):
+                with varstore.variable_scope(name):
+                    h = ops.pixel_norm(ops.act(ops.apply_bias(ops.conv3d(h, c, (3, 3, 3), 'leaky_relu', 0.2)), 'leaky_relu', 0.2))
+            y = ops.materialize(h)
+        names = ['g/c1/weight', 'g/c1/bias', 'g/c2/weight', 'g/c2/bias']
+        leaves = [xg] + [store.vars[k] for k in names]
+        return y, leaves, names
+
+    store = varstore.VariableStore(dev(), seed=5)
+    y, leaves, names = run(store)
+    gy = rnd(tuple(y.shape), 142, dtype)
+    got = torch.autograd.grad(y, leaves, cl(gy, dtype))
+    assert used == [True], 'the pixel-norm backward epilogue was not used'
+    # oracle on the same (rounded) weights
+    ws = {k: store.vars[k].detach().double().cpu() for k in names}
+    lr = [x.clone().requires_grad_(True)]
+    hr = lr[0]
+    for nm in ('c1', 'c2'):
+        w = ws[f'g/{nm}/weight']
+        coef = O.runtime_coef(w.shape, 'leaky_relu', 0.2)
+        wq = ((w * coef).to(dtype).double() / coef).requires_grad_(True)
+        b = ws[f'g/{nm}/bias'].clone().requires_grad_(True)
+        lr += [wq, b]
+        hr = O.pixel_norm(O.act(O.apply_bias(O.conv3d(hr, wq, 'leaky_relu', 0.2), b), 'leaky_relu', 0.2))
+    close(y, hr, dtype, 'two stages')
+    ref = torch.autograd.grad(hr, lr, gy)
+    for name, a, r in zip(['dx'] + names, got, ref):
+        _mostly_close(a, r, 3e-2, 3e-2, name, max_bad=5e-3)
+    # the same graph with the stage's own pass: same gradients to bf16 rounding of one intermediate
+    monkeypatch.setattr(F, '_NO_PN_EPILOGUE', True)
+    y2, leaves2, _ = run(store)
+    sep = torch.autograd.grad(y2, leaves2, cl(gy, dtype))
+    assert used == [True]
+    for name, a, r in zip(['dx'] + names, got, sep):
+        _mostly_close(a, r, 3e-2, 3e-2, name + ' vs separate pass', max_bad=5e-3)

@@ -84,7 +84,8 @@ class _LazyRgbTail(_LazyConv):
                 self._v, p._v = F.conv3d_pn_to_rgb(p.x, p.w, p.coef, p.bias, p.ups, p.slope, p.eps, p.in_info,
                                                    self.w, self.coef, self.bias)
             else:      # the stage was materialised by another consumer first, or the tail grew an epilogue of its own
-                self._v = F.conv3d(p.value(), self.w, self.coef, bias=self.bias, act=self.act, slope=self.slope,
+                # (registered as an ordinary consumer: an earlier consumer may have signed up for the stage's backward)
+                self._v = F.conv3d(_consume(p, False)[0], self.w, self.coef, bias=self.bias, act=self.act, slope=self.slope,
                                    pixel_norm=self.pn, eps=self.eps)
         return self._v
 

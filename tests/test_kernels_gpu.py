@@ -998,3 +998,47 @@ def test_two_generator_stages_pixel_norm_backward_fused_into_the_data_gradient(m
     assert used == [True]
     for name, a, r in zip(['dx'] + names, got, sep):
         _mostly_close(a, r, 3e-2, 3e-2, name + ' vs separate pass', max_bad=5e-3)
+
+
+@pytest.mark.parametrize('rgb_first', [False, True])
+def test_pixel_norm_stage_with_a_conv_and_a_to_rgb_consumer(monkeypatch, rgb_first):
+    """A pixel-norm stage read by the next 3x3x3 conv FIRST (which signs up for the stage's backward) and by to_rgb
+    afterwards (an ordinary consumer, as during a mixing phase): nobody may skip the stage's own backward then.
+    Gradients against the oracle."""
+    from saragan_amd import varstore
+    from saragan_amd.networks import ops
+    dtype = torch.bfloat16
+    n, cin, c, sp = 2, 16, 32, (4, 128, 256)
+    x = rnd((n, cin, *sp), 151, dtype)
+    monkeypatch.setitem(varstore.COMPUTE_DTYPE, 'dtype', dtype)
+    store = varstore.VariableStore(dev(), seed=6)
+    xg = cl(x, dtype).requires_grad_(True)
+    with varstore.use_store(store), varstore.variable_scope('g'):
+        with varstore.variable_scope('c1'):
+            h1 = ops.pixel_norm(ops.act(ops.apply_bias(ops.conv3d(xg, c, (3, 3, 3), 'leaky_relu', 0.2)), 'leaky_relu', 0.2))
+        if rgb_first:       # to_rgb meets the unmaterialised stage: one node for both; the conv reads its second output
+            with varstore.variable_scope('rgb'):
+                img = ops.materialize(ops.to_rgb(h1, 1))
+        with varstore.variable_scope('c2'):
+            h2 = ops.materialize(ops.apply_bias(ops.conv3d(h1, c, (3, 3, 3), 'linear')))
+        if not rgb_first:
+            with varstore.variable_scope('rgb'):
+                img = ops.materialize(ops.to_rgb(h1, 1))
+    names = ['g/c1/weight', 'g/c1/bias', 'g/c2/weight', 'g/c2/bias', 'g/rgb/weight', 'g/rgb/bias']
+    leaves = [xg] + [store.vars[k] for k in names]
+    g2, gi = rnd(tuple(h2.shape), 152, dtype), rnd(tuple(img.shape), 153, dtype)
+    got = torch.autograd.grad([h2, img], leaves, [cl(g2, dtype), cl(gi, dtype)])
+    ws = {k: store.vars[k].detach().double().cpu() for k in names}
+
+    def q(w, act):
+        coef = O.runtime_coef(w.shape, act, 0.2 if act == 'leaky_relu' else None)
+        return ((w * coef).to(dtype).double() / coef).requires_grad_(True)
+    lr = [x.clone().requires_grad_(True), q(ws[names[0]], 'leaky_relu'), ws[names[1]].clone().requires_grad_(True),
+          q(ws[names[2]], 'linear'), ws[names[3]].clone().requires_grad_(True), q(ws[names[4]], 'linear'),
+          ws[names[5]].clone().requires_grad_(True)]
+    r1 = O.pixel_norm(O.act(O.apply_bias(O.conv3d(lr[0], lr[1], 'leaky_relu', 0.2), lr[2]), 'leaky_relu', 0.2))
+    r2 = O.apply_bias(O.conv3d(r1, lr[3], 'linear', None), lr[4])
+    ri = O.apply_bias(O.conv3d(r1, lr[5], 'linear', None), lr[6])
+    ref = torch.autograd.grad([r2, ri], lr, [g2, gi])
+    for name, a, r in zip(['dx'] + names, got, ref):
+        _mostly_close(a, r, 3e-2, 3e-2, name, max_bad=5e-3)

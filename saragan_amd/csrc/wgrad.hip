@@ -542,6 +542,7 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a) {
   for (int p = 0; p <= K; ++p) {
     if ((p & 1) == grp) {
       if (p < K) {
+#pragma unroll
         for (int run = 0; run < KSTEPS; ++run) {               // 16 consecutive tile voxels = one K step
           const uint32_t m0 = (uint32_t)run * 16u;
           const uint32_t q1 = sg_div(m0, g.fTW);

@@ -71,26 +71,53 @@ def parse():
 # N > 1 without a launcher: spawn the ranks (this process never touches a GPU)
 # -----------------------------------------------------------------------------------------------------
 def spawn_ranks(args):
+    """The parent only counts devices and starts children; it never initialises a GPU context it would keep, and it
+    never replaces its own program.  Children are polled: the first non-zero exit (a rank that died in start-up or in
+    its first collective) ends the others instead of leaving them in rendezvous until the distributed timeout, and an
+    overall deadline bounds the wait."""
     import socket
-    import torch   # device_count() does not initialise the GPU
+    import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    stack = bool(int(os.environ.get('SARAGAN_BENCH_STACK_RANKS', '0')))    # rehearsal: several ranks share one GPU (gloo)
+    if have < args.gpus and not (stack and have >= 1):
         print(f'bench.py: --gpus {args.gpus} but only {have} device(s) are visible', file=sys.stderr)
         return 3
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     procs = []
+    out0 = tempfile.TemporaryFile(mode='w+')
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
-    line = [ln for ln in (out0 or '').splitlines() if ln.startswith('{')]
-    if any(codes) or not line:
-        print(f'bench.py: rank exit codes {codes}', file=sys.stderr)
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    deadline = time.time() + float(os.environ.get('SARAGAN_BENCH_DEADLINE_S', '1500'))
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        failed = [c for c in codes if c not in (None, 0)]
+        if failed or time.time() > deadline:
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.terminate()
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    try:
+                        codes[i] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill()
+                        codes[i] = p.wait()
+            why = 'a rank failed' if failed else 'deadline passed'
+            print(f'bench.py: {why}; rank exit codes {codes}', file=sys.stderr)
+            return 1
+        time.sleep(0.2)
+    out0.seek(0)
+    line = [ln for ln in out0.read().splitlines() if ln.startswith('{')]
+    if not line:
+        print(f'bench.py: rank 0 printed no result line; rank exit codes {codes}', file=sys.stderr)
         return 1
     rec = json.loads(line[-1])
     if rec.get('n_gpus') != args.gpus:
@@ -187,7 +214,10 @@ def conv_flops_per_volume(ks, fs, phase, base_shape, latent, dims=3):
     shapes = pgan_variable_shapes(phase, base_shape, latent, ks, fs)
 
     def vox(level):
-        return int(np.prod([s * 2 ** (level - 1) for s in base_shape[1:]]))
+        sp = [s * 2 ** (level - 1) for s in base_shape[1:]]
+        if dims == 2:
+            sp[0] = 1            # images are D == 1 volumes at every level: only H and W grow (SURFGAN_2D)
+        return int(np.prod(sp))
     fg = fd = 0.0
     for name, shp in shapes.items():
         if not name.endswith('weight'):
@@ -359,10 +389,7 @@ def main():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     device = torch.device('cuda', local % max(1, torch.cuda.device_count()))   # (rehearsals may stack ranks on one GPU)
     torch.cuda.set_device(device)
-    comm = None
-    if world > 1:
-        dist = torch.distributed
-        comm = dict(backend=dist.get_backend(), world_size=dist.get_world_size())
+    comm = parallel.collective_info() if world > 1 else None     # backend, RCCL version, communicator size, bucket algorithm
     cfg = build(args, device, args.dtype)
     sess, ph = cfg['sess'], cfg['ph']
     batches = [synthetic_batch(cfg['shape'], rank * 1000 + i, device) for i in range(4)]
@@ -512,12 +539,43 @@ def main():
         def step32(i):
             cfg32['sess'].run(cfg32['train'], feed_dict={cfg32['ph']: b32[i % 2]})
             cfg32['sess'].run(cfg32['ema_op'])
-        step32(0)
-        n32 = 3
+        for i in range(5):           # warm-up; then two calibration steps with every conv launch bracketed, as above
+            step32(i)
+        barrier()
+        lib.sg_prof_enable(1)
+        for i in range(ncal):
+            step32(i)
+        barrier()
+        tab32 = collect()
+        lib.sg_prof_enable(0)
+        by32 = {}
+        for e in tab32:
+            by32[e.kernel] = by32.get(e.kernel, 0.0) + e.total_ms
+        dom32 = next((e for e in tab32 if e.kernel == max(by32, key=by32.get)), None) if by32 else None
+        if dom32 is not None:
+            lib.sg_prof_set_filter(dom32.kind, C.byref(dom32.shape))
+        lib.sg_prof_enable(1)
+        n32 = max(10, args.steps // 2)
         dt32 = timed_steps(step32, n32, barrier)
+        timed32 = collect()
+        lib.sg_prof_enable(0)
+        lib.sg_prof_set_filter(0, None)
+        roof32 = None
+        if timed32 and timed32[0].launches > 0:
+            b_ = timed32[0]
+            avg32 = b_.total_ms / b_.launches
+            ach32 = b_.flops_per_launch / (avg32 * 1e-3) / 1e12
+            s_ = b_.shape
+            roof32 = dict(bound='mfma', achieved=round(ach32, 2), peak=157.3, unit='TFLOP/s', frac=round(ach32 / 157.3, 4),
+                          traffic=None, kernel=b_.kernel.decode(),
+                          shape=dict(n=s_.n, d=s_.d, h=s_.h, w=s_.w, cin=s_.cin, cout=s_.cout, k=[s_.kd, s_.kh, s_.kw],
+                                     upsample_in=s_.upsample_in),
+                          launches=int(b_.launches), avg_ms=round(avg32, 4), flops_per_launch=b_.flops_per_launch)
         extras['f32'] = dict(value=round(args.batch * n32 / dt32, 3), ms_per_step=round(dt32 / n32 * 1e3, 3), steps=n32,
-                             step_mfma_tflops=round(args.batch * n32 / dt32 * step_gf / 1e3, 2), peak_tflops=157.3,
-                             note='same workload, fp32 storage and v_mfma_f32_32x32x2_f32 (1/16 of the bf16 MFMA rate)')
+                             warmup=5 + ncal, step_mfma_tflops=round(args.batch * n32 / dt32 * step_gf / 1e3, 2),
+                             peak_tflops=157.3, roofline=roof32,
+                             note='same workload, fp32 storage and v_mfma_f32_32x32x2_f32 (1/16 of the bf16 MFMA rate): '
+                                  'the reference\'s own arithmetic (ops.py:147-150)')
         out['extras'] = extras
         cfg = cfg32
     if world == 1 and not args.no_cpu_baseline:

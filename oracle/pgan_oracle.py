@@ -33,6 +33,88 @@ Params = Dict[str, torch.Tensor]
 
 
 # ----------------------------------------------------------------------------------------------
+# bf16 emulation: the HIP path's storage rounding restated (a checker for the bf16 build; not a reference behaviour)
+# ----------------------------------------------------------------------------------------------
+# The bf16 build keeps activations, their gradients and the packed coef*w in bf16 and accumulates in f32.  Against the
+# plain fp64 oracle that moves ~0.3 % of the LeakyReLU masks, so single gradient tensors differ by 5-20 % for a reason
+# that is not a kernel error -- and a tolerance that wide cannot see one.  Inside `bf16_emulation()` this oracle rounds
+# to bf16 at the points where the HIP path stores a tensor (listed at each `_q` call below, with the product's
+# file:function that stores it) and takes every mask from the same values the kernels see; what is left between the two
+# is accumulation order.  Gradients are rounded where they are stored as tensors (`_Q.backward`), weight gradients stay
+# f32 (`_QW` is straight-through: the wgrad kernels write f32, saragan_amd/functional.py:raw_wgrad).
+_EMU = {'on': False}
+
+
+class bf16_emulation:
+    def __enter__(self):
+        self.prev = _EMU['on']
+        _EMU['on'] = True
+        return self
+
+    def __exit__(self, *a):
+        _EMU['on'] = self.prev
+
+
+def _round_bf16(x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+
+class _Q(torch.autograd.Function):
+    """A tensor stored in bf16; the gradient that arrives for it is a stored bf16 tensor too."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return _round_bf16(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Q.apply(g)
+
+
+class _QW(torch.autograd.Function):
+    """coef*w as the packed weight image holds it (sg_conv3d_pack_weights); its gradient is the f32 wgrad output."""
+
+    @staticmethod
+    def forward(ctx, w):
+        return _round_bf16(w)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def _q(x):
+    return _Q.apply(x) if _EMU['on'] else x
+
+
+def hip_pool_mode(n, cin, cout, d, h, w, k):
+    """Which 2x2x2-pooling fusion the bf16 HIP path uses for downscale3d(leaky_relu(conv3d + b)) of this shape
+    (restates saragan_amd/functional.py:_pool_mode; checked against it in tests/test_oracle.py): 1 = the conv epilogue
+    stores D x W pair means and a second kernel pools H, 2 = H x W pairs then D, 0 = the activation is stored and pooled."""
+    if tuple(k) != (3, 3, 3) or (d | h | w) & 1 or w % 32:
+        return 0
+    nvox = n * d * h * w
+    if cin <= 32 and cin % 8 == 0 and cout % 32 == 0 and d >= 4 and nvox >= (1 << 20):
+        return 1
+    if cin % 16 == 0 and cout % 64 == 0 and nvox >= (1 << 18):
+        return 2
+    return 0
+
+
+def _downscale_stored(y, cin, k):
+    """downscale3d of a LeakyReLU output `y` (not yet stored), with the bf16 path's rounding points."""
+    if not _EMU['on'] or _TWO_D['on']:
+        return downscale3d(_q(y))
+    n, cout, d, h, w = y.shape
+    mode = hip_pool_mode(n, cin, cout, d, h, w, k)
+    if mode == 1:
+        return _q(F.avg_pool3d(_q(F.avg_pool3d(y, (2, 1, 2))), (1, 2, 1)))
+    if mode == 2:
+        return _q(F.avg_pool3d(_q(F.avg_pool3d(y, (1, 2, 2))), (2, 1, 1)))
+    return _q(downscale3d(_q(y)))
+
+
+# ----------------------------------------------------------------------------------------------
 # networks/ops.py
 # ----------------------------------------------------------------------------------------------
 def k_rule(x: int) -> int:
@@ -69,7 +151,10 @@ def conv3d(x: torch.Tensor, w: torch.Tensor, activation: str, param=None) -> tor
     cross-correlation with zero padding k//2 per side for odd k (SURVEY Appendix D)."""
     kd, kh, kw = w.shape[:3]
     assert kd % 2 == 1 and kh % 2 == 1 and kw % 2 == 1, "SAME == k//2 only for odd kernels"
-    wt = (w * runtime_coef(w.shape, activation, param)).permute(4, 3, 0, 1, 2)
+    wt = w * runtime_coef(w.shape, activation, param)
+    if _EMU['on']:
+        wt = _QW.apply(wt)
+    wt = wt.permute(4, 3, 0, 1, 2)
     return F.conv3d(x, wt, padding=(kd // 2, kh // 2, kw // 2))
 
 
@@ -77,7 +162,10 @@ def dense(x: torch.Tensor, w: torch.Tensor, activation: str, param=None) -> torc
     """networks/ops.py:139-144.  Flatten is C-major of NCDHW (tf.reshape of an NCDHW tensor)."""
     if x.dim() > 2:
         x = x.reshape(x.shape[0], -1)
-    return x @ (w * runtime_coef(w.shape, activation, param))
+    wt = w * runtime_coef(w.shape, activation, param)
+    if _EMU['on'] and w.shape[1] != 1:      # the one-unit logit layer runs in f32 (saragan_amd/networks/ops.py:dense)
+        wt = _QW.apply(wt)
+    return x @ wt
 
 
 def apply_bias(x: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -295,25 +383,33 @@ def generator(p: Params, z, alpha, phase, base_shape, activation, kernel_spec, f
         raise NotImplementedError()
     g = 'generator/'
     fs = filter_spec
-    x = dense(z, p[g + 'generator_in/dense/weight'], activation, param)
-    x = act(apply_bias(x, p[g + 'generator_in/dense/bias']), activation, param)
+    # _q: the tensors the bf16 HIP path stores -- each fused conv + bias + LeakyReLU + pixel-norm launch writes its result
+    # once (saragan_amd/networks/ops.py:_LazyConv.value); above 128 channels pixel_norm is a pass of its own
+    # (networks/ops.py:pixel_norm) and the activation is stored in between
+    def pn_stored(a):
+        return _q(pixel_norm(a if a.shape[1] <= 128 else _q(a)))
+
+    x = dense(_q(z), p[g + 'generator_in/dense/weight'], activation, param)
+    x = _q(act(apply_bias(x, p[g + 'generator_in/dense/bias']), activation, param))
     x = x.reshape(-1, _spec(fs, 0, 0), *base_shape[1:])
     x = conv3d(x, p[g + 'generator_in/conv/weight'], activation, param)
-    x = pixel_norm(act(apply_bias(x, p[g + 'generator_in/conv/bias']), activation, param))
+    x = pn_stored(act(apply_bias(x, p[g + 'generator_in/conv/bias']), activation, param))
     x_upsample = None
     for i in range(2, phase + 1):
-        if i == phase:
+        if i == phase and not (_EMU['on'] and float(alpha) == 0.0):     # (pruned at alpha = 0: networks/ops.py:lerp)
             t = conv3d(x, p[g + f'to_rgb_{phase - 1}/weight'], 'linear')
-            x_upsample = upscale3d(apply_bias(t, p[g + f'to_rgb_{phase - 1}/bias']))
+            x_upsample = upscale3d(_q(apply_bias(t, p[g + f'to_rgb_{phase - 1}/bias'])))
         b = g + f'generator_block_{i}/'
         x = upscale3d(x)
         x = conv3d(x, p[b + 'conv_1/weight'], activation, param)
-        x = pixel_norm(act(apply_bias(x, p[b + 'conv_1/bias']), activation, param))
+        x = pn_stored(act(apply_bias(x, p[b + 'conv_1/bias']), activation, param))
         x = conv3d(x, p[b + 'conv_2/weight'], activation, param)
-        x = pixel_norm(act(apply_bias(x, p[b + 'conv_2/bias']), activation, param))
-    x_out = apply_bias(conv3d(x, p[g + f'to_rgb_{phase}/weight'], 'linear'), p[g + f'to_rgb_{phase}/bias'])
+        x = pn_stored(act(apply_bias(x, p[b + 'conv_2/bias']), activation, param))
+    x_out = _q(apply_bias(conv3d(x, p[g + f'to_rgb_{phase}/weight'], 'linear'), p[g + f'to_rgb_{phase}/bias']))
     if x_upsample is not None:
-        x_out = alpha * x_upsample + (1 - alpha) * x_out
+        if _EMU['on'] and float(alpha) == 1.0:
+            return x_upsample
+        x_out = _q(alpha * x_upsample + (1 - alpha) * x_out)
     return x_out
 
 
@@ -325,23 +421,26 @@ def discriminator(p: Params, x, alpha, phase, latent_dim, activation, kernel_spe
     d = 'discriminator/'
     x_downscale = x
     x = conv3d(x, p[d + f'from_rgb_{phase}/weight'], activation, param)
-    x = act(apply_bias(x, p[d + f'from_rgb_{phase}/bias']), activation, param)
+    x = _q(act(apply_bias(x, p[d + f'from_rgb_{phase}/bias']), activation, param))
     for i in reversed(range(2, phase + 1)):
         b = d + f'discriminator_block_{i}/'
         x = conv3d(x, p[b + 'conv_1/weight'], activation, param)
-        x = act(apply_bias(x, p[b + 'conv_1/bias']), activation, param)
+        x = _q(act(apply_bias(x, p[b + 'conv_1/bias']), activation, param))
+        cin = x.shape[1]
         x = conv3d(x, p[b + 'conv_2/weight'], activation, param)
         x = act(apply_bias(x, p[b + 'conv_2/bias']), activation, param)
-        x = downscale3d(x)
+        x = _downscale_stored(x, cin, p[b + 'conv_2/weight'].shape[:3])     # (the fused tail: functional._ConvBiasActPool)
         if i == phase:
-            t = conv3d(downscale3d(x_downscale), p[d + f'from_rgb_{phase - 1}/weight'], activation, param)
-            t = act(apply_bias(t, p[d + f'from_rgb_{phase - 1}/bias']), activation, param)
-            x = alpha * t + (1 - alpha) * x
+            if _EMU['on'] and float(alpha) == 0.0:      # the faded-out branch is pruned (networks/ops.py:lerp)
+                continue
+            t = conv3d(_q(downscale3d(x_downscale)), p[d + f'from_rgb_{phase - 1}/weight'], activation, param)
+            t = _q(act(apply_bias(t, p[d + f'from_rgb_{phase - 1}/bias']), activation, param))
+            x = t if (_EMU['on'] and float(alpha) == 1.0) else _q(alpha * t + (1 - alpha) * x)
     x = conv3d(x, p[d + 'discriminator_out/weight'], activation, param)
-    x = act(apply_bias(x, p[d + 'discriminator_out/bias']), activation, param)
+    x = _q(act(apply_bias(x, p[d + 'discriminator_out/bias']), activation, param))
     x = dense(x, p[d + 'discriminator_out/dense_1/weight'], activation, param)
-    x = act(apply_bias(x, p[d + 'discriminator_out/dense_1/bias']), activation, param)
-    x = dense(x, p[d + 'discriminator_out/dense_2/weight'], 'linear')
+    x = _q(act(apply_bias(x, p[d + 'discriminator_out/dense_1/bias']), activation, param))
+    x = dense(x, p[d + 'discriminator_out/dense_2/weight'], 'linear')      # f32 logits (networks/ops.py:dense)
     return apply_bias(x, p[d + 'discriminator_out/dense_2/bias'])
 
 
@@ -482,18 +581,37 @@ def forward_simultaneous(p: Params, real, z, noise_real, noise_fake, gamma, alph
     generator, discriminator = ARCHS[arch][:2]      # networks.<arch> (optuna_objective.py:64-65)
     _TWO_D['on'] = bool(two_d)
     gen_sample = generator(p, z, alpha, base_shape=base_shape, **net)
-    real_n = real + noise_real * noise_stddev
-    fake_n = gen_sample + noise_fake * noise_stddev
-    disc_fake_d = discriminator(p, fake_n.detach(), alpha, latent_dim=latent_dim, **net)
-    disc_real = discriminator(p, real_n, alpha, latent_dim=latent_dim, **net)
-    interpolates = (gamma * real_n + (1 - gamma) * fake_n.detach()).requires_grad_(True)
+    if _EMU['on']:
+        # saragan_amd/networks/loss.py: images and noise enter in bf16, sg_axpby adds in f32 and stores bf16; the
+        # interpolates are torch bf16 arithmetic (every op rounds); with the wgan loss D(real) and D(fake) are ONE pass
+        # over the concatenated batch (forward_simultaneous, `link`), which is what decides the pooling fusion per layer
+        real_n = _q(_q(real) + _q(noise_real) * noise_stddev)
+        fake_n = _q(gen_sample + _q(noise_fake) * noise_stddev)
+        gq = _q(gamma)
+        interpolates = _q(_q(gq * real_n) + _q(_q(1 - gq) * fake_n.detach())).detach().requires_grad_(True)
+        if loss_fn == 'wgan':
+            both = discriminator(p, torch.cat([real_n, fake_n], dim=0), alpha, latent_dim=latent_dim, **net)
+            disc_real, disc_fake_g = both[:real.shape[0]], both[real.shape[0]:]
+            disc_fake_d = disc_fake_g
+        else:
+            disc_fake_g = discriminator(p, fake_n, alpha, latent_dim=latent_dim, **net)
+            disc_fake_d = disc_fake_g
+            disc_real = discriminator(p, real_n, alpha, latent_dim=latent_dim, **net)
+    else:
+        real_n = real + noise_real * noise_stddev
+        fake_n = gen_sample + noise_fake * noise_stddev
+        disc_fake_d = discriminator(p, fake_n.detach(), alpha, latent_dim=latent_dim, **net)
+        disc_real = discriminator(p, real_n, alpha, latent_dim=latent_dim, **net)
+        interpolates = (gamma * real_n + (1 - gamma) * fake_n.detach()).requires_grad_(True)
     d_int = discriminator(p, interpolates, alpha, latent_dim=latent_dim, **net)
     (gradients,) = torch.autograd.grad(d_int.sum(), interpolates, create_graph=True)
+    gradients = _q(gradients)       # (emulation: from_rgb's data gradient is a stored bf16 tensor)
     if two_d:
         slopes = torch.sqrt(torch.sum(gradients * gradients, dim=(1, 2, 3, 4))).reshape(-1, 1)
     else:
         slopes = torch.sqrt(torch.sum(gradients * gradients, dim=(1, 2, 3)))
-    disc_fake_g = discriminator(p, fake_n, alpha, latent_dim=latent_dim, **net)
+    if not _EMU['on']:
+        disc_fake_g = discriminator(p, fake_n, alpha, latent_dim=latent_dim, **net)
     if loss_fn == 'wgan':
         gp_loss = gp_weight * (slopes - 1) ** 2
         disc_loss = disc_fake_d - disc_real
@@ -699,10 +817,12 @@ def step_simultaneous(p: Params, adam_g: TFAdam, adam_d: TFAdam, shadow: Optiona
         fz = set(freeze)
         gnames = [k for k in gnames if k not in fz]
         dnames = [k for k in dnames if k not in fz]
-    g_grads = torch.autograd.grad(gen_loss, [work[k] for k in gnames], retain_graph=True)
-    d_grads = torch.autograd.grad(disc_loss, [work[k] for k in dnames])
-    g_grads = dict(zip(gnames, [g.detach() for g in g_grads]))
-    d_grads = dict(zip(dnames, [g.detach() for g in d_grads]))
+    # (allow_unused: under bf16_emulation the faded-out branch of alpha = 0 is pruned as in the product; tf.gradients
+    # delivers zeros for its variables either way)
+    g_grads = torch.autograd.grad(gen_loss, [work[k] for k in gnames], retain_graph=True, allow_unused=_EMU['on'])
+    d_grads = torch.autograd.grad(disc_loss, [work[k] for k in dnames], allow_unused=_EMU['on'])
+    g_grads = {k: (g.detach() if g is not None else torch.zeros_like(work[k])) for k, g in zip(gnames, g_grads)}
+    d_grads = {k: (g.detach() if g is not None else torch.zeros_like(work[k])) for k, g in zip(dnames, d_grads)}
     if g_clipping:
         g_grads, _ = clip_by_global_norm(g_grads)
     if d_clipping:

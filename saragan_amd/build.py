@@ -15,7 +15,9 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-u
 # (v_pk_mul_f32 / v_pk_add_f32, which the SLP vectoriser forms from the epilogues' per-element arithmetic) were measured at
 # ~110 cycles EACH there -- they queue behind the matrix pipe -- against 4-8 for the scalar forms: a 32-element masked
 # epilogue took 4.3k cycles instead of 0.7k (tools/ts_conv.py, SG_DBG_FLAGS=128|256).  No SLP in those two files.
-FILE_FLAGS = {'conv3d.hip': ['-fno-slp-vectorize'], 'wgrad.hip': ['-fno-slp-vectorize']}
+# -save-temps=obj: the device assembly of exactly the code that ships (build/<name>-hip-amdgcn-amd-amdhsa-gfx950.s) is kept
+# for tests/test_build_resources.py, which checks the hand-counted `s_waitcnt lgkmcnt(N)` regions of the unrolled K loops.
+FILE_FLAGS = {'conv3d.hip': ['-fno-slp-vectorize', '-save-temps=obj'], 'wgrad.hip': ['-fno-slp-vectorize', '-save-temps=obj']}
 
 
 def _hipcc():
@@ -23,6 +25,14 @@ def _hipcc():
     if c:
         return c
     return '/opt/rocm/bin/hipcc' if os.path.exists('/opt/rocm/bin/hipcc') else 'hipcc'
+
+
+def device_asm(source):
+    """Path of the gfx950 assembly hipcc kept for `source` (conv3d.hip / wgrad.hip), building if it is not there."""
+    path = os.path.join(HERE, 'build', source.replace('.hip', '') + '-hip-amdgcn-amd-amdhsa-gfx950.s')
+    if not os.path.exists(path) or needs_build():
+        build(force=True, verbose=False)
+    return path
 
 
 def needs_build():
@@ -34,7 +44,7 @@ def needs_build():
 
 
 RESOURCES = os.path.join(HERE, 'build', 'resource_usage.json')
-_REMARK = re.compile(r'remark:\s+(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|'
+_REMARK = re.compile(r'remark:\s+(?:\S+:\d+:\d+:\s+)?(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|'
                      r'SGPRs Spill|VGPRs Spill|LDS Size \[bytes/block\]):\s+(\S+)')
 _KEYS = {'TotalSGPRs': 'sgprs', 'VGPRs': 'vgprs', 'AGPRs': 'agprs', 'ScratchSize [bytes/lane]': 'scratch_bytes',
          'Occupancy [waves/SIMD]': 'occupancy', 'SGPRs Spill': 'sgpr_spill', 'VGPRs Spill': 'vgpr_spill',
@@ -82,6 +92,10 @@ def build(force=False, verbose=True):
         if verbose and any('warning' in ln or 'error' in ln for ln in rest):
             sys.stderr.write('\n'.join(rest) + '\n')
         usage[s] = parse_resource_remarks(text)
+    for f_ in os.listdir(os.path.join(HERE, 'build')):      # of the saved temporaries only the device assembly is kept
+        if f_.endswith(('.bc', '.hipi', '.out', '.hipfb', '.resolution.txt', '-unknown-linux-gnu.s')) or \
+                f_.endswith('-gfx950.o'):
+            os.unlink(os.path.join(HERE, 'build', f_))
     with open(RESOURCES, 'w') as f:
         json.dump(usage, f, indent=1, sort_keys=True)
     cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs

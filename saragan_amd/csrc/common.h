@@ -111,6 +111,14 @@ __device__ __forceinline__ void sg_mfma_drain(f32x16 (&acc)[N]) {
   static_assert(N == 2, "extend the operand list");
   asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc[0]), "+v"(acc[1]));
 }
+// The unrolled K loops below issue their LDS fragment reads and (bf16) their MFMAs through inline asm and synchronise them
+// with hand-counted `s_waitcnt lgkmcnt(N > 0)`: that count is only right while NOTHING else that lgkmcnt counts (LDS,
+// SMEM -- which returns out of order --, s_memtime, messages) is outstanding when the prologue starts or is emitted by the
+// compiler inside the loop.  SG_KLOOP_BEGIN drains the counter first; the assembler comments delimit the region for
+// tests/test_build_resources.py, which disassembles the build and fails on any compiler-emitted LGKM instruction between
+// them and on any instruction of the compiler's that touches an accumulator of the tied MFMAs before the drain.
+#define SG_KLOOP_BEGIN() asm volatile("; SG_KLOOP_BEGIN\n\ts_waitcnt lgkmcnt(0)")
+#define SG_KLOOP_END() asm volatile("; SG_KLOOP_END")
 template <>
 __device__ __forceinline__ f32x16 sg_mfma_chunk<float>(u32x4 a, u32x4 b, f32x16 c) {
   f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);

@@ -680,8 +680,10 @@ struct sg_unrolled_k {
   }
   static __device__ __forceinline__ void run(f32x16 (&acc)[MTW], u32x4 (&wfr)[RING], u32x4 (&xfr)[RING][MTW],
                                              const int (&xaddr)[NA], int wl_off) {
+    SG_KLOOP_BEGIN();
     prologue<0>(wfr, xfr, xaddr, wl_off);
     step<0>(acc, wfr, xfr, xaddr, wl_off);
+    SG_KLOOP_END();
   }
 };
 
@@ -729,8 +731,10 @@ struct sg_unrolled_k4 {
   }
   static __device__ __forceinline__ void run(f32x16 (&acc)[MTW][NTB], const int (&xaddr)[NA], int wl_off) {
     u32x4 wfr[RING][NTB], xfr[RING][MTW];
+    SG_KLOOP_BEGIN();
     prologue<0>(wfr, xfr, xaddr, wl_off);
     step<0>(acc, wfr, xfr, xaddr, wl_off);
+    SG_KLOOP_END();
   }
 };
 
@@ -1102,8 +1106,10 @@ struct sg_unrolled_ks {
   }
   static __device__ __forceinline__ void run(f32x16 (&acc)[2], const int (&xa)[9][GC], int wl_off) {
     u32x4 wfr[RING], xfr[RING][2];
+    SG_KLOOP_BEGIN();
     prologue<0>(wfr, xfr, xa, wl_off);
     step<0>(acc, wfr, xfr, xa, wl_off);
+    SG_KLOOP_END();
   }
 };
 
@@ -1155,9 +1161,11 @@ struct sg_unrolled_ks2 {
   static __device__ __forceinline__ void run(f32x16 (&acc)[2], const int (&xa)[9][GC], int wl_off) {
     static_assert(sizeof(T) == 2, "bf16 only");
     u32x4 wfr[RING], xfr[RING];
+    SG_KLOOP_BEGIN();
     prologue<0>(wfr, xfr, xa, wl_off);
     step<0>(acc, wfr, xfr, xa, wl_off);
     sg_mfma_drain(acc);
+    SG_KLOOP_END();
   }
 };
 
@@ -2180,9 +2188,11 @@ struct sg_unrolled_k5 {   // one step = one tap: 2 weight + 2 activation fragmen
   }
   static __device__ __forceinline__ void run(f32x16 (&acc)[2][2], const int (&xaddr)[NA], int wl_off) {
     u32x4 wfr[RING][2], xfr[RING][2];
+    SG_KLOOP_BEGIN();
     prologue<0>(wfr, xfr, xaddr, wl_off);
     step<0>(acc, wfr, xfr, xaddr, wl_off);
     asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]));   // MFMA result hazard
+    SG_KLOOP_END();
   }
 };
 

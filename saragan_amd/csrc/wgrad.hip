@@ -698,8 +698,10 @@ struct sg_wgrad_tile {
   }
   static __device__ __forceinline__ void run(const Ctx& c, f32x16 (&acc)[MAXT]) {
     frag_t a0[RING], a1[RING], b0[2], b1[2];
+    SG_KLOOP_BEGIN();
     prologue<0>(c, a0, a1, b0, b1);
     step<0>(c, acc, a0, a1, b0, b1);
+    SG_KLOOP_END();
   }
 };
 
@@ -1006,8 +1008,10 @@ struct sg_wgrad_tile_lean {
   }
   static __device__ __forceinline__ void run(const Ctx& c, f32x16 (&acc)[MAXT]) {
     frag_t a0[RING], a1[RING], b0[2], b1[2];
+    SG_KLOOP_BEGIN();
     prologue<0>(c, a0, a1, b0, b1);
     step<0>(c, acc, a0, a1, b0, b1);
+    SG_KLOOP_END();
   }
 };
 

@@ -311,8 +311,8 @@ class StepGraph:
         flat, ranges, names = info['flat'], info['ranges'], info['names']
         gscale = 1.0
         if info['dist'] is not None:
-            info['dist'].finish()              # waits for the bucketed all-reduces (sum)
-            gscale = 1.0 / info['dist'].world_size
+            info['dist'].finish()              # waits for the bucketed reductions
+            gscale = info['dist'].grad_scale   # 1 / world after a SUM (the average is folded into the update kernel)
         if tr['clipping'] or ('max_norm', tid) in self._wanted:
             if 'bounds' not in tr:
                 offs = flat['offsets']
@@ -324,7 +324,11 @@ class StepGraph:
             if tr['clipping']:                 # tf.clip_by_global_norm(gradients, 1.0), optimization.py:66-67
                 scale = 1.0 / torch.clamp(torch.sqrt(sq.sum()), min=1.0)
                 out[('max_norm', tid)] = torch.sqrt(sq).max() * scale
-                gscale = float(scale) * gscale
+                # the clip factor stays on the device (reading it back would stall the host every step): the gradients
+                # are scaled in place, which also makes the returned `gradients` the clipped ones, as the reference's are
+                for (o, n) in ranges:
+                    flat['grad'][o:o + n].mul_(scale * gscale)
+                gscale = 1.0
             else:
                 out[('max_norm', tid)] = torch.sqrt(sq).max()
         out[('gradients', tid)] = [self.store.vars[n].grad for n in names]

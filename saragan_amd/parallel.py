@@ -7,7 +7,12 @@ CPU for tests).  Replaces the reference's Horovod usage on the hot path:
   MPI scatter of file lists (dataset.py:307-333) -> a shared-seed permutation each rank slices (dataset.py).
 xGMI is point-to-point (7 links per GPU): large buckets amortise the ring's latency, but the bucket that becomes
 ready LAST is exposed (the generator's parameter-heavy low-resolution layers finish its backward), so the default
-is 32 MiB (SARAGAN_BUCKET_MIB overrides); the whole gradient of a small network still goes out as one message."""
+is 32 MiB (SARAGAN_BUCKET_MIB overrides); the whole gradient of a small network still goes out as one message.
+SARAGAN_DP_ALGO selects how a bucket is summed: "allreduce" (default: one dist.all_reduce, RCCL picks the algorithm) or
+"rs_ag" (reduce-scatter then all-gather issued by hand -- on a fully connected xGMI node each of the two is one direct
+exchange over all 7 links; offered so that the first 8-GPU run can A/B it against RCCL's own choice).
+hvd.DistributedOptimizer(op=hvd.Adasum) (optuna_objective.py:180-183, the discriminator under --use_adasum) ->
+AdasumReducer."""
 import os
 
 import torch
@@ -69,6 +74,13 @@ class GradientAllReducer:
         self.group = group
         self.bucket_elems = max(1, bucket_bytes // 4)
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.algo = os.environ.get('SARAGAN_DP_ALGO', 'allreduce')
+        if self.algo not in ('allreduce', 'rs_ag'):
+            raise ValueError(f'SARAGAN_DP_ALGO must be "allreduce" or "rs_ag", got {self.algo!r}')
+        # in-order queues (RCCL: every collective of a group runs on that group's stream in issue order) let the
+        # all-gather be issued right behind its reduce-scatter; other backends (gloo) get an explicit wait in between
+        self._ordered = dist.is_initialized() and dist.get_backend(group) == 'nccl'
         self._hooked = {}
         self._plan_key = None
         self._buckets = []
@@ -118,11 +130,37 @@ class GradientAllReducer:
                 if id(p) not in reach:
                     self._hook(p)
 
+    @property
+    def grad_scale(self):
+        """What the summed buffer still has to be multiplied with to become Horovod's average."""
+        return 1.0 / self.world_size
+
     def _launch(self, b):
         b['launched'] = True
         if self.world_size > 1:
             view = self._flat[b['off']:b['off'] + b['len']]
-            self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            if self.algo == 'rs_ag':
+                self._launch_rs_ag(view)
+            else:
+                self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _launch_rs_ag(self, view):
+        """The same sum as all_reduce(view), as reduce-scatter + all-gather in place: rank r reduces the r-th of `world`
+        equal chunks into its own slot of the bucket, then every rank gathers all slots.  A tail that does not divide by
+        the world size (< world elements) goes through a plain all_reduce."""
+        w = self.world_size
+        chunk = view.numel() // w
+        if chunk:
+            body = view[:chunk * w]
+            mine = body[self.rank * chunk:(self.rank + 1) * chunk]
+            h = dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            if not self._ordered:
+                h.wait()
+            else:
+                self._handles.append(h)
+            self._handles.append(dist.all_gather_into_tensor(body, mine, group=self.group, async_op=True))
+        if view.numel() > chunk * w:
+            self._handles.append(dist.all_reduce(view[chunk * w:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _hook(self, p):
         if not self._armed:
@@ -162,11 +200,95 @@ class GradientAllReducer:
         return out
 
 
-def DistributedOptimizer(optimizer, group=None, bucket_bytes=None, op=None):
-    """hvd.DistributedOptimizer(optimizer): gradients are averaged over ranks before they are applied.
-    (`op` is accepted for the reference's Adasum call site, optuna_objective.py:182-183, and ignored.)"""
-    optimizer.distributed = GradientAllReducer(group, bucket_bytes)
+Average, Adasum = 'Average', 'Adasum'      # hvd.Average / hvd.Adasum
+
+
+def adasum_pair(a, b, seg, nseg):
+    """Adasum of two gradient vectors, per tensor (Horovod 0.19 `ops/adasum/adasum.h`, third-party and not in the
+    reference tree: restated from the published rule, Maleki et al. 2020):
+        a' = (1 - <a,b> / (2 |a|^2)) a + (1 - <a,b> / (2 |b|^2)) b       per tensor; a coefficient stays 1 where the norm is ~0.
+    `seg` maps every element of the flat vectors to its tensor's index (alignment padding has a segment of its own)."""
+    dot = torch.zeros(nseg, device=a.device, dtype=torch.float64).index_add_(0, seg, (a * b).double())
+    na = torch.zeros(nseg, device=a.device, dtype=torch.float64).index_add_(0, seg, (a * a).double())
+    nb = torch.zeros(nseg, device=a.device, dtype=torch.float64).index_add_(0, seg, (b * b).double())
+    one = torch.ones_like(dot)
+    ca = torch.where(na >= 1e-8, 1.0 - dot / (2.0 * na.clamp_min(1e-30)), one).to(a.dtype)
+    cb = torch.where(nb >= 1e-8, 1.0 - dot / (2.0 * nb.clamp_min(1e-30)), one).to(a.dtype)
+    return ca[seg] * a + cb[seg] * b
+
+
+class AdasumReducer(GradientAllReducer):
+    """hvd.DistributedOptimizer(optimizer, op=hvd.Adasum) (optuna_objective.py:182-183): the ranks' gradients are
+    combined by the Adasum rule along a binary tree (ranks (0,1), (2,3), ... first, then pairs of pairs) instead of
+    being averaged.  Here every rank gathers all gradients (one all_gather of the flat buffer: 8 x 116 MB for the largest
+    discriminator of the presets) and evaluates the tree locally, so all ranks hold bit-identical results; the world
+    size must be a power of two, as Horovod requires.  Not overlapped with backward (the rule needs whole tensors)."""
+
+    def __init__(self, group=None, bucket_bytes=None):
+        super().__init__(group, bucket_bytes)
+        if self.world_size & (self.world_size - 1):
+            raise ValueError(f'Adasum needs a power-of-two number of ranks, got {self.world_size}')
+        self._seg_key = None
+
+    @property
+    def grad_scale(self):
+        return 1.0
+
+    def begin(self, flat_grad, ranges, params, roots=None):
+        self._flat, self._ranges, self._params = flat_grad, list(ranges), list(params)
+        self._armed = False
+
+    def _segments(self, lo, hi):
+        key = (self._flat.data_ptr(), lo, hi, len(self._params))
+        if key != self._seg_key:
+            base = self._flat.data_ptr()
+            seg = torch.full((hi - lo,), len(self._params), dtype=torch.int64)
+            for i, p in enumerate(self._params):
+                off = (p.grad.data_ptr() - base) // 4 - lo
+                seg[off:off + p.numel()] = i
+            self._seg, self._nseg, self._seg_key = seg.to(self._flat.device), len(self._params) + 1, key
+        return self._seg, self._nseg
+
+    def finish(self):
+        if self.world_size == 1 or not self._ranges:
+            return
+        lo = min(o for o, _ in self._ranges)
+        hi = max(o + n for o, n in self._ranges)
+        mine = self._flat[lo:hi]
+        allg = torch.empty(self.world_size * (hi - lo), device=mine.device, dtype=mine.dtype)
+        dist.all_gather_into_tensor(allg, mine.contiguous(), group=self.group)
+        allg = allg.view(self.world_size, hi - lo)
+        seg, nseg = self._segments(lo, hi)
+        level = [allg[r] for r in range(self.world_size)]
+        while len(level) > 1:
+            level = [adasum_pair(level[i], level[i + 1], seg, nseg) for i in range(0, len(level), 2)]
+        mine.copy_(level[0])
+
+
+def DistributedOptimizer(optimizer, group=None, bucket_bytes=None, op=Average):
+    """hvd.DistributedOptimizer(optimizer, op=hvd.Average | hvd.Adasum): gradients are averaged over ranks (or combined
+    by Adasum) before they are applied."""
+    if op in (None, Average):
+        optimizer.distributed = GradientAllReducer(group, bucket_bytes)
+    elif op == Adasum:
+        optimizer.distributed = AdasumReducer(group, bucket_bytes)
+    else:
+        raise ValueError(f'unknown reduction op {op!r} (Average or Adasum)')
     return optimizer
+
+
+def collective_info(group=None):
+    """What bench.py records as config.collective: backend, library version and communicator size."""
+    if not dist.is_initialized():
+        return None
+    info = dict(backend=dist.get_backend(group), world_size=dist.get_world_size(group),
+                algo=os.environ.get('SARAGAN_DP_ALGO', 'allreduce'))
+    if info['backend'] == 'nccl':
+        try:
+            info['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:      # pragma: no cover - informational only
+            info['rccl_version'] = f'unavailable ({type(e).__name__})'
+    return info
 
 
 def broadcast_global_variables(store, root_rank=0, group=None):

@@ -87,9 +87,10 @@ def run_training(args, device=None, max_steps_per_phase=None, log_every=1):
                                     args.g_lr_decrease, args.g_lr_rise_niter, args.g_lr_decay_niter)
         update_d_lr = opt.lr_update(d_lr, intra_phase_step, steps_per_phase, args.d_lr, args.d_lr_increase,
                                     args.d_lr_decrease, args.d_lr_rise_niter, args.d_lr_decay_niter)
-        if horovod:
+        if horovod:      # optuna_objective.py:179-186: --use_adasum switches the DISCRIMINATOR's reduction only
             optimizer_gen = parallel.DistributedOptimizer(optimizer_gen)
-            optimizer_disc = parallel.DistributedOptimizer(optimizer_disc)
+            optimizer_disc = parallel.DistributedOptimizer(
+                optimizer_disc, op=parallel.Adasum if getattr(args, 'use_adasum', False) else parallel.Average)
 
         alpha = ScalarVariable(1, 'alpha/alpha')
         update_alpha = nops.alpha_update(alpha, args.mixing_nimg, args.starting_alpha, batch_size, global_size)

@@ -123,3 +123,34 @@ def bf16_gradient_report(groups, w_rel=0.30, w_cos=0.95, net_cos=0.98, net_norm=
             if v.key.endswith('weight') and (e > w_rel or c < w_cos):
                 bad.append((v.key, report[v.key]))
     return report, bad
+
+
+def bf16_emulated_step(p0, rnd, real, alpha, cfg, freeze=None, dtype=torch.float64):
+    """One `simultaneous` step of the oracle with the bf16 HIP path's storage rounding restated
+    (oracle.pgan_oracle.bf16_emulation): the reference the bf16 build is held to tightly."""
+    p = {k: v.to(dtype).clone() for k, v in p0.items()}
+    with O.bf16_emulation():
+        return O.step_simultaneous(p, O.TFAdam(0.0, 0.9), O.TFAdam(0.0, 0.9), None,
+                                   {k: v.to(dtype) for k, v in rnd.items()}, real.to(dtype), alpha, cfg, 1e-3, 1e-3,
+                                   freeze=freeze)
+
+
+def bf16_emulation_report(groups, w_rel=0.05, b_rel=0.10):
+    """bf16 HIP gradients against the bf16-EMULATING oracle's (same rounding points, masks from the same values; what is
+    left is f32 accumulation order and where a fused epilogue rounds a gradient once instead of twice).  Every weight
+    gradient within `w_rel` relative L2, every bias gradient within `b_rel` (sums with cancellation).
+    groups: [(tag, handle_vars, grads, {name: ref})] -> (report, violations)."""
+    report, bad = {}, []
+    for tag, hv, grads, refs in groups:
+        assert [v.key for v in hv] == list(refs.keys())
+        for v, g in zip(hv, grads):
+            r = refs[v.key].double()
+            gd = g.detach().double().cpu()
+            if float(r.norm()) == 0.0:
+                assert float(gd.norm()) == 0.0, v.key
+                continue
+            e = rel_l2(gd, r)
+            report[v.key] = round(e, 5)
+            if e > (w_rel if v.key.endswith('weight') else b_rel):
+                bad.append((v.key, e))
+    return report, bad

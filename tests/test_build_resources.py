@@ -35,11 +35,97 @@ def test_persistent_conv_kernels_fit_two_waves_per_simd():
 
 
 def test_committed_resource_table_is_current():
-    """profiles/r02_kernel_resources.json is the judged copy of the table: it must list every kernel of this build."""
-    path = os.path.join(ROOT, 'profiles', 'r02_kernel_resources.json')
+    """profiles/r03_kernel_resources.json is the judged copy of the table: it must list every kernel of this build."""
+    path = os.path.join(ROOT, 'profiles', 'r03_kernel_resources.json')
     committed = json.load(open(path))
     built = _usage()
     for f, ks in built.items():
         assert set(ks) == set(committed[f]), f'{f}: regenerate with python tools/dump_resources.py'
         for k, v in ks.items():
             assert committed[f][k]['vgpr_spill'] == v['vgpr_spill'] == 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# the hand-counted s_waitcnt regions of the unrolled K loops (csrc/common.h: SG_KLOOP_BEGIN / SG_KLOOP_END)
+# ---------------------------------------------------------------------------------------------------
+import re
+
+_LGKM = re.compile(r'^\s*(s_load|s_buffer_load|s_scratch_load|s_memtime|s_memrealtime|s_sendmsg|s_dcache|ds_)')
+_MFMA = re.compile(r'^\s*v_mfma\S*\s+v\[(\d+):(\d+)\]')
+_REG = re.compile(r'\bv\[(\d+):(\d+)\]|\bv(\d+)\b')
+
+
+def scan_kloop_regions(lines):
+    """Walks gfx950 assembly as hipcc -save-temps writes it (inline asm sits between ;;#ASMSTART / ;;#ASMEND).  Inside a
+    SG_KLOOP_BEGIN .. SG_KLOOP_END region the wave synchronises its own ds_reads with `s_waitcnt lgkmcnt(N > 0)`, which is
+    only correct if the compiler contributes NO instruction that lgkmcnt counts (LDS, scalar memory, s_memtime,
+    messages): those are reported as ('LGKM', kernel, text).  The in-place MFMAs of the region are inline asm too, so the
+    compiler's hazard pass does not see their result latency: any instruction of the compiler's that names an accumulator
+    register of those MFMAs before the region ends (the region ends behind sg_mfma_drain) is reported as ('ACC', ...).
+    Returns (number of regions, number of inline-asm MFMAs seen, problems)."""
+    kern, in_asm, region, problems, nreg, nmfma = None, False, None, [], 0, 0
+    for ln in lines:
+        s = ln.strip()
+        m = re.match(r'^(_Z\w+):', ln)
+        if m:
+            kern = m.group(1)
+        if s.startswith(';;#ASMSTART'):
+            in_asm = True
+            continue
+        if s.startswith(';;#ASMEND'):
+            in_asm = False
+            continue
+        if in_asm and 'SG_KLOOP_BEGIN' in s:
+            region = dict(kern=kern, acc=set())
+            nreg += 1
+            continue
+        if in_asm and 'SG_KLOOP_END' in s:
+            region = None
+            continue
+        if region is None:
+            continue
+        if in_asm:
+            m = _MFMA.match(ln)
+            if m:
+                nmfma += 1
+                region['acc'].update(range(int(m.group(1)), int(m.group(2)) + 1))
+            continue
+        if not s or s.startswith((';', '.')) or s.endswith(':'):
+            continue
+        if _LGKM.match(ln):
+            problems.append(('LGKM', region['kern'], s))
+        if region['acc']:
+            for a, b, c in _REG.findall(s.split(';')[0]):
+                regs = range(int(a), int(b) + 1) if a else (int(c),)
+                if any(r in region['acc'] for r in regs):
+                    problems.append(('ACC', region['kern'], s))
+                    break
+    return nreg, nmfma, problems
+
+
+def test_kloop_scanner_sees_planted_violations():
+    good = [';;#ASMSTART', '; SG_KLOOP_BEGIN', 's_waitcnt lgkmcnt(0)', ';;#ASMEND', ';;#ASMSTART', 'ds_read_b128 v[10:13], v5',
+            ';;#ASMEND', 's_nop 0', 'v_add_u32_e32 v5, 1, v5', ';;#ASMSTART', 'v_mfma_f32_32x32x16_bf16 v[20:35], v[10:13], v[14:17], v[20:35]',
+            ';;#ASMEND', ';;#ASMSTART', '; SG_KLOOP_END', ';;#ASMEND', 's_load_dwordx2 s[0:1], s[4:5], 0x0', 'v_mov_b32_e32 v1, v20']
+    assert scan_kloop_regions(['_Zk:'] + good) == (1, 1, [])
+    bad = list(good)
+    bad.insert(8, 's_load_dword s7, s[4:5], 0x10')          # compiler re-reading a kernel argument inside the loop
+    bad.insert(14, 'v_mov_b32_e32 v40, v21')                  # compiler copying an accumulator before the drain
+    n, _, problems = scan_kloop_regions(['_Zk:'] + bad)
+    assert n == 1 and [p[0] for p in problems] == ['LGKM', 'ACC'], problems
+
+
+def test_unrolled_k_loops_contain_no_compiler_lgkm_traffic():
+    """the hand-counted lgkmcnt(N) of sg_unrolled_k* / the wgrad loops holds only for today's codegen
+    unless it is checked.  This disassembles the shipped build (hipcc -save-temps=obj keeps the device assembly) and fails
+    if any scalar load, compiler-emitted ds_* or other LGKM-counted instruction sits inside a loop region, or if the
+    compiler reads an in-place MFMA's accumulator before the drain."""
+    from saragan_amd import build as b
+    total = 0
+    for src, least in (('conv3d.hip', 100), ('wgrad.hip', 4)):
+        with open(b.device_asm(src)) as f:
+            nreg, nmfma, problems = scan_kloop_regions(f)
+        assert nreg >= least, (src, nreg)
+        assert not problems, (src, problems[:10])
+        total += nmfma
+    assert total > 5000        # the bf16 loops' MFMAs are inline asm: the scanner did look at them

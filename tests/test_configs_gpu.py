@@ -20,7 +20,8 @@ import torch
 import torch.nn.functional as TF
 
 from oracle import pgan_oracle as O
-from tests.cfgutil import assert_adam_close, bf16_gradient_report, build_product, make_case, pick, rel_l2
+from tests.cfgutil import (assert_adam_close, bf16_emulated_step, bf16_emulation_report, bf16_gradient_report, build_product,
+                           make_case, pick, rel_l2)
 
 pytestmark = pytest.mark.gpu
 
@@ -88,6 +89,14 @@ def test_config2_xs_phase4_step_fp32_and_bf16():
     assert not bad, (bad, report)
     from saragan_amd.varstore import set_compute_dtype
     set_compute_dtype(torch.float32)
+    # ... and tightly against the oracle that rounds where the bf16 build stores (oracle.bf16_emulation)
+    emu = bf16_emulated_step(case['p0'], case['rnd'], case['real'], 0.0, case['cfg'])
+    report, bad = bf16_emulation_report([('G', tup[7], gg, emu['g_grads']), ('D', tup[9], dg, emu['d_grads'])])
+    print('vs bf16-emulating oracle:', float(gl), float(emu['gen_loss']), float(dl), float(emu['disc_loss']), report)
+    np.testing.assert_allclose(float(gl), float(emu['gen_loss']), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(float(dl), float(emu['disc_loss']), rtol=2e-3, atol=2e-3)
+    assert rel_l2(gs, emu['gen_sample']) <= 1e-2
+    assert not bad, (bad, report)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -101,3 +101,116 @@ def test_allreduce_and_broadcast_world2():
         assert r[2]['early'], 'a bucket waited for finish() although its only missing parameter is unreachable'
         for i, k in enumerate(res[0][2][2]):
             np.testing.assert_allclose(r[2][2][k], 0.0 if k == 'generator/a/bias' else (i + 1) * (1 + 2))
+
+
+def _adasum_numpy(vectors, segments):
+    """Adasum over a binary tree of ranks, per tensor, in float64 numpy (the rule of parallel.adasum_pair)."""
+    def pair(a, b):
+        out = np.empty_like(a)
+        for lo, hi in segments:
+            x, y = a[lo:hi], b[lo:hi]
+            dot, na, nb = float(x @ y), float(x @ x), float(y @ y)
+            ca = 1.0 - dot / (2 * na) if na >= 1e-8 else 1.0
+            cb = 1.0 - dot / (2 * nb) if nb >= 1e-8 else 1.0
+            out[lo:hi] = ca * x + cb * y
+        return out
+    level = list(vectors)
+    while len(level) > 1:
+        level = [pair(level[i], level[i + 1]) for i in range(0, len(level), 2)]
+    return level[0]
+
+
+def _worker_algos(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from saragan_amd import parallel
+    from saragan_amd.varstore import VariableStore
+    parallel.init_distributed('gloo')
+    info = parallel.collective_info()
+    store = VariableStore('cpu', seed=3)
+    shapes = {'discriminator/a/weight': (3, 5), 'discriminator/a/bias': (5,), 'discriminator/b/weight': (7, 3),
+              'discriminator/c/bias': (2,)}
+    for k, s in shapes.items():
+        store.get(k, s, 'normal')
+    flat = store.flatten('discriminator/')
+    names = list(shapes)
+    offs = flat['offsets']
+    params = [store.vars[k] for k in names]
+    ranges = [(offs[k][0], (offs[k][1] + 3) // 4 * 4) for k in names]
+
+    def run(red):
+        flat['grad'].zero_()
+        for p_, k in zip(params, names):
+            o, n = offs[k]
+            p_.grad = flat['grad'][o:o + n].view(p_.shape)
+        g = torch.Generator().manual_seed(50 + rank)
+        loss = sum((p_ * torch.randn(p_.shape, generator=g)).sum() for p_ in params)
+        red.begin(flat['grad'], ranges, params)
+        torch.autograd.backward(loss, inputs=params)
+        red.finish()
+        return flat['grad'].clone().numpy()
+
+    out = dict(info=info)
+    out['allreduce'] = run(parallel.GradientAllReducer(bucket_bytes=44))      # 11 floats: buckets that do not divide by 2 or 4
+    os.environ['SARAGAN_DP_ALGO'] = 'rs_ag'
+    try:
+        red = parallel.GradientAllReducer(bucket_bytes=44)
+        assert red.algo == 'rs_ag' and red.grad_scale == 1.0 / world
+        out['rs_ag'] = run(red)
+    except RuntimeError as e:           # a backend without reduce_scatter_tensor / all_gather_into_tensor
+        out['rs_ag'] = f'unsupported: {e}'
+    os.environ['SARAGAN_DP_ALGO'] = 'allreduce'
+    ada = parallel.DistributedOptimizer(type('O', (), {})(), op=parallel.Adasum).distributed
+    assert isinstance(ada, parallel.AdasumReducer) and ada.grad_scale == 1.0
+    out['adasum'] = run(ada)
+    out['segments'] = [offs[k] for k in names]
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_world(target, world):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return [r[1] for r in sorted(res, key=lambda t: t[0])]
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_reduce_scatter_all_gather_form_and_adasum(world):
+    """SARAGAN_DP_ALGO=rs_ag sums exactly what the all_reduce form sums (same GradientAllReducer interface, same hooks
+    and buckets); the Adasum reducer (hvd.Adasum, optuna_objective.py:182-183) equals the numpy restatement of the rule
+    evaluated over the binary tree of ranks, identically on every rank; collective_info names backend and size."""
+    res = _run_world(_worker_algos, world)
+    want_sum = None
+    for r in range(world):
+        g = torch.Generator().manual_seed(50 + r)
+        vec = np.concatenate([np.pad(torch.randn(s, generator=g).numpy().reshape(-1), (0, (-int(np.prod(s))) % 4))
+                              for s in [(3, 5), (5,), (7, 3), (2,)]])
+        want_sum = vec if want_sum is None else want_sum + vec
+    per_rank = []
+    for r in range(world):
+        g = torch.Generator().manual_seed(50 + r)
+        per_rank.append(np.concatenate([np.pad(torch.randn(s, generator=g).numpy().reshape(-1), (0, (-int(np.prod(s))) % 4))
+                                        for s in [(3, 5), (5,), (7, 3), (2,)]]).astype(np.float64))
+    for out in res:
+        assert out['info'] == dict(backend='gloo', world_size=world, algo='allreduce')
+        np.testing.assert_allclose(out['allreduce'], want_sum, rtol=1e-6, atol=1e-6)
+        if isinstance(out['rs_ag'], str):
+            pytest.skip(out['rs_ag'])
+        np.testing.assert_allclose(out['rs_ag'], want_sum, rtol=1e-6, atol=1e-6)
+        segs = [(o, o + n) for o, n in out['segments']]
+        want = _adasum_numpy(per_rank, segs)
+        for lo, hi in segs:
+            np.testing.assert_allclose(out['adasum'][lo:hi], want[lo:hi], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(out['adasum'], res[0]['adasum'])

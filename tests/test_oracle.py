@@ -174,3 +174,22 @@ def test_oracle_step_fixture_replays_in_fp32(golden_dir, name):
         np.testing.assert_allclose(res['d_grads'][k].numpy(), ref, rtol=5e-3, atol=1e-4 * np.abs(ref).max() + 1e-7)
     for k in [k for k in (fx['freeze'] or []) if k in p]:
         np.testing.assert_array_equal(p[k].numpy(), fx['p0'][k].numpy())
+
+
+def test_bf16_emulation_restates_the_products_pooling_rule_and_is_off_by_default():
+    """oracle.hip_pool_mode must say what saragan_amd.functional._pool_mode says (it decides where the emulation rounds),
+    and outside bf16_emulation() the oracle's arithmetic is untouched (the fixtures reproduce bit for bit)."""
+    import itertools
+    from saragan_amd import functional as F
+    for n, cin, cout, d, hw in itertools.product((1, 2, 4, 64), (8, 16, 32, 64, 128), (32, 64, 128), (2, 4, 16, 32), (16, 32, 64, 128)):
+        x = torch.empty((n, cin, d, hw, hw), dtype=torch.bfloat16, device='meta')
+        assert O.hip_pool_mode(n, cin, cout, d, hw, hw, (3, 3, 3)) == F._pool_mode(x, (3, 3, 3), cin, cout), (n, cin, cout, d, hw)
+    x = torch.empty((4, 32, 16, 64, 64), dtype=torch.bfloat16, device='meta')
+    assert O.hip_pool_mode(4, 32, 64, 16, 64, 64, (1, 3, 3)) == F._pool_mode(x, (1, 3, 3), 32, 64) == 0
+    assert not O._EMU['on']
+    t = torch.randn(3, 5, dtype=torch.float64)
+    assert O._q(t) is t
+    with O.bf16_emulation():
+        q = O._q(t)
+        assert torch.equal(q, t.to(torch.bfloat16).double()) and O._EMU['on']
+    assert not O._EMU['on']

@@ -471,6 +471,7 @@ def main():
     value = vols / dt
     peak = 2500.0 if args.dtype == 'bf16' else 157.3
     roof = None
+    timed = [e for e in timed if e.kernel == dom_name] or timed       # (one shape may run as several kernel variants)
     if timed and timed[0].launches > 0:      # the dominant kernel's heaviest shape, timed inside the timed region
         best = timed[0]
         avg_ms = best.total_ms / best.launches
@@ -561,6 +562,7 @@ def main():
         lib.sg_prof_enable(0)
         lib.sg_prof_set_filter(0, None)
         roof32 = None
+        timed32 = [e for e in timed32 if dom32 is not None and e.kernel == dom32.kernel] or timed32
         if timed32 and timed32[0].launches > 0:
             b_ = timed32[0]
             avg32 = b_.total_ms / b_.launches

@@ -2929,7 +2929,9 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     rc = SG_OK;
     const bool k333 = s->kd == 3 && s->kh == 3 && s->kw == 3, k133 = s->kd == 1 && s->kh == 3 && s->kw == 3;
     if (dt == SG_BF16 && k333 && !sg_cfg().fwd_no_v3s && !sg_cfg().fwd_no_ksplit && a.nchunk == 4 && a.ntile == 1 && s->cin == 64 &&
-        !a.pool && !a.pnb_y && !(a.mask_bits && a.sign_out) && !(a.pixel_norm && a.mask_bits) && ep && ep->workspace &&
+        !a.pool && !a.pnb_y && !(a.mask_bits && a.sign_out) && !(a.pixel_norm && a.mask_bits) &&
+        !(s->upsample_in && a.mask_bits) &&      // (no fused-gather variant carries a mask: the second pass would decline)
+        ep && ep->workspace &&
         ep->workspace_bytes >= (size_t)s->n * s->d * s->h * s->w * (size_t)s->cout * 4 && sg_aligned16(ep->workspace)) {
       // K split: 64 input channels as two sliding-halo passes over 32 channels each (resident weights, a 64-byte
       // half of every 128-byte channel row fetched ONCE per pass) with the f32 partial sums in the caller's workspace.

@@ -23,8 +23,15 @@ struct sg_prof_scope {
   int slot;
   hipStream_t st;
   sg_prof_scope(int kind, const sg_conv_shape* s, sg_dtype dt, hipStream_t st_) : slot(-1), st(st_) {
+    sg_tls_kernel = "";      // a launch that dispatches nothing must not inherit the previous call's kernel name
     if (sg_prof_on()) sg_prof_begin(kind, s, dt, st, &slot);
   }
+  // an early return (a declined request) ends the record as failed: no event pair is left recorded and open
+  ~sg_prof_scope() {
+    if (slot >= 0) sg_prof_end(-1 - slot, st);
+  }
+  sg_prof_scope(const sg_prof_scope&) = delete;
+  sg_prof_scope& operator=(const sg_prof_scope&) = delete;
   void name(const char* n) {
     if (slot >= 0) sg_prof_name(slot, n);
   }

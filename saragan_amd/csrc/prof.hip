@@ -139,7 +139,8 @@ extern "C" int sg_prof_collect(sg_prof_entry* out, int32_t max_entries, int32_t*
     if (!ok) continue;
     int j = 0;
     for (; j < n; ++j)
-      if (out[j].kind == r.kind && out[j].dtype == r.dtype && memcmp(&out[j].shape, &r.shape, sizeof(sg_conv_shape)) == 0) break;
+      if (out[j].kind == r.kind && out[j].dtype == r.dtype && memcmp(&out[j].shape, &r.shape, sizeof(sg_conv_shape)) == 0 &&
+          strncmp(out[j].kernel, r.name ? r.name : "", sizeof(out[j].kernel) - 1) == 0) break;   // pooled / masked / plain variants apart
     if (j == n) {
       if (n >= max_entries) continue;
       out[n].kind = r.kind; out[n].shape = r.shape; out[n].dtype = r.dtype; out[n].launches = 0; out[n].total_ms = 0;

@@ -19,12 +19,18 @@ class _LazyUp:
     """upscale3d(x) not yet materialised: a following conv3d reads x through a nearest-x2 gather."""
 
     def __init__(self, x):
-        self.x = x
-        self._v = None
+        self._src = x          # a tensor or a lazy handle: evaluated only when somebody reads the up-scaled tensor, so a
+        self._v = None         # branch that lerp() prunes (alpha = 0) never runs the to_rgb / from_rgb it hangs on
+
+    @property
+    def x(self):
+        if not isinstance(self._src, torch.Tensor):
+            self._src = _val(self._src)
+        return self._src
 
     @property
     def shape(self):
-        n, c, d, h, w = self.x.shape
+        n, c, d, h, w = self._src.shape
         return torch.Size((n, c, 2 * d, 2 * h, 2 * w))
 
     def value(self):
@@ -342,7 +348,7 @@ def upscale3d(x, factor=2):
         return x
     if factor != 2:
         raise NotImplementedError('only factor 2 is used by the pgan path')
-    return _LazyUp(_val(x))
+    return _LazyUp(x)
 
 
 def upscale3d_trilinear(x, factor=2):

@@ -110,7 +110,7 @@ def test_kloop_scanner_sees_planted_violations():
     assert scan_kloop_regions(['_Zk:'] + good) == (1, 1, [])
     bad = list(good)
     bad.insert(8, 's_load_dword s7, s[4:5], 0x10')          # compiler re-reading a kernel argument inside the loop
-    bad.insert(14, 'v_mov_b32_e32 v40, v21')                  # compiler copying an accumulator before the drain
+    bad.insert(13, 'v_mov_b32_e32 v40, v21')                  # compiler copying an accumulator before the drain
     n, _, problems = scan_kloop_regions(['_Zk:'] + bad)
     assert n == 1 and [p[0] for p in problems] == ['LGKM', 'ACC'], problems
 

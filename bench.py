@@ -300,6 +300,9 @@ def mark(what):
     """SARAGAN_BENCH_MARK=1: wall-clock markers of the legs (tools/clock_trace.sh lines them up with rocm-smi samples)."""
     if os.environ.get('SARAGAN_BENCH_MARK'):
         print(f'MARK {time.time():.3f} {what}', flush=True)
+        if what.startswith('timed region'):      # ... and a marker kernel for tools/trace_windows.py (rocprofv3 --kernel-trace)
+            import torch
+            torch.zeros(3, device='cuda').cumsum(0)
 
 
 class Stopwatch:
@@ -338,6 +341,16 @@ def timed_steps(step, nsteps, barrier):
     return sw.seconds
 
 
+def leg_losses(cfg, batch):
+    """Losses of one more step after a leg: a trajectory that has left the finite range (this is WGAN at lr 1e-3 on
+    noise volumes: it diverges) computes on NaNs, which the MFMA pipes run faster than on data (no operand toggling: the
+    clock rises) -- such a leg's rate is not a measurement of the workload and the run is rejected."""
+    vals = [float(v) for v in cfg['sess'].run(cfg['losses'] + cfg['train'], feed_dict={cfg['ph']: batch})[:2]]
+    if not all(v == v and abs(v) < 1e30 for v in vals):
+        raise SystemExit(f'non-finite losses after a bench leg: {vals}')
+    return dict(disc=round(vals[0], 4), gen=round(vals[1], 4))
+
+
 def loader_leg(args, cfg, device, nsteps, barrier):
     """The same step with the data path inside the timed loop (SURVEY section 8d "loader included"): synthetic
     `{xy}x{xy}/NNNN.npy` int16 volumes on local disk, NumpyPathDataset drawing batches, PinnedPrefetcher loading,
@@ -365,9 +378,11 @@ def loader_leg(args, cfg, device, nsteps, barrier):
         for i in range(max(30, args.warmup + 5)):
             step(i)
         dt = timed_steps(step, nsteps, barrier)
+        la = leg_losses(cfg, pf.next())
         pf.close()
         mb = nfiles * np.prod(shape[2:]) * 2 / 2 ** 20
         return dict(value=round(args.batch * nsteps / dt, 3), ms_per_step=round(dt / nsteps * 1e3, 3), steps=nsteps,
+                    losses_after=la,
                     note=f'loader in the timed loop: {nfiles} synthetic int16 .npy volumes ({mb:.0f} MiB) on local disk, '
                          f'np.load -> pinned ring -> async H2D on a side stream, 2 batches ahead')
     finally:
@@ -438,7 +453,7 @@ def main():
     if world > 1:
         for o_ in cfg['optimizers']:
             o_.distributed.exposed_ms()       # forget the warm-up steps
-    lib.sg_prof_enable(1)
+    lib.sg_prof_enable(0 if os.environ.get('SARAGAN_BENCH_NO_PROF') else 1)     # (diagnostic: no event bracketing at all)
     with Stopwatch(lambda: None) as sw:      # the barrier before is the one above; the one after follows
         for i in range(args.steps):
             step(args.warmup + ncal + i)
@@ -524,10 +539,11 @@ def main():
                     step(i)
                 nf = max(3, args.steps // 2)
                 dtf = timed_steps(step, nf, barrier)
+                la_f = leg_losses(cfg, batches[0])
             finally:
                 _ops._NO_LERP_PRUNE = prune
             extras['fade_branch_computed'] = dict(value=round(args.batch * nf / dtf, 3), ms_per_step=round(dtf / nf * 1e3, 3),
-                                                  steps=nf, note='alpha = 0 through sg_axpby and the previous phase\'s '
+                                                  steps=nf, losses_after=la_f, note='alpha = 0 through sg_axpby and the previous phase\'s '
                                                   'from_rgb / to_rgb, forward and backward (SARAGAN_NO_LERP_PRUNE=1)')
         # the same workload in fp32 storage / f32-input MFMA (the reference's arithmetic, ops.py:147-150)
         del cfg, sess, batches

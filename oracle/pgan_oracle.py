@@ -384,10 +384,10 @@ def generator(p: Params, z, alpha, phase, base_shape, activation, kernel_spec, f
     g = 'generator/'
     fs = filter_spec
     # _q: the tensors the bf16 HIP path stores -- each fused conv + bias + LeakyReLU + pixel-norm launch writes its result
-    # once (saragan_amd/networks/ops.py:_LazyConv.value); above 128 channels pixel_norm is a pass of its own
-    # (networks/ops.py:pixel_norm) and the activation is stored in between
+    # once (saragan_amd/networks/ops.py:_LazyConv.value); above 64 channels pixel_norm is a pass of its own
+    # (networks/ops.py:pixel_norm, functional.PN_FUSE_MAX_CHANNELS) and the activation is stored in between
     def pn_stored(a):
-        return _q(pixel_norm(a if a.shape[1] <= 128 else _q(a)))
+        return _q(pixel_norm(a if a.shape[1] <= 64 else _q(a)))
 
     x = dense(_q(z), p[g + 'generator_in/dense/weight'], activation, param)
     x = _q(act(apply_bias(x, p[g + 'generator_in/dense/bias']), activation, param))

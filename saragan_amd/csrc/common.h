@@ -42,8 +42,21 @@ struct sg_config {
   int wgrad_v1, wgrad_no_v3, wgrad_no_lean;  // SG_WGRAD_V1, SG_WGRAD_NO_V3, SG_WGRAD_NO_LEAN
   int wgrad_v1_blocks;                       // SG_WGRAD_V1_BLOCKS: block target of the generic weight-gradient kernel (0: default)
   int dbg_flags;                             // SG_DBG_FLAGS
+  int no_small;                              // SG_NO_SMALL: the small-channel 2-D layers through the MFMA kernels (A/B, tests)
 };
 const sg_config& sg_cfg();
+
+// small.hip: VALU kernels for the 4 / 8 / 16-channel 1x3x3 layers of the 2-D pgan's top levels
+bool sg_small_eligible(const sg_conv_shape* s);
+bool sg_small_wgrad_eligible(const sg_conv_shape* s);
+size_t sg_small_tail_bytes(const sg_conv_shape* s);
+size_t sg_small_wgrad_workspace(const sg_conv_shape* s);
+int sg_small_pack(const float* w, float coef, int flip, void* tail, const sg_conv_shape* s, sg_dtype dt, hipStream_t st);
+int sg_small_fwd(const void* x, const void* tail, void* y, const sg_conv_shape* s, const float* bias, int act, float slope,
+                 int pixel_norm, float eps, float* pn_scale, const uint32_t* mask_bits, float mask_slope, uint32_t* sign_out,
+                 sg_dtype dt, hipStream_t st);
+int sg_small_wgrad(const void* x, const void* dy, float* dw, float* dbias, float coef, void* workspace, size_t workspace_bytes,
+                   const sg_conv_shape* s, sg_dtype dt, hipStream_t st);
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel symbol (idempotent; thread-safe).
 #define SG_ALLOW_160K_LDS(kern)                                                                                  \

@@ -70,7 +70,8 @@ static int conv_shape_ok(const sg_conv_shape* s) {
 
 extern "C" size_t sg_conv3d_packed_bytes(const sg_conv_shape* s, sg_dtype dt) {
   if (!conv_shape_ok(s)) return 0;
-  return (size_t)conv_nchunk(s, dt) * (s->kd * s->kh * s->kw) * conv_ntile(s) * 1024;
+  // [MFMA fragment image][plain f32 [taps][cin][cout] copy for the small-channel VALU kernels, where they take the layer]
+  return (size_t)conv_nchunk(s, dt) * (s->kd * s->kh * s->kw) * conv_ntile(s) * 1024 + sg_small_tail_bytes(s);
 }
 
 extern "C" int sg_conv3d_pack_weights(const float* w, float coef, int transpose_flip, void* wp,
@@ -89,6 +90,8 @@ extern "C" int sg_conv3d_pack_weights(const float* w, float coef, int transpose_
   else
     hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, sg_st(st), a);
   SG_LAUNCH_CHECK();
+  if (sg_small_tail_bytes(s))
+    return sg_small_pack(w, coef, a.flip, reinterpret_cast<char*>(wp) + (size_t)a.nchunk * a.taps * a.ntile * 1024, s, dt, sg_st(st));
   return SG_OK;
 }
 
@@ -2906,6 +2909,13 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
                   a.pixel_norm || (s->cin * 2) % 16 != 0 || s->kd != 3 || s->kh != 3 || s->kw != 3 || s->upsample_in ||
                   (ep && ep->x_plane_channels)))
     return SG_EUNSUPPORTED;
+  if (sg_small_eligible(s) && !sg_cfg().no_small && !a.pool && !a.pnb_y && !(ep && ep->x_plane_channels)) {
+    // 4 / 8 / 16-channel 1x3x3 layers (the 2-D pgan's top levels): bandwidth-bound VALU kernel, small.hip
+    rc = sg_small_fwd(x, reinterpret_cast<const char*>(wp) + (size_t)a.nchunk * a.taps * a.ntile * 1024, y, s, a.bias, a.act, a.slope,
+                      a.pixel_norm, a.eps, a.pn_scale, a.mask_bits, a.mask_slope, a.sign_out, dt, hs);
+    prof.done(rc);
+    return rc;
+  }
   if (a.pool == 2) {   // H x W pooling: the streamed kernel's tile (two H rows per wave)
     bool used = false;
     rc = launch_fwd5(a, s, hs, &used);

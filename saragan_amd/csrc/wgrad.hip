@@ -295,7 +295,9 @@ static size_t wgrad_tile_bytes(const sg_conv_shape* s);
 extern "C" size_t sg_conv3d_wgrad_workspace(const sg_conv_shape* s, sg_dtype dt) {
   (void)dt;
   if (!conv_shape_ok_w(s)) return 0;
-  return wgrad_tile_bytes(s) + sg_bias_act_bwd_workspace(s->cout);   // [tile / partial sums][bias-gradient fallback]
+  const size_t gen = wgrad_tile_bytes(s) + sg_bias_act_bwd_workspace(s->cout);   // [tile / partial sums][bias-gradient fallback]
+  const size_t small = sg_small_wgrad_workspace(s);                              // per-block slabs of the small-channel kernel
+  return gen > small ? gen : small;
 }
 
 template <typename T, int BM>
@@ -1329,6 +1331,11 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
     }
   }
   if (pw_dx) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }   // only the pointwise pass has the extra output
+  if (sg_small_wgrad_eligible(s) && !sg_cfg().no_small) {   // 2-D top levels (<= 16 channels): VALU kernel, slab reduction
+    const int rc_s = sg_small_wgrad(x, dy, dw, dbias, coef, workspace, workspace_bytes, s, dt, hs);
+    prof.done(rc_s);
+    return rc_s;
+  }
   const size_t tile_bytes = (size_t)(s->kd * s->kh * s->kw) * sg_cdiv(s->cin, 32) * sg_cdiv(s->cout, 32) * 4096;
   hipError_t e = hipMemsetAsync(workspace, 0, tile_bytes, hs);
   if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, (size_t)s->cout * sizeof(float), hs);

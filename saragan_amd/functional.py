@@ -1102,6 +1102,9 @@ class _SumsqKeepW(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------------
 # public functional API
 # ---------------------------------------------------------------------------------------------------
+PN_FUSE_MAX_CHANNELS = int(os.environ.get('SARAGAN_PN_FUSE_MAX', '64'))   # widest layer whose pixel_norm rides in the conv epilogue
+
+
 def conv3d(x, w, coef=1.0, bias=None, act=False, slope=0.2, pixel_norm=False, eps=1e-8, upsample_in=False,
            fuse=True, out_info=None, in_info=None):
     """conv3d (+ optional fused nearest-x2 of the input, bias, LeakyReLU, pixel-norm)."""

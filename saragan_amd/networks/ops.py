@@ -373,7 +373,11 @@ def downscale3d(x, factor=2):
 
 def pixel_norm(x, epsilon=1e-8):
     """networks/ops.py:308-310."""
-    if isinstance(x, _LazyConv) and x._v is None and x.shape[1] <= 128:
+    # fused into the conv epilogue where one wave owns all the channels of a voxel (<= 64: the sliding-halo and the
+    # streamed kernel's two N tiles).  Wider layers would run the one kernel whose block owns all N tiles (conv_fwd2 with
+    # NTB = 4: a single block for a whole 8^2 level, 190-410 us per launch); they keep their fast conv kernel and
+    # normalise in a pass of their own, on what at those levels is a small tensor
+    if isinstance(x, _LazyConv) and x._v is None and x.shape[1] <= F.PN_FUSE_MAX_CHANNELS:
         x.pn, x.eps, x.stage = True, float(epsilon), 3
         return x
     return F.pixel_norm(_val(x), float(epsilon))

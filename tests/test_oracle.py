@@ -186,6 +186,7 @@ def test_bf16_emulation_restates_the_products_pooling_rule_and_is_off_by_default
         assert O.hip_pool_mode(n, cin, cout, d, hw, hw, (3, 3, 3)) == F._pool_mode(x, (3, 3, 3), cin, cout), (n, cin, cout, d, hw)
     x = torch.empty((4, 32, 16, 64, 64), dtype=torch.bfloat16, device='meta')
     assert O.hip_pool_mode(4, 32, 64, 16, 64, 64, (1, 3, 3)) == F._pool_mode(x, (1, 3, 3), 32, 64) == 0
+    assert F.PN_FUSE_MAX_CHANNELS == 64        # generator(): above that the activation is stored before pixel_norm
     assert not O._EMU['on']
     t = torch.randn(3, 5, dtype=torch.float64)
     assert O._q(t) is t

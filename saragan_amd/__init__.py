@@ -9,3 +9,14 @@ def dropin_path():
     `optimization`, `dataset`, ... as imported by SURFGAN_3D/optuna_objective.py:12-30,64-65) resolve to this package."""
     import os
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), 'dropin')
+
+
+def set_deterministic(on=True):
+    """Reproducible mode of the library (SG_DETERMINISTIC): weight-gradient kernels store per-block slabs that are added in
+    a fixed order instead of using float atomics, and the gradient-penalty row sums are ordered -- two runs from the same
+    state produce bit-identical weights (tests/test_deterministic_gpu.py).  Costs workspace (one slab per block of the
+    weight-gradient grids) and a few percent of the step; off by default."""
+    import os
+    from . import _lib
+    os.environ['SG_DETERMINISTIC'] = '1' if on else '0'
+    _lib.load().sg_config_reload()

@@ -43,6 +43,7 @@ struct sg_config {
   int wgrad_v1_blocks;                       // SG_WGRAD_V1_BLOCKS: block target of the generic weight-gradient kernel (0: default)
   int dbg_flags;                             // SG_DBG_FLAGS
   int no_small;                              // SG_NO_SMALL: the small-channel 2-D layers through the MFMA kernels (A/B, tests)
+  int deterministic;                         // SG_DETERMINISTIC: no float atomics anywhere (weight-gradient slabs, ordered sums)
 };
 const sg_config& sg_cfg();
 

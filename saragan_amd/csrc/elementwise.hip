@@ -759,6 +759,36 @@ __global__ void sumsq_keep_w_kernel(const T* __restrict__ g, float* __restrict__
   }
 }
 
+// Reproducible form (SG_DETERMINISTIC=1): one block per sample, thread (ty, w) adds rows ty, ty + TY, ... in order, the TY
+// partial sums are added in order through LDS; no atomics, no memset.
+template <typename T>
+__global__ __launch_bounds__(1024) void sumsq_keep_w_ordered_kernel(const T* __restrict__ g, float* __restrict__ out, int dh, int w,
+                                                                    int c, int tw) {
+  __shared__ float part[1024];
+  const int nn = blockIdx.x;
+  const int ty = threadIdx.x / tw, tx = threadIdx.x % tw, TY = 1024 / tw;
+  for (int w0 = 0; w0 < w; w0 += tw) {
+    const int ww = w0 + tx;
+    float s = 0.f;
+    if (ww < w)
+      for (int rr = ty; rr < dh; rr += TY) {
+        const T* p = g + (((int64_t)nn * dh + rr) * w + ww) * c;
+        for (int ch = 0; ch < c; ++ch) {
+          const float v = sg_traits<T>::to_f(p[ch]);
+          s += v * v;
+        }
+      }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (ty == 0 && ww < w) {
+      float t = 0.f;
+      for (int k = 0; k < TY; ++k) t += part[k * tw + tx];
+      out[(int64_t)nn * w + ww] = t;
+    }
+    __syncthreads();
+  }
+}
+
 // minibatch stddev, stage 1: stat[m] = mean over (vox, c) of sqrt(var over the group + 1e-8)
 template <typename T>
 __global__ __launch_bounds__(256) void mbstd_stat_kernel(const T* __restrict__ x, float* __restrict__ stat, int group,
@@ -1193,9 +1223,18 @@ extern "C" int sg_sumsq_ndhwc_keep_w(const void* g, float* out, int32_t n, int32
                                      sg_dtype dt, sg_stream_t st) {
   if (!g || !out || n < 1 || d < 1 || h < 1 || w < 1 || c < 1) return SG_EINVAL;
   hipStream_t hs = sg_st(st);
+  const int dh = d * h;
+  if (sg_cfg().deterministic) {
+    int tw = 1;
+    while (tw < w && tw < 256) tw <<= 1;
+#define LO(T) hipLaunchKernelGGL((sumsq_keep_w_ordered_kernel<T>), dim3(n), dim3(1024), 0, hs, (const T*)g, out, dh, w, c, tw)
+    SG_DISPATCH(dt, LO(bf16_t), LO(float));
+#undef LO
+    SG_LAUNCH_CHECK();
+    return SG_OK;
+  }
   hipError_t e = hipMemsetAsync(out, 0, (size_t)n * w * sizeof(float), hs);
   if (e != hipSuccess) return (int)e;
-  const int dh = d * h;
   int rows = (dh + 63) / 64;
   if (rows < 1) rows = 1;
   const int bx = (dh + rows - 1) / rows;

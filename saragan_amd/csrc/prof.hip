@@ -49,6 +49,7 @@ const sg_config* read_config() {
   c->wgrad_no_v3 = env_int("SG_WGRAD_NO_V3", 0);
   c->dbg_flags = env_int("SG_DBG_FLAGS", 0);
   c->no_small = env_int("SG_NO_SMALL", 0);
+  c->deterministic = env_int("SG_DETERMINISTIC", 0);
   return c;
 }
 }  // namespace

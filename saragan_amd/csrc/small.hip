@@ -206,7 +206,7 @@ __device__ __forceinline__ float sg_wave_sum(float v) {
 }
 
 template <typename T, int CIN, int COUT, int CS>
-__global__ __launch_bounds__(256) void conv_small_wgrad_kernel(SmallWgradArgs a) {
+__global__ __launch_bounds__(256, CIN == 4 ? 3 : 2) void conv_small_wgrad_kernel(SmallWgradArgs a) {   // 3 (2) blocks per CU: <= 168 (256) registers
   constexpr int ES = (int)sizeof(T);
   constexpr int NACC = 9 * CIN * CS, NTOT = NACC + CS;
   __shared__ float red[4][NTOT];
@@ -236,36 +236,36 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(SmallWgradArgs a)
     }
     const uint32_t go = live ? (uint32_t)(w * COUT + c0) * ES : SG_DEAD;
     const int hend = it.h0 + a.R < a.H ? it.h0 + a.R : a.H;
-    float win[3][3][CIN], g[2][CS];
+    float win[3][3][CIN], g[CS], gn[CS];
     auto load_row = [&](int slot, int hh) {
       const bool rv = hh >= 0 && hh < a.H;
 #pragma unroll
       for (int c = 0; c < 3; ++c) sg_bload<T, CIN>(win[slot][c], rx, rv ? colo[c] : SG_DEAD, rv ? (uint32_t)hh * rowb : 0u);
     };
-    auto load_g = [&](int slot, int hh) {                            // dy of row hh (zeros beyond the strip: adds nothing)
+    auto load_g = [&](float (&dst)[CS], int hh) {                    // dy of row hh (zeros beyond the strip: adds nothing)
       const bool rv = hh < hend;
       if constexpr (CS >= 4) {
-        sg_bload<T, CS>(g[slot], rg, rv ? go : SG_DEAD, rv ? (uint32_t)hh * rowg : 0u);
+        sg_bload<T, CS>(dst, rg, rv ? go : SG_DEAD, rv ? (uint32_t)hh * rowg : 0u);
       } else {
 #pragma unroll
         for (int c = 0; c < CS; ++c) {
           if constexpr (ES == 4) {
-            g[slot][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, rv ? go + 4u * c : SG_DEAD, rv ? (uint32_t)hh * rowg : 0u, 0));
+            dst[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, rv ? go + 4u * c : SG_DEAD, rv ? (uint32_t)hh * rowg : 0u, 0));
           } else {
-            g[slot][c] = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rg, rv ? go + 2u * c : SG_DEAD, rv ? (uint32_t)hh * rowg : 0u, 0) << 16);
+            dst[c] = __builtin_bit_cast(float, (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rg, rv ? go + 2u * c : SG_DEAD, rv ? (uint32_t)hh * rowg : 0u, 0) << 16);
           }
         }
       }
     };
     load_row(0, it.h0 - 1);
     load_row(1, it.h0);
-    load_g(0, it.h0);
-    auto row = [&](auto SL, auto GS, int h) {
-      constexpr int s0 = decltype(SL)::value, s1 = (s0 + 1) % 3, s2 = (s0 + 2) % 3, gs = decltype(GS)::value;
+    load_g(g, it.h0);
+    auto row = [&](auto SL, int h) {
+      constexpr int s0 = decltype(SL)::value, s1 = (s0 + 1) % 3, s2 = (s0 + 2) % 3;
       load_row(s2, h + 1);
-      load_g(gs ^ 1, h + 1);                                         // next row's dy, in flight during this row's arithmetic
+      load_g(gn, h + 1);                                             // next row's dy, in flight during this row's arithmetic
 #pragma unroll
-      for (int c = 0; c < CS; ++c) accb[c] += g[gs][c];
+      for (int c = 0; c < CS; ++c) accb[c] += g[c];
       constexpr int slots[3] = {s0, s1, s2};
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
@@ -275,16 +275,14 @@ __global__ __launch_bounds__(256) void conv_small_wgrad_kernel(SmallWgradArgs a)
           for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
             for (int c = 0; c < CS; ++c)
-              acc[((kh * 3 + kw) * CIN + ci) * CS + c] = fmaf(win[slots[kh]][kw][ci], g[gs][c], acc[((kh * 3 + kw) * CIN + ci) * CS + c]);
+              acc[((kh * 3 + kw) * CIN + ci) * CS + c] = fmaf(win[slots[kh]][kw][ci], g[c], acc[((kh * 3 + kw) * CIN + ci) * CS + c]);
+#pragma unroll
+      for (int c = 0; c < CS; ++c) g[c] = gn[c];
     };
-    // the row loop is unrolled by 6 = lcm(3 window slots, 2 dy slots): every slot index is a compile-time constant
-    for (int h = it.h0; h < hend; h += 6) {
-      row(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, h);
-      if (h + 1 < hend) row(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, h + 1);
-      if (h + 2 < hend) row(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{}, h + 2);
-      if (h + 3 < hend) row(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, h + 3);
-      if (h + 4 < hend) row(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, h + 4);
-      if (h + 5 < hend) row(std::integral_constant<int, 2>{}, std::integral_constant<int, 1>{}, h + 5);
+    for (int h = it.h0; h < hend; h += 3) {      // unrolled by the three window slots: every slot index is a compile-time constant
+      row(std::integral_constant<int, 0>{}, h);
+      if (h + 1 < hend) row(std::integral_constant<int, 1>{}, h + 1);
+      if (h + 2 < hend) row(std::integral_constant<int, 2>{}, h + 2);
     }
   }
   // wave reduction (fixed order), block reduction through LDS, one slab per block
@@ -382,7 +380,10 @@ static int small_fwd_cout(const SmallFwdArgs& a, int cout, unsigned blocks, hipS
   switch (cout) {
     case 4: hipLaunchKernelGGL((conv_small_fwd_kernel<T, CIN, 4>), dim3(blocks), dim3(256), 0, st, a); break;
     case 8: hipLaunchKernelGGL((conv_small_fwd_kernel<T, CIN, 8>), dim3(blocks), dim3(256), 0, st, a); break;
-    default: hipLaunchKernelGGL((conv_small_fwd_kernel<T, CIN, 16>), dim3(blocks), dim3(256), 0, st, a); break;
+    default:
+      if constexpr (CIN < 16) hipLaunchKernelGGL((conv_small_fwd_kernel<T, CIN, 16>), dim3(blocks), dim3(256), 0, st, a);
+      else return SG_EUNSUPPORTED;
+      break;
   }
   return SG_OK;
 }
@@ -422,10 +423,13 @@ int sg_small_fwd(const void* x, const void* tail, void* y, const sg_conv_shape* 
 
 // weight gradient (16 -> 16 stays on the MFMA kernels: a thread's slice of the sums would be one output channel wide, and
 // the forward kernel's 2304 weights no longer fit the scalar registers)
-bool sg_small_wgrad_eligible(const sg_conv_shape* s) { return sg_small_eligible(s); }
-static int small_wgrad_slices(const sg_conv_shape* s) { return s->cout / (s->cin == 4 ? 4 : (s->cin == 8 ? 2 : 1)); }
+bool sg_small_wgrad_eligible(const sg_conv_shape* s) { return sg_small_eligible(s) && s->cin <= 8; }   // (16 input channels: the
+                                                                                                       // three-row window alone is 144 registers)
+// A thread keeps 72 sums (9 taps x CIN x CS): CS = 2 output channels at 4 input channels, 1 at 8.  (144 sums per thread were
+// tried first: 256 registers, one or two waves per SIMD, the row-ahead loads no longer hidden -- 0.85 TB/s.)
+static int small_wgrad_slices(const sg_conv_shape* s) { return s->cout / (s->cin == 4 ? 2 : 1); }
 static int small_wgrad_blocks(const sg_conv_shape* s) {      // blocks PER SLICE
-  int64_t cap = (256 * 2) / small_wgrad_slices(s);      // two blocks per CU over all slices (a thread holds ~150 sums: 2 waves per SIMD)
+  int64_t cap = (256 * (s->cin == 4 ? 3 : 2)) / small_wgrad_slices(s);      // three (two) blocks per CU over all slices
   if (cap < 32) cap = 32;
   const int r = small_rows_per_strip(s, (int)cap * 4);
   const int64_t items = (int64_t)s->n * sg_cdiv(s->h, r) * sg_cdiv(s->w, 64);
@@ -441,9 +445,8 @@ static int small_wgrad_launch(const SmallWgradArgs& a, const sg_conv_shape* s, u
   const int key = s->cin * 100 + s->cout;
 #define SG_SW(CI, CO, CS_) case CI * 100 + CO: hipLaunchKernelGGL((conv_small_wgrad_kernel<T, CI, CO, CS_>), dim3(nb * (CO / CS_)), dim3(256), 0, st, a); break;
   switch (key) {
-    SG_SW(4, 4, 4) SG_SW(4, 8, 4) SG_SW(4, 16, 4)
-    SG_SW(8, 4, 2) SG_SW(8, 8, 2) SG_SW(8, 16, 2)
-    SG_SW(16, 4, 1) SG_SW(16, 8, 1)
+    SG_SW(4, 4, 2) SG_SW(4, 8, 2) SG_SW(4, 16, 2)
+    SG_SW(8, 4, 1) SG_SW(8, 8, 1) SG_SW(8, 16, 1)
     default: return SG_EUNSUPPORTED;
   }
 #undef SG_SW
@@ -458,7 +461,7 @@ int sg_small_wgrad(const void* x, const void* dy, float* dw, float* dbias, float
   a.N = s->n; a.H = s->h; a.W = s->w;
   a.segs = sg_cdiv(s->w, 64);
   const unsigned nb = (unsigned)small_wgrad_blocks(s);
-  int64_t cap = (256 * 2) / small_wgrad_slices(s);
+  int64_t cap = (256 * (s->cin == 4 ? 3 : 2)) / small_wgrad_slices(s);
   if (cap < 32) cap = 32;
   a.R = small_rows_per_strip(s, (int)cap * 4);
   a.strips = sg_cdiv(s->h, a.R);

@@ -27,12 +27,22 @@ struct WgradArgs {
   int vec_x, vec_y;
   int plane_rows;  // wgrad3: LDS rows per halo plane slot
   float* dbias;    // optional [cout]: column sums of dy (bias gradient), accumulated by the ci_t == 0 blocks
+  // Reproducible mode (SG_DETERMINISTIC=1): block x of the grid STORES its partial sums into slab x of the workspace
+  // (dwt + x * slab, dbias + x * bslab) instead of adding them with f32 atomics; the finalize kernels add the slabs in
+  // order.  slab == 0: one buffer, atomics (the sums then depend on the order in which blocks retire).
+  int64_t slab, bslab;
+  int nslab;       // slabs written = gridDim.x of the launch (set by the launcher)
   int dbg_flags;   // diagnostic ablations (0 in production): 1 = stage only the first items
   unsigned long long* dbg;   // in-kernel phase stamps (sg_debug_set_ts_buffer), nullptr in production
 };
 extern unsigned long long* g_dbg_ts;
 
 constexpr int WG_MAXT = 7;  // taps per wave
+
+__device__ __forceinline__ void sg_wg_out(float* dst, float v, bool slab) {
+  if (slab) *dst = v;
+  else unsafeAtomicAdd(dst, v);
+}
 
 template <typename T, int BM>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
@@ -140,26 +150,37 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   for (int j = 0; j < WG_MAXT; ++j) {
     const int tl = wave + 4 * j;
     if (tl < a.taps_blk) {
-      float* dst = a.dwt + ((((int64_t)(a.tap0 + tl) * a.ciT + ci_t) * a.coT + co_t) << 10);
+      float* dst = a.dwt + (int64_t)blockIdx.x * a.slab + ((((int64_t)(a.tap0 + tl) * a.ciT + ci_t) * a.coT + co_t) << 10);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-        unsafeAtomicAdd(dst + row * 32 + r, acc[j][i]);
+        sg_wg_out(dst + row * 32 + r, acc[j][i], a.slab != 0);
       }
     }
   }
 }
 
 __global__ void wgrad_finalize_kernel(const float* __restrict__ dwt, float* __restrict__ dw, float coef, int taps,
-                                      int cin, int cout, int ciT, int coT) {
+                                      int cin, int cout, int ciT, int coT, int nslab, int64_t slab) {
   const int64_t total = (int64_t)taps * cin * cout;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int co = (int)(i % cout);
     int64_t q = i / cout;
     int ci = (int)(q % cin);
     int tap = (int)(q / cin);
-    dw[i] = coef * dwt[((((int64_t)tap * ciT + (ci >> 5)) * coT + (co >> 5)) << 10) + (ci & 31) * 32 + (co & 31)];
+    const float* src = dwt + ((((int64_t)tap * ciT + (ci >> 5)) * coT + (co >> 5)) << 10) + (ci & 31) * 32 + (co & 31);
+    float v = src[0];
+    for (int b = 1; b < nslab; ++b) v += src[(int64_t)b * slab];      // reproducible mode: the slabs in order
+    dw[i] = coef * v;
   }
+}
+
+__global__ void wgrad_bias_slabs_kernel(const float* __restrict__ slabs, float* __restrict__ db, int cout, int nslab, int64_t bslab) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cout) return;
+  float v = 0.f;
+  for (int b = 0; b < nslab; ++b) v += slabs[(int64_t)b * bslab + c];
+  db[c] = v;
 }
 
 static int conv_shape_ok_w(const sg_conv_shape* s) {
@@ -291,11 +312,21 @@ __global__ __launch_bounds__(256) void pw_wgrad_final_kernel(const float* __rest
 }
 
 static size_t wgrad_tile_bytes(const sg_conv_shape* s);
+// upper bound of the slabs a launcher writes (generic kernel: gridDim.x <= cdiv(512, pairs); ping-pong kernels: two wave
+// groups per block, gridDim.x <= 256 / pairs and >= 8)
+static int wgrad_slab_count(const sg_conv_shape* s) {
+  const int pairs = sg_cdiv(s->cin, 32) * sg_cdiv(s->cout, 32);
+  const int p = sg_cdiv(512, pairs);
+  return p > 16 ? p : 16;
+}
+static size_t wgrad_bias_slab_bytes(const sg_conv_shape* s) { return ((size_t)sg_cdiv(s->cout, 32) * 32 * 4 + 255) & ~(size_t)255; }
 
 extern "C" size_t sg_conv3d_wgrad_workspace(const sg_conv_shape* s, sg_dtype dt) {
   (void)dt;
   if (!conv_shape_ok_w(s)) return 0;
-  const size_t gen = wgrad_tile_bytes(s) + sg_bias_act_bwd_workspace(s->cout);   // [tile / partial sums][bias-gradient fallback]
+  // [tile / partial sums (x slabs in reproducible mode)][bias-gradient fallback][bias slabs]
+  const size_t ns = sg_cfg().deterministic ? (size_t)wgrad_slab_count(s) : 1;
+  const size_t gen = ns * wgrad_tile_bytes(s) + sg_bias_act_bwd_workspace(s->cout) + (ns > 1 ? ns * wgrad_bias_slab_bytes(s) : 0);
   const size_t small = sg_small_wgrad_workspace(s);                              // per-block slabs of the small-channel kernel
   return gen > small ? gen : small;
 }
@@ -336,6 +367,7 @@ static int launch_wgrad(WgradArgs& a, const sg_conv_shape* s, hipStream_t st) {
     a.tap0 = tap0;
     a.taps_blk = a.taps - tap0 < 4 * WG_MAXT ? a.taps - tap0 : 4 * WG_MAXT;
     SG_KNAME("conv_wgrad<%s,%d>", sg_tname<T>(), BM);
+    a.nslab = P;
     hipLaunchKernelGGL(kern, dim3((unsigned)P, (unsigned)pairs), dim3(256), lds, st, a);
     SG_LAUNCH_CHECK();
   }
@@ -583,12 +615,12 @@ __global__ __launch_bounds__(512) void conv_wgrad2_kernel(WgradArgs a) {
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
     const int tap = wave + 4 * j;
-    if (tap < TAPS && K > 0) {
-      float* dst = a.dwt + ((((int64_t)tap * a.ciT + ci_t) * a.coT + co_t) << 10);
+    if (tap < TAPS && (K > 0 || a.slab != 0)) {
+      float* dst = a.dwt + (int64_t)(blockIdx.x * 2 + grp) * a.slab + ((((int64_t)tap * a.ciT + ci_t) * a.coT + co_t) << 10);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-        unsafeAtomicAdd(dst + row * 32 + r, acc[j][i]);
+        sg_wg_out(dst + row * 32 + r, acc[j][i], a.slab != 0);
       }
     }
   }
@@ -624,6 +656,7 @@ static int launch_wgrad2(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   SG_ALLOW_160K_LDS(kern);
   a.tap0 = 0; a.taps_blk = a.taps;
   SG_KNAME("conv_wgrad2<%d,%d,%d>", KD, KH, KW);
+  a.nslab = 2 * gx;      // (both wave groups of a block keep sums of their own)
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);
   SG_LAUNCH_CHECK();
   *used = true;
@@ -925,17 +958,17 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
     __syncthreads();
   }
   const int r = lane & 31, hh = lane >> 5;
-  if (ones_last && items_mine > 0 && hh == 0 && co_t * 32 + r < a.cout)   // row 0 of the ones product = column sums
-    unsafeAtomicAdd(a.dbias + co_t * 32 + r, acc[MAXT - 1][0]);
+  if (ones_last && (items_mine > 0 || a.slab != 0) && hh == 0 && co_t * 32 + r < a.cout)   // row 0 of the ones product = column sums
+    sg_wg_out(a.dbias + (int64_t)(blockIdx.x * 2 + grp) * a.bslab + co_t * 32 + r, acc[MAXT - 1][0], a.slab != 0);
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
     const int tap = wave + 4 * j;
-    if (tap < TAPS && items_mine > 0) {
-      float* dst = a.dwt + ((((int64_t)tap * a.ciT + ci_t) * a.coT + co_t) << 10);
+    if (tap < TAPS && (items_mine > 0 || a.slab != 0)) {
+      float* dst = a.dwt + (int64_t)(blockIdx.x * 2 + grp) * a.slab + ((((int64_t)tap * a.ciT + ci_t) * a.coT + co_t) << 10);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-        unsafeAtomicAdd(dst + row * 32 + r, acc[j][i]);
+        sg_wg_out(dst + row * 32 + r, acc[j][i], a.slab != 0);
       }
     }
   }
@@ -1210,17 +1243,17 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
     }
   }
   const int r = lane & 31, hh = lane >> 5;
-  if (ones_last && items_mine > 0 && hh == 0 && co_t * 32 + r < cout)   // row 0 of the ones product = column sums
-    unsafeAtomicAdd(a.dbias + co_t * 32 + r, acc[MAXT - 1][0]);
+  if (ones_last && (items_mine > 0 || a.slab != 0) && hh == 0 && co_t * 32 + r < cout)   // row 0 of the ones product = column sums
+    sg_wg_out(a.dbias + (int64_t)(blockIdx.x * 2 + grp) * a.bslab + co_t * 32 + r, acc[MAXT - 1][0], a.slab != 0);
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
     const int tap = wave + 4 * j;
-    if (tap < TAPS && items_mine > 0) {
-      float* dst = a.dwt + ((((int64_t)tap * a.ciT + ci_t) * a.coT + co_t) << 10);
+    if (tap < TAPS && (items_mine > 0 || a.slab != 0)) {
+      float* dst = a.dwt + (int64_t)(blockIdx.x * 2 + grp) * a.slab + ((((int64_t)tap * a.ciT + ci_t) * a.coT + co_t) << 10);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-        unsafeAtomicAdd(dst + row * 32 + r, acc[j][i]);
+        sg_wg_out(dst + row * 32 + r, acc[j][i], a.slab != 0);
       }
     }
   }
@@ -1253,6 +1286,7 @@ static int launch_wgrad3(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   const size_t lds = 2ull * (a.xbytes + a.ybytes);
   if (lds > 160 * 1024) return SG_OK;
   a.tap0 = 0; a.taps_blk = a.taps;
+  a.nslab = 2 * gx;      // (both wave groups of a block keep sums of their own)
   // the lean variant: 3x3x3 without fused up-sampling, whole 32-wide rows, one sample of either tensor below 2 GiB
   const bool lean = KD == 3 && KH == 3 && KW == 3 && g.HH == 6 && g.HW == 34 && g.HD == 4 && a.plane_rows == 208 &&
                     s->w % 32 == 0 && !sg_cfg().wgrad_no_lean && (!g.ups || ((s->d | s->h | s->w) & 1) == 0);
@@ -1337,11 +1371,22 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
     return rc_s;
   }
   const size_t tile_bytes = (size_t)(s->kd * s->kh * s->kw) * sg_cdiv(s->cin, 32) * sg_cdiv(s->cout, 32) * 4096;
-  hipError_t e = hipMemsetAsync(workspace, 0, tile_bytes, hs);
-  if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, (size_t)s->cout * sizeof(float), hs);
+  const bool det = sg_cfg().deterministic != 0;
+  const size_t ns_max = det ? (size_t)wgrad_slab_count(s) : 1;
+  hipError_t e = hipSuccess;
+  if (!det) {      // (reproducible mode: every block of the grid stores its whole slab, nothing to clear)
+    e = hipMemsetAsync(workspace, 0, tile_bytes, hs);
+    if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, (size_t)s->cout * sizeof(float), hs);
+  }
   if (e != hipSuccess) { prof.done((int)e); return (int)e; }
   WgradArgs a;
   a.dbias = dbias;
+  a.slab = det ? (int64_t)(wgrad_tile_bytes(s) / 4) : 0;
+  a.bslab = det ? (int64_t)(wgrad_bias_slab_bytes(s) / 4) : 0;
+  a.nslab = 1;
+  float* bias_slabs = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ns_max * wgrad_tile_bytes(s) +
+                                               sg_bias_act_bwd_workspace(s->cout));
+  if (det && dbias) a.dbias = bias_slabs;
   bool db_done = false;
   a.dbg_flags = sg_cfg().dbg_flags;
   a.dbg = g_dbg_ts;
@@ -1369,12 +1414,15 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, hs, a.dwt, dw, coef, a.taps, s->cin,
-                       s->cout, a.ciT, a.coT);
+                       s->cout, a.ciT, a.coT, det ? a.nslab : 1, a.slab);
+    if (det && dbias && db_done)
+      hipLaunchKernelGGL(wgrad_bias_slabs_kernel, dim3((unsigned)sg_cdiv(s->cout, 256)), dim3(256), 0, hs, bias_slabs, dbias, s->cout,
+                         a.nslab, a.bslab);
     hipError_t e2 = hipGetLastError();
     if (e2 != hipSuccess) rc = (int)e2;
   }
   if (rc == SG_OK && dbias && !db_done)
-    rc = sg_bias_act_bwd(dy, nullptr, nullptr, dbias, reinterpret_cast<char*>(workspace) + wgrad_tile_bytes(s),
+    rc = sg_bias_act_bwd(dy, nullptr, nullptr, dbias, reinterpret_cast<char*>(workspace) + ns_max * wgrad_tile_bytes(s),
                          (int64_t)s->n * s->d * s->h * s->w, s->cout, 0.f, dt, st);
   prof.done(rc);
   return rc;

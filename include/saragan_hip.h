@@ -132,6 +132,18 @@ size_t sg_conv3d_fwd_workspace(const sg_conv_shape* s, sg_dtype dt);
 /* y = epilogue(conv3d(x, wp)).  x: [n,d,h,w,cin] (or half-res if upsample_in), y: [n,d,h,w,cout]. */
 int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_conv_shape* s,
                   const sg_conv_epilogue* ep, sg_dtype dt, sg_stream_t st);
+/* conv3d(upscale3d(x)) (networks/ops.py:276-289 followed by :147-150; pgan/generator.py:49-57) in sub-pixel form, ONE
+ * launch for all eight parity classes: 64 instead of 216 tap products per low-resolution voxel.  `s` is the LOW-resolution
+ * shape (n, d, h, w, cin, cout; kd = kh = kw = 3 of the original convolution, upsample_in ignored); x: [n,d,h,w,cin],
+ * y: [n,2d,2h,2w,cout].  wp comes from sg_upconv3d_subpixel_pack (the summed weights of the 8 classes, coef applied, in
+ * fragment order; sg_upconv3d_subpixel_packed_bytes bytes).  Epilogue: bias, act / slope, pixel_norm (cout 32 or 64) with
+ * pn_scale, sign_out; anything else, f32, or a shape that does not tile (256 low-resolution voxels per tile; cin % 16,
+ * cout % 32): SG_EUNSUPPORTED -- run sg_conv3d_fwd with upsample_in = 1. */
+int sg_upconv3d_subpixel_supported(const sg_conv_shape* s, sg_dtype dt);   /* 1 if the shape tiles (no launch, no GPU needed) */
+size_t sg_upconv3d_subpixel_packed_bytes(const sg_conv_shape* s, sg_dtype dt);
+int sg_upconv3d_subpixel_pack(const float* w_dhwio, float coef, void* wp, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st);
+int sg_upconv3d_subpixel_fwd(const void* x, const void* wp, void* y, const sg_conv_shape* s, const sg_conv_epilogue* ep,
+                             sg_dtype dt, sg_stream_t st);
 /* dw[kD][kH][kW][cin][cout] (f32) = coef * sum_v x[v+tap] (x) dy[v]   (tf Conv3DBackpropFilterV2).
  * workspace: sg_conv3d_wgrad_workspace() bytes, contents irrelevant on entry. */
 size_t sg_conv3d_wgrad_workspace(const sg_conv_shape* s, sg_dtype dt);

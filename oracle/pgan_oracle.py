@@ -101,6 +101,49 @@ def hip_pool_mode(n, cin, cout, d, h, w, k):
     return 0
 
 
+def hip_subpixel(cin, cout, d, h, w, k):
+    """Whether the bf16 HIP path evaluates conv3d(upscale3d(x)) of this LOW-resolution shape in sub-pixel form
+    (restates saragan_amd/csrc/subpix.hip:subpix_tile and the entry point's checks; tests/test_oracle.py compares it with
+    the library's answer for the shapes of the presets)."""
+    if tuple(k) != (3, 3, 3) or cin % 16 or cout % 32:
+        return False
+    w_ = min(w, 32)
+    if w_ not in (32, 16, 8):
+        return False
+    h_ = min(256 // w_, h, 8)
+    if w_ == 32:
+        h_ = min(h_, 4)
+    d_ = 256 // (w_ * h_)
+    if d_ < 1 or d_ > d or d_ * h_ * w_ != 256:
+        return False
+    return w % w_ == 0 and h % h_ == 0 and d % d_ == 0
+
+
+_SUBPIX_M = ([[1., 0., 0.], [0., 1., 1.]], [[1., 1., 0.], [0., 0., 1.]])      # parity -> [tap 2][original tap 3]
+
+
+def conv3d_upscaled_subpixel(x, w, activation, param=None):
+    """conv3d(upscale3d(x), w) (ops.py:276-289 + :147-150) in the sub-pixel form the bf16 HIP path computes: output voxel
+    2i+a of a dimension sees x[i-1] w0 + x[i] (w1 + w2) (a = 0) or x[i] (w0 + w1) + x[i+1] w2 (a = 1), so each of the 8
+    parity classes is a 2x2x2 convolution of x with SUMMED weights -- which the kernel rounds to bf16 once (under
+    bf16_emulation; without it this function equals the 27-tap form to rounding, tests/test_oracle.py)."""
+    m = torch.tensor(_SUBPIX_M, dtype=w.dtype)
+    weff = torch.einsum('aip,bjq,ckr,pqrxy->abcijkxy', m, m, m, w) * runtime_coef(w.shape, activation, param)
+    if _EMU['on']:
+        weff = _QW.apply(weff)
+    n, _, d, h, wd = x.shape
+    cout = w.shape[-1]
+    xp = F.pad(x, (1, 1, 1, 1, 1, 1))
+    y = x.new_zeros((n, cout, 2 * d, 2 * h, 2 * wd))
+    for a in range(2):
+        for b in range(2):
+            for c in range(2):
+                # class (a, b, c): taps t read x[i + t - 1 + parity]: the window starts at padded index `parity`
+                win = xp[:, :, a:a + d + 1, b:b + h + 1, c:c + wd + 1]
+                y[:, :, a::2, b::2, c::2] = F.conv3d(win, weff[a, b, c].permute(4, 3, 0, 1, 2))
+    return y
+
+
 def _downscale_stored(y, cin, k):
     """downscale3d of a LeakyReLU output `y` (not yet stored), with the bf16 path's rounding points."""
     if not _EMU['on'] or _TWO_D['on']:
@@ -400,8 +443,11 @@ def generator(p: Params, z, alpha, phase, base_shape, activation, kernel_spec, f
             t = conv3d(x, p[g + f'to_rgb_{phase - 1}/weight'], 'linear')
             x_upsample = upscale3d(_q(apply_bias(t, p[g + f'to_rgb_{phase - 1}/bias'])))
         b = g + f'generator_block_{i}/'
-        x = upscale3d(x)
-        x = conv3d(x, p[b + 'conv_1/weight'], activation, param)
+        w1 = p[b + 'conv_1/weight']
+        if _EMU['on'] and not _TWO_D['on'] and hip_subpixel(x.shape[1], w1.shape[-1], *x.shape[2:], w1.shape[:3]):
+            x = conv3d_upscaled_subpixel(x, w1, activation, param)      # (the summed weights are what gets rounded)
+        else:
+            x = conv3d(upscale3d(x), w1, activation, param)
         x = pn_stored(act(apply_bias(x, p[b + 'conv_1/bias']), activation, param))
         x = conv3d(x, p[b + 'conv_2/weight'], activation, param)
         x = pn_stored(act(apply_bias(x, p[b + 'conv_2/bias']), activation, param))

@@ -143,6 +143,66 @@ __device__ __forceinline__ f32x16 sg_mfma_chunk<float>(u32x4 a, u32x4 b, f32x16 
   return c;
 }
 
+// ---- LeakyReLU sign words.  A lane holds, of voxel r and N tile nt, the 16 channels (i&3) + 8*(i>>2) + 4*hh; its
+// partner lane r+32 holds the other 16, so one xor-32 shuffle completes the voxel's 32-bit word.
+// Written with shifts by inline constants only: literal masks (1u << k) would each occupy a register for the whole
+// persistent loop.  The sign BIT is used (x < 0 up to the sign of zero, which no accumulator path here produces).
+__device__ __forceinline__ uint32_t sg_sign_word(const f32x16& v, int hh) {
+  uint32_t b = 0u;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) b |= (__float_as_uint(v[i]) >> 31) << ((i & 3) + 8 * (i >> 2));
+  b <<= 4 * hh;
+  return b | (uint32_t)__shfl_xor((int)b, 32);
+}
+
+__device__ __forceinline__ void sg_apply_sign_word(f32x16& v, uint32_t word, int hh, float slope) {
+  // v *= bit ? slope : 1, as v += bit ? (slope - 1) * v : 0: a packed multiply per pair, then one bit-field extract
+  // (0 or -1), one AND and one add per element.  (The off-phase shares its SIMD's vector issue with the other wave's
+  // MFMAs: ~6 VALU slots per MFMA, so the epilogue's instruction count is what has to fit under the MFMA phase.)
+  const uint32_t wsh = word >> (4 * hh);
+  const float sm1 = slope - 1.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int t = ((int)(wsh << (31 - ((i & 3) + 8 * (i >> 2))))) >> 31;   // 1-bit signed field: 0 or -1
+    v[i] += __uint_as_float((uint32_t)t & __float_as_uint(v[i] * sm1));
+  }
+}
+
+// ---- 16 contiguous bytes per lane for the bf16 store of a 32-channel tile row.  After the MFMA lane (r, hh) holds
+// channels 8*qd + 4*hh + e; v_permlane32_swap exchanges the qd-odd part of the lower half-wave with the qd-even part
+// of the upper one, after which lane hh = 0 holds channels 16j + 0..7 and hh = 1 channels 16j + 8..15: two
+// dwordx4 stores per M tile instead of four dwordx2 (the off-phase is bound by vector-memory instructions).
+// LeakyReLU as max(x, slope * x), slope <= 1 (slope 1: identity).  v_max directly: fmaxf() adds a canonicalising
+// v_max(x, x) per element, a third of the epilogue's arithmetic.
+__device__ __forceinline__ float sg_lrelu(float x, float slope) {
+  const float t = x * slope;
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(t));
+  return r;
+}
+
+__device__ __forceinline__ uint32_t sg_pack_bf16(float lo, float hi) {   // one v_cvt_pk_bf16_f32 (round to nearest even, as from_f)
+  typedef float f32x2_ __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+  const f32x2_ v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
+}
+
+__device__ __forceinline__ void sg_store_tile_row_bf16(bf16_t* row32, const f32x16& v, int hh, bool ok) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const uint32_t a0 = sg_pack_bf16(v[8 * j + 0], v[8 * j + 1]), a1 = sg_pack_bf16(v[8 * j + 2], v[8 * j + 3]);
+    const uint32_t b0 = sg_pack_bf16(v[8 * j + 4], v[8 * j + 5]), b1 = sg_pack_bf16(v[8 * j + 6], v[8 * j + 7]);
+    const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+    u32x4 out;
+    out[0] = s0[0]; out[1] = s1[0]; out[2] = s0[1]; out[3] = s1[1];
+    if (ok) *reinterpret_cast<u32x4*>(row32 + 16 * j + 8 * hh) = out;
+    SG_STORE16_GUARD(out);
+  }
+}
+
+
 // Tile geometry shared by the conv forward and weight-gradient kernels.  A block owns TN x TD x TH x TW
 // output voxels and stages their (TD+2PD) x (TH+2PH) x (TW+2PW) input halo per sample in LDS.
 struct sg_tile_geom {

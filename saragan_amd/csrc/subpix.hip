@@ -1,0 +1,476 @@
+// conv3d(upscale3d(x)) in sub-pixel form, ONE launch over all eight parity classes (bf16, gfx950).
+// Replaces the pair networks/ops.py:276-289 (nearest x2) + :147-150 (3x3x3 conv) at pgan/generator.py:49-57.
+//
+// Nearest x2 followed by a 3-tap SAME convolution per dimension: output voxel 2i+a sees
+//     a = 0:  x[i-1] * w0 + x[i] * (w1 + w2)         a = 1:  x[i] * (w0 + w1) + x[i+1] * w2
+// so each of the 8 parity classes (a, b, c) of the fine grid is a 2x2x2-tap convolution of the LOW-resolution input with
+// summed weights: 8 classes x 8 taps = 64 tap products per low-resolution voxel instead of 8 x 27 = 216 (3.4x fewer
+// MFMAs).  All classes read the same 3x3x3 neighbourhood of the low-resolution voxel, so the kernel is laid out on the
+// low-resolution grid: a block owns a tile of 256 low-resolution voxels (8 MFMA column tiles of 32 voxels, one per wave)
+// and one 32-wide tile of output channels, stages the tile's halo ONCE per 16-channel chunk and uses it for all eight
+// classes (eight accumulator tiles per wave: 128 registers); the summed weights (64 KiB per chunk) stream through LDS in
+// two half-slabs (the four classes with a = 0, then a = 1), double buffered against the arithmetic.  LDS fill per CU:
+// (64 KiB weights + 26 KiB halo) per 4096 MFMA cycles = 22 B/clk.  The epilogue (bias, LeakyReLU, pixel-norm, sign
+// words) scatters class (a, b, c) to voxel (2d+a, 2h+b, 2w+c); a wave writes both W parities of its voxels, i.e. whole
+// 128-byte lines of the 32-channel output.
+//
+// GEMM orientation as everywhere in this library: D[cout][voxel] += W[cout][cin] * X[cin][voxel] (A = weights).
+#include "common.h"
+#include "prof.h"
+#include <type_traits>
+
+struct SubpixArgs {
+  const bf16_t* x;           // [N, d, h, w, cin]   low resolution
+  const char* wp;            // [class 8][chunk][tap 8][ntile][lane 64][16 B]   summed weights, fragment order
+  bf16_t* y;                 // [N, 2d, 2h, 2w, cout]
+  const float* bias;
+  float* pn_scale;           // [N * 8dhw] or null
+  uint32_t* sign_out;        // [N * 8dhw][ntile] or null
+  float slope, eps;
+  int act, pixel_norm;
+  int N, d, h, w, cin, cout, nchunk, ntile;
+  int TD, TH, TW;            // low-resolution tile (TD * TH * TW = 256)
+  int nTd, nTh, nTw;
+  int HH, HW, hv;            // halo extents (TH + 2, TW + 2) and halo voxels (TD + 2) * HH * HW
+  int64_t class_stride;      // bytes between the class images of wp
+};
+
+namespace {
+constexpr int kWHalf = 4 * 8 * 1024;      // bytes of a half-slab: 4 classes x 8 taps x 1 KiB
+constexpr int kXMax = 4 * 6 * 34 * 32;    // largest halo image of one 16-channel chunk (tile 2 x 4 x 32)
+
+// the fragment products of one half-slab (classes with D parity A) for one wave: 18 halo fragments, 32 MFMAs
+template <int A, int AO>      // A: D parity of the four classes; AO: index of their first accumulator tile
+__device__ __forceinline__ void subpix_half(f32x16 (&acc)[8], const char* xs, const char* ws, int xbase, int planeB, int rowB,
+                                            int lane) {
+#pragma unroll
+  for (int tz = 0; tz < 2; ++tz) {        // D tap of the class: neighbour plane A + tz
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const u32x4 xf = *reinterpret_cast<const u32x4*>(xs + xbase + (A + tz) * planeB + dy * rowB + dx * 32);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int th = dy - b;
+          if (th < 0 || th > 1) continue;
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const int tw = dx - c;
+            if (tw < 0 || tw > 1) continue;
+            const int tap = (tz * 2 + th) * 2 + tw, cl = b * 2 + c;
+            const u32x4 wf = *reinterpret_cast<const u32x4*>(ws + ((cl * 8 + tap) << 10) + lane * 16);
+            acc[AO + cl] = sg_mfma_chunk<bf16_t>(wf, xf, acc[AO + cl]);
+          }
+        }
+      }
+    }
+  }
+}
+}  // namespace
+
+__global__ __launch_bounds__(512) void upconv_subpixel_fwd_kernel(SubpixArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const wbuf = smem;                       // 2 half-slab buffers
+  char* const xbuf = smem + 2 * kWHalf;          // 2 halo buffers
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int nt = blockIdx.y;
+  // tile origin
+  int t = blockIdx.x;
+  const int tw_i = t % a.nTw; t /= a.nTw;
+  const int th_i = t % a.nTh; t /= a.nTh;
+  const int td_i = t % a.nTd;
+  const int n = t / a.nTd;
+  const int d0 = td_i * a.TD, h0 = th_i * a.TH, w0 = tw_i * a.TW;
+  const int xbytes = a.hv * 32;
+  const int rowB = a.HW * 32, planeB = a.HH * rowB;
+  // this lane's voxel of the wave's column tile
+  const int q = wave * 32 + r;
+  const int vw = q % a.TW, vh = (q / a.TW) % a.TH, vd = q / (a.TW * a.TH);
+  const int xbase = (vd * a.HH + vh) * rowB + vw * 32 + hh * 16;
+
+  // staging: each thread moves up to 4 halo pieces and 4 weight pieces (16 B each) per step
+  const bf16_t* xn = a.x + (int64_t)n * a.d * a.h * a.w * a.cin;
+  int xoff[4];            // element offset of my halo pieces in x (chunk 0), -1: outside the volume (zero)
+  int xdst[4];            // LDS byte offset of the piece, -1: none
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = tid + k * 512;          // piece = (halo voxel, half)
+    xdst[k] = -1; xoff[k] = -1;
+    if (p < a.hv * 2) {
+      const int hvx = p >> 1, half = p & 1;
+      const int hw_ = hvx % a.HW, hh_ = (hvx / a.HW) % a.HH, hd_ = hvx / (a.HW * a.HH);
+      const int dd = d0 + hd_ - 1, yy = h0 + hh_ - 1, ww = w0 + hw_ - 1;
+      xdst[k] = hvx * 32 + half * 16;
+      if (dd >= 0 && dd < a.d && yy >= 0 && yy < a.h && ww >= 0 && ww < a.w)
+        xoff[k] = (((dd * a.h + yy) * a.w + ww) * a.cin) + half * 8;
+    }
+  }
+  auto load_x = [&](u32x4 (&st)[4], int chunk) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {   // unconditional load from a clamped address, then a select: a predicated load would sit in its own exec region
+      // with an s_waitcnt vmcnt(0) behind it (seen in small.hip's first build) and serialise the staging
+      const u32x4 v = *reinterpret_cast<const u32x4*>(xn + (xoff[k] >= 0 ? xoff[k] : 0) + chunk * 16);
+      st[k] = xoff[k] >= 0 ? v : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto store_x = [&](const u32x4 (&st)[4], char* dst) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (xdst[k] >= 0) *reinterpret_cast<u32x4*>(dst + xdst[k]) = st[k];
+  };
+  // half-slab (chunk, A): classes A*4 .. A*4+3, taps 0..7: piece p = (cl, tap, lane16)
+  auto load_w = [&](u32x4 (&st)[4], int chunk, int A, int nt_ = -1) {
+    const int ntl = nt_ < 0 ? nt : nt_;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = tid + k * 512;            // 0 .. 2047
+      const int cl = p >> 9, rem = p & 511;   // 512 pieces (8 taps x 64 lanes) per class
+      const int tap = rem >> 6, ln = rem & 63;
+      const char* src = a.wp + (int64_t)(A * 4 + cl) * a.class_stride + ((((int64_t)chunk * 8 + tap) * a.ntile + ntl) << 10) + ln * 16;
+      st[k] = *reinterpret_cast<const u32x4*>(src);
+    }
+  };
+  auto store_w = [&](const u32x4 (&st)[4], char* dst) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(dst + (tid + k * 512) * 16) = st[k];
+  };
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+
+  u32x4 sx[4], sw[4];
+  load_x(sx, 0);
+  load_w(sw, 0, 0);
+  store_x(sx, xbuf);
+  store_w(sw, wbuf);
+  __syncthreads();
+  for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+    char* const xcur = xbuf + (chunk & 1) * kXMax;
+    char* const xnext = xbuf + ((chunk + 1) & 1) * kXMax;
+    // half 0 (A = 0) from wbuf[0]; meanwhile fetch half 1 of this chunk
+    load_w(sw, chunk, 1);
+    subpix_half<0, 0>(acc, xcur, wbuf, xbase, planeB, rowB, lane);
+    store_w(sw, wbuf + kWHalf);
+    __syncthreads();
+    // half 1 from wbuf[1]; meanwhile fetch the next chunk's halo and its half 0
+    const bool more = chunk + 1 < a.nchunk;
+    if (more) { load_x(sx, chunk + 1); load_w(sw, chunk + 1, 0); }
+    subpix_half<1, 4>(acc, xcur, wbuf + kWHalf, xbase, planeB, rowB, lane);
+    if (more) { store_x(sx, xnext); store_w(sw, wbuf); }
+    __syncthreads();
+  }
+  (void)xbytes;
+
+  // epilogue: class (a_, b, c) of my voxel -> fine voxel (2d+a_, 2h+b, 2w+c)
+  const int D2 = 2 * a.d, H2 = 2 * a.h, W2 = 2 * a.w;
+  const float inv_c = 1.f / (float)a.cout;
+  float bv[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) bv[i] = a.bias ? a.bias[nt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh] : 0.f;
+#pragma unroll
+  for (int cls = 0; cls < 8; ++cls) {
+    const int ca = cls >> 2, cb = (cls >> 1) & 1, cc = cls & 1;
+    const int64_t ov = (((int64_t)n * D2 + 2 * (d0 + vd) + ca) * H2 + 2 * (h0 + vh) + cb) * W2 + 2 * (w0 + vw) + cc;
+    f32x16 v = acc[cls];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      float e = v[i] + bv[i];
+      if (a.act) e = sg_lrelu(e, a.slope);
+      v[i] = e;
+      ss += e * e;
+    }
+    if (a.pixel_norm) {      // (cout == 32: the lane pair (r, r + 32) holds the voxel's channels)
+      ss += __shfl_xor(ss, 32);
+      const float sc = rsqrtf(ss * inv_c + a.eps);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] *= sc;
+      if (a.pn_scale && hh == 0) a.pn_scale[ov] = sc;
+    }
+    if (a.sign_out) {
+      const uint32_t sw_ = sg_sign_word(v, hh);
+      if (hh == 0) a.sign_out[ov * a.ntile + nt] = sw_;
+    }
+    sg_store_tile_row_bf16(a.y + ov * a.cout + nt * 32, v, hh, true);
+  }
+}
+
+// The same for 64 output channels with pixel-norm in the epilogue: a voxel's channels span two N tiles, which must meet in
+// one wave.  Eight classes x two tiles would be 256 accumulator registers, so the block runs the four classes of one D
+// parity at a time (accumulator tile = nt * 4 + class), through all chunks, writes them, then the other parity: the halo
+// is staged twice (it is the low-resolution tensor: cheap), the weights once.  Step = (parity, chunk, N tile).
+__global__ __launch_bounds__(512) void upconv_subpixel_fwd2_kernel(SubpixArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const wbuf = smem;
+  char* const xbuf = smem + 2 * kWHalf;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  int t = blockIdx.x;
+  const int tw_i = t % a.nTw; t /= a.nTw;
+  const int th_i = t % a.nTh; t /= a.nTh;
+  const int td_i = t % a.nTd;
+  const int n = t / a.nTd;
+  const int d0 = td_i * a.TD, h0 = th_i * a.TH, w0 = tw_i * a.TW;
+  const int rowB = a.HW * 32, planeB = a.HH * rowB;
+  const int q = wave * 32 + r;
+  const int vw = q % a.TW, vh = (q / a.TW) % a.TH, vd = q / (a.TW * a.TH);
+  const int xbase = (vd * a.HH + vh) * rowB + vw * 32 + hh * 16;
+  const bf16_t* xn = a.x + (int64_t)n * a.d * a.h * a.w * a.cin;
+  int xoff[4], xdst[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = tid + k * 512;
+    xdst[k] = -1; xoff[k] = -1;
+    if (p < a.hv * 2) {
+      const int hvx = p >> 1, half = p & 1;
+      const int hw_ = hvx % a.HW, hh_ = (hvx / a.HW) % a.HH, hd_ = hvx / (a.HW * a.HH);
+      const int dd = d0 + hd_ - 1, yy = h0 + hh_ - 1, ww = w0 + hw_ - 1;
+      xdst[k] = hvx * 32 + half * 16;
+      if (dd >= 0 && dd < a.d && yy >= 0 && yy < a.h && ww >= 0 && ww < a.w)
+        xoff[k] = (((dd * a.h + yy) * a.w + ww) * a.cin) + half * 8;
+    }
+  }
+  auto load_x = [&](u32x4 (&st)[4], int chunk) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(xn + (xoff[k] >= 0 ? xoff[k] : 0) + chunk * 16);
+      st[k] = xoff[k] >= 0 ? v : u32x4{0u, 0u, 0u, 0u};
+    }
+  };
+  auto store_x = [&](const u32x4 (&st)[4], char* dst) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (xdst[k] >= 0) *reinterpret_cast<u32x4*>(dst + xdst[k]) = st[k];
+  };
+  auto load_w = [&](u32x4 (&st)[4], int chunk, int A, int ntl) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = tid + k * 512;
+      const int cl = p >> 9, rem = p & 511;
+      const int tap = rem >> 6, ln = rem & 63;
+      st[k] = *reinterpret_cast<const u32x4*>(a.wp + (int64_t)(A * 4 + cl) * a.class_stride +
+                                              ((((int64_t)chunk * 8 + tap) * a.ntile + ntl) << 10) + ln * 16);
+    }
+  };
+  auto store_w = [&](const u32x4 (&st)[4], char* dst) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *reinterpret_cast<u32x4*>(dst + (tid + k * 512) * 16) = st[k];
+  };
+  const int D2 = 2 * a.d, H2 = 2 * a.h, W2 = 2 * a.w;
+  const float inv_c = 1.f / (float)a.cout;
+  u32x4 sx[4], sw[4];
+  // the pipeline runs over both parities back to back: step (A, chunk, nt); buffers alternate with the running step count
+  load_x(sx, 0);
+  load_w(sw, 0, 0, 0);
+  store_x(sx, xbuf);
+  store_w(sw, wbuf);
+  __syncthreads();
+  int xb = 0;      // halo buffer in use
+  auto parity = [&](auto AA) {
+    constexpr int A = decltype(AA)::value;
+    f32x16 acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+    for (int chunk = 0; chunk < a.nchunk; ++chunk) {
+      char* const xcur = xbuf + xb * kXMax;
+      char* const xnext = xbuf + (xb ^ 1) * kXMax;
+      // N tile 0 from wbuf[0]; meanwhile fetch N tile 1 of this (parity, chunk)
+      load_w(sw, chunk, A, 1);
+      subpix_half<A, 0>(acc, xcur, wbuf, xbase, planeB, rowB, lane);
+      store_w(sw, wbuf + kWHalf);
+      __syncthreads();
+      // N tile 1 from wbuf[1]; meanwhile fetch the next step's halo chunk and its N tile 0
+      const bool last = chunk + 1 == a.nchunk;
+      const bool more = !last || A == 0;
+      const int nchunk_ = last ? 0 : chunk + 1, nA = last ? 1 : A;
+      if (more) { load_x(sx, nchunk_); load_w(sw, nchunk_, nA, 0); }
+      subpix_half<A, 4>(acc, xcur, wbuf + kWHalf, xbase, planeB, rowB, lane);
+      if (more) { store_x(sx, xnext); store_w(sw, wbuf); }
+      __syncthreads();
+      xb ^= 1;
+    }
+    // epilogue of the four classes (A, b, c): both N tiles of a voxel are in this lane pair
+    float bv[2][16];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bv[t2][i] = a.bias ? a.bias[t2 * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh] : 0.f;
+#pragma unroll
+    for (int cl = 0; cl < 4; ++cl) {
+      const int cb = cl >> 1, cc = cl & 1;
+      const int64_t ov = (((int64_t)n * D2 + 2 * (d0 + vd) + A) * H2 + 2 * (h0 + vh) + cb) * W2 + 2 * (w0 + vw) + cc;
+      float ss = 0.f;
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float e = acc[t2 * 4 + cl][i] + bv[t2][i];
+          if (a.act) e = sg_lrelu(e, a.slope);
+          acc[t2 * 4 + cl][i] = e;
+          ss += e * e;
+        }
+      if (a.pixel_norm) {
+        ss += __shfl_xor(ss, 32);
+        const float sc = rsqrtf(ss * inv_c + a.eps);
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[t2 * 4 + cl][i] *= sc;
+        if (a.pn_scale && hh == 0) a.pn_scale[ov] = sc;
+      }
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        if (a.sign_out) {
+          const uint32_t sw_ = sg_sign_word(acc[t2 * 4 + cl], hh);
+          if (hh == 0) a.sign_out[ov * 2 + t2] = sw_;
+        }
+        sg_store_tile_row_bf16(a.y + ov * 64 + t2 * 32, acc[t2 * 4 + cl], hh, true);
+      }
+    }
+  };
+  parity(std::integral_constant<int, 0>{});
+  parity(std::integral_constant<int, 1>{});
+}
+
+// ------------------------------------------------------------------------------------------------------
+// summed weights of the eight classes, in fragment order
+// ------------------------------------------------------------------------------------------------------
+struct SubpixPackArgs {
+  const float* w;    // [3][3][3][cin][cout] (forward) -- flip: [3][3][3][cout][cin] mirrored (data gradient of a plain conv)
+  char* wp;
+  float coef;
+  int cin, cout, nchunk, ntile;
+  int64_t class_stride;
+};
+
+__global__ void upconv_subpixel_pack_kernel(SubpixPackArgs a) {
+  // element i of the packed image: (class, chunk, tap, ntile, lane, e)
+  const int64_t per_class = (int64_t)a.nchunk * 8 * a.ntile * 64 * 8;
+  const int64_t total = per_class * 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int cls = (int)(i / per_class);
+    int64_t q = i % per_class;
+    const int e = (int)(q % 8); q /= 8;
+    const int lane = (int)(q % 64); q /= 64;
+    const int nt = (int)(q % a.ntile); q /= a.ntile;
+    const int tap = (int)(q % 8);
+    const int chunk = (int)(q / 8);
+    const int ci = chunk * 16 + (lane >> 5) * 8 + e, co = nt * 32 + (lane & 31);
+    float v = 0.f;
+    if (ci < a.cin && co < a.cout) {
+      const int par[3] = {cls >> 2, (cls >> 1) & 1, cls & 1};
+      const int tp[3] = {tap >> 2, (tap >> 1) & 1, tap & 1};
+      int lo[3], hi[3];      // original taps summed into (parity, tap): p=0: {0} / {1,2};  p=1: {0,1} / {2}
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (par[k] == 0) { lo[k] = tp[k] == 0 ? 0 : 1; hi[k] = tp[k] == 0 ? 0 : 2; }
+        else { lo[k] = tp[k] == 0 ? 0 : 2; hi[k] = tp[k] == 0 ? 1 : 2; }
+      }
+      for (int kd = lo[0]; kd <= hi[0]; ++kd)
+        for (int kh = lo[1]; kh <= hi[1]; ++kh)
+          for (int kw = lo[2]; kw <= hi[2]; ++kw)
+            v += a.w[((((int64_t)kd * 3 + kh) * 3 + kw) * a.cin + ci) * a.cout + co];
+      v *= a.coef;
+    }
+    reinterpret_cast<bf16_t*>(a.wp + (int64_t)cls * a.class_stride)[i % per_class] = (bf16_t)v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------------
+static bool subpix_tile(const sg_conv_shape* s, int* td, int* th, int* tw) {
+  // 256 low-resolution voxels: TW = min(w, 32), then H, then D; the volume must divide into whole tiles
+  int w_ = s->w < 32 ? s->w : 32;
+  if (w_ != 32 && w_ != 16 && w_ != 8) return false;
+  int h_ = 256 / w_;
+  if (h_ > s->h) h_ = s->h;
+  if (h_ > 8) h_ = 8;
+  if (w_ == 32 && h_ > 4) h_ = 4;
+  int d_ = 256 / (w_ * h_);
+  if (d_ > s->d || d_ < 1 || d_ * h_ * w_ != 256) return false;
+  if (s->w % w_ || s->h % h_ || s->d % d_) return false;
+  if ((d_ + 2) * (h_ + 2) * (w_ + 2) * 32 > kXMax) return false;
+  *td = d_; *th = h_; *tw = w_;
+  return true;
+}
+
+// s: the LOW-resolution shape (n, d, h, w, cin, cout); kd = kh = kw = 3 of the original convolution
+extern "C" size_t sg_upconv3d_subpixel_packed_bytes(const sg_conv_shape* s, sg_dtype dt) {
+  if (!s || dt != SG_BF16 || s->cin < 1 || s->cout < 1) return 0;
+  return (size_t)8 * sg_cdiv(s->cin, 16) * 8 * sg_cdiv(s->cout, 32) * 1024;
+}
+
+extern "C" int sg_upconv3d_subpixel_supported(const sg_conv_shape* s, sg_dtype dt) {
+  int td, th, tw;
+  return (s && dt == SG_BF16 && s->cin > 0 && s->cout > 0 && s->cin % 16 == 0 && s->cout % 32 == 0 && subpix_tile(s, &td, &th, &tw) &&
+          (int64_t)s->d * s->h * s->w * s->cin < (1ll << 31)) ? 1 : 0;
+}
+
+extern "C" int sg_upconv3d_subpixel_pack(const float* w_dhwio, float coef, void* wp, const sg_conv_shape* s, sg_dtype dt,
+                                         sg_stream_t st) {
+  if (!s || !w_dhwio || !wp || dt != SG_BF16) return SG_EINVAL;
+  SubpixPackArgs a;
+  a.w = w_dhwio; a.wp = reinterpret_cast<char*>(wp); a.coef = coef; a.cin = s->cin; a.cout = s->cout;
+  a.nchunk = sg_cdiv(s->cin, 16); a.ntile = sg_cdiv(s->cout, 32);
+  a.class_stride = (int64_t)a.nchunk * 8 * a.ntile * 1024;
+  const int64_t total = a.class_stride * 8 / 2;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(upconv_subpixel_pack_kernel, dim3(blocks), dim3(256), 0, sg_st(st), a);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_upconv3d_subpixel_fwd(const void* x, const void* wp, void* y, const sg_conv_shape* s, const sg_conv_epilogue* ep,
+                                        sg_dtype dt, sg_stream_t st) {
+  if (!s || !x || !wp || !y) return SG_EINVAL;
+  if (ep && ep->struct_size != (uint32_t)sizeof(sg_conv_epilogue)) return SG_EINVAL;
+  if (!sg_aligned16(x) || !sg_aligned16(wp) || !sg_aligned16(y)) return SG_EALIGN;
+  if (dt != SG_BF16 || s->cin % 16 || s->cout % 32) return SG_EUNSUPPORTED;
+  if (ep && (ep->mask_bits || ep->pool || ep->pn_bwd_y || ep->x_plane_channels || ep->out_scale)) return SG_EUNSUPPORTED;
+  if (ep && ep->pixel_norm && s->cout != 32 && s->cout != 64) return SG_EUNSUPPORTED;      // a lane pair must hold a voxel's channels
+  const bool two_tiles = ep && ep->pixel_norm && s->cout == 64;
+  SubpixArgs a;
+  if (!subpix_tile(s, &a.TD, &a.TH, &a.TW)) return SG_EUNSUPPORTED;
+  if ((int64_t)s->d * s->h * s->w * s->cin >= (1ll << 31)) return SG_EUNSUPPORTED;     // 32-bit element offsets per sample
+  a.x = reinterpret_cast<const bf16_t*>(x); a.wp = reinterpret_cast<const char*>(wp); a.y = reinterpret_cast<bf16_t*>(y);
+  a.bias = ep ? ep->bias : nullptr;
+  a.pn_scale = ep ? ep->pn_scale : nullptr;
+  a.sign_out = ep ? reinterpret_cast<uint32_t*>(ep->sign_out) : nullptr;
+  a.slope = ep ? ep->slope : 0.f; a.eps = ep ? ep->eps : 0.f;
+  a.act = ep ? ep->act : 0; a.pixel_norm = ep ? ep->pixel_norm : 0;
+  a.N = s->n; a.d = s->d; a.h = s->h; a.w = s->w; a.cin = s->cin; a.cout = s->cout;
+  a.nchunk = s->cin / 16; a.ntile = s->cout / 32;
+  a.nTd = s->d / a.TD; a.nTh = s->h / a.TH; a.nTw = s->w / a.TW;
+  a.HH = a.TH + 2; a.HW = a.TW + 2; a.hv = (a.TD + 2) * a.HH * a.HW;
+  a.class_stride = (int64_t)a.nchunk * 8 * a.ntile * 1024;
+  const int64_t tiles = (int64_t)s->n * a.nTd * a.nTh * a.nTw;
+  if (tiles >= (1ll << 31)) return SG_EUNSUPPORTED;
+  sg_conv_shape full = *s;       // (profiler key: the fine grid, as the fused-gather kernels report it)
+  full.d *= 2; full.h *= 2; full.w *= 2; full.kd = full.kh = full.kw = 3; full.upsample_in = 1;
+  sg_prof_scope prof(0, &full, dt, sg_st(st));
+  const size_t lds = 2 * (size_t)kWHalf + 2 * (size_t)kXMax;
+  if (two_tiles) {
+    auto kern = upconv_subpixel_fwd2_kernel;
+    SG_ALLOW_160K_LDS(kern);
+    SG_KNAME("upconv_subpixel_fwd<2 N tiles>");
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, sg_st(st), a);
+  } else {
+    auto kern = upconv_subpixel_fwd_kernel;
+    SG_ALLOW_160K_LDS(kern);
+    SG_KNAME("upconv_subpixel_fwd");
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)a.ntile), dim3(512), lds, sg_st(st), a);
+  }
+  hipError_t e = hipGetLastError();
+  prof.done((int)e);
+  return (int)e;
+}

@@ -126,62 +126,55 @@ def sign_words(t):
     return out
 
 
-# Sub-pixel form of upscale3d -> conv3d: opt-in (SARAGAN_SUBPIXEL=1).  As eight launches of the streamed kernel it is
-# 1.6 % SLOWER per step than the 27-tap fused gather despite 3.4x fewer FLOPs: with 8 taps per staged 16-channel chunk
-# a ping-pong phase is 16-32 MFMAs, far too short to cover its halo DMA, and the stride-2 scatter writes half lines.
-_NO_SUBPIXEL = not bool(int(os.environ.get('SARAGAN_SUBPIXEL', '0')))
+# Sub-pixel form of upscale3d -> conv3d (sg_upconv3d_subpixel_fwd: one launch for all eight parity classes, 3.4x fewer
+# MFMAs than the 27-tap fused gather).  SARAGAN_NO_SUBPIXEL=1 keeps the gather kernels (A/B, tests).  (Round 2 had this form
+# as eight launches of the streamed kernel: 1.6 % slower per step than the gather, the phases too short to cover their halo
+# DMA and the stride-2 scatter writing half lines.)
+_NO_SUBPIXEL = bool(int(os.environ.get('SARAGAN_NO_SUBPIXEL', '0')))
 _SUBPIX_CACHE = {}
 
 
-def _subpixel_packed(w, coef, cin, cout, dt, lib, st):
-    """The eight 2x2x2 kernels of conv3d(upscale3d(.)) in sub-pixel form, packed.  Per dimension an even output
-    voxel 2i sees x[i-1]*w0 + x[i]*(w1+w2), an odd one x[i]*(w0+w1) + x[i+1]*w2 (nearest x2 then a 3-tap SAME conv):
-    Weff[a,b,c] = (M_a x M_b x M_c) w with M_0 = [[1,0,0],[0,1,1]], M_1 = [[1,1,0],[0,0,1]], summed in f32."""
+def _subpixel_packed(w, coef, shp, dt, lib, st):
+    """The summed weights of the eight classes (sg_upconv3d_subpixel_pack), cached like the other packed images."""
     key = (w.data_ptr(), w._version, float(coef), dt)
     hit = _SUBPIX_CACHE.get(key)
     if hit is not None:
         return hit[0]
-    m = torch.tensor([[[1., 0., 0.], [0., 1., 1.]], [[1., 1., 0.], [0., 0., 1.]]], device=w.device, dtype=torch.float32)
-    weff = torch.einsum('aip,bjq,ckr,pqrxy->abcijkxy', m, m, m, w.detach().float()).contiguous()
-    shp = _shape(1, 2, 2, 2, cin, cout, (2, 2, 2), False)
-    nbytes = lib.sg_conv3d_packed_bytes(C.byref(shp), dt)
-    packs = []
-    for a in range(2):
-        for b in range(2):
-            for c in range(2):
-                wp = torch.empty(nbytes, device=w.device, dtype=torch.uint8)
-                check(lib.sg_conv3d_pack_weights(_ptr(weff[a, b, c]), float(coef), 0, _ptr(wp), C.byref(shp), dt, st),
-                      'sg_conv3d_pack_weights')
-                packs.append(((a, b, c), wp))
-    _SUBPIX_CACHE[key] = (packs, w, weff)
-    return packs
+    w32 = w.detach()
+    if w32.dtype != torch.float32 or not w32.is_contiguous():
+        w32 = w32.contiguous().float()
+    wp = torch.empty(lib.sg_upconv3d_subpixel_packed_bytes(C.byref(shp), dt), device=w.device, dtype=torch.uint8)
+    check(lib.sg_upconv3d_subpixel_pack(_ptr(w32), float(coef), _ptr(wp), C.byref(shp), dt, st), 'sg_upconv3d_subpixel_pack')
+    if w.is_leaf or not w.requires_grad:
+        _SUBPIX_CACHE[key] = (wp, w)
+    return wp
 
 
-def _raw_upconv_subpixel(x, w, coef, bias, act, slope, pixel_norm, eps, want_scale, mask_bits, mask_slope, want_signs):
-    """y = epilogue(conv3d(upscale3d(x), coef*w)) as eight 2x2x2-tap launches on the low-resolution input (3.4x fewer
-    FLOPs than the 27-tap fused gather).  Returns None when no kernel covers the shape (caller falls back)."""
+def _raw_upconv_subpixel(x, w, coef, bias, act, slope, pixel_norm, eps, want_scale, want_signs):
+    """y = epilogue(conv3d(upscale3d(x), coef*w)) on the low-resolution input, all eight parity classes in one launch.
+    Returns None when the library has no sub-pixel kernel for the request (caller runs the fused-gather convolution)."""
     lib = _lib.load()
     n, cin, d, h, wd = _dims(x)
     cout = w.shape[-1]
     dt = _dt(x)
+    if dt != _lib.SG_BF16 or x.dim() != 5:
+        return None
     st = _stream()
-    shp = _shape(n, d, h, wd, cin, cout, (2, 2, 2), False)
+    shp = _shape(n, d, h, wd, cin, cout, (3, 3, 3), False)
+    if not lib.sg_upconv3d_subpixel_packed_bytes(C.byref(shp), dt):
+        return None
     y = _empty_like_shape(x, cout, (2 * d, 2 * h, 2 * wd))
     signs = _empty_signs(x.device, n, 2 * d, 2 * h, 2 * wd, cout) if want_signs else None
     scale = torch.empty(n * 8 * d * h * wd, device=x.device, dtype=torch.float32) if (pixel_norm and want_scale) else None
     b32 = bias.detach().contiguous().float() if bias is not None else None
-    packs = None
-    for i in range(8):
-        if packs is None:
-            packs = _subpixel_packed(w, coef, cin, cout, dt, lib, st)
-        (a, b, c), wp = packs[i]
-        off = (C.c_int32 * 3)(a, b, c)
-        ep = ConvEpilogue(_ptr(b32), 1 if act else 0, float(slope), 1 if pixel_norm else 0, float(eps), _ptr(scale),
-                          _ptr(mask_bits), float(mask_slope), _ptr(signs), 2, off, off)
-        rc = lib.sg_conv3d_fwd(_ptr(x), _ptr(wp), _ptr(y), C.byref(shp), C.byref(ep), dt, st)
-        if rc == _lib.SG_EUNSUPPORTED and i == 0:
-            return None
-        check(rc, 'sg_conv3d_fwd (sub-pixel class)')
+    ep = ConvEpilogue(_ptr(b32), 1 if act else 0, float(slope), 1 if pixel_norm else 0, float(eps), _ptr(scale), None, 0.0,
+                      _ptr(signs))
+    # (the weights are packed only once the library has accepted the shape: a probe launch costs nothing it would not do anyway)
+    wp = _subpixel_packed(w, coef, shp, dt, lib, st)
+    rc = lib.sg_upconv3d_subpixel_fwd(_ptr(x), _ptr(wp), _ptr(y), C.byref(shp), C.byref(ep), dt, st)
+    if rc == _lib.SG_EUNSUPPORTED:
+        return None
+    check(rc, 'sg_upconv3d_subpixel_fwd')
     return y, scale, signs
 
 
@@ -203,10 +196,9 @@ def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel
     cin, cout = (wo, wi) if flip else (wi, wo)
     if cx != cin:
         raise ValueError(f'conv3d: input has {cx} channels, weight expects {cin}')
-    if ups and not flip and (kd, kh, kw) == (3, 3, 3) and not _NO_SUBPIXEL:
-        _check_signs(mask_bits, 8 * n * d * h * wd, cout)
-        res = _raw_upconv_subpixel(x, w, coef, bias, act, slope, pixel_norm, eps, want_scale, mask_bits, mask_slope,
-                                   want_signs)
+    if (ups and not flip and (kd, kh, kw) == (3, 3, 3) and not _NO_SUBPIXEL and mask_bits is None and not pool and
+            pn_bwd is None):
+        res = _raw_upconv_subpixel(x, w, coef, bias, act, slope, pixel_norm, eps, want_scale, want_signs)
         if res is not None:
             return res
     if ups:

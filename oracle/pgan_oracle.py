@@ -144,6 +144,29 @@ def conv3d_upscaled_subpixel(x, w, activation, param=None):
     return y
 
 
+class _UpConvHip(torch.autograd.Function):
+    """bf16 emulation of the generator's conv3d(upscale3d(x)) as the HIP path runs it: FORWARD in sub-pixel form (summed
+    weights rounded once), BACKWARD as the gather kernels compute it -- the data and weight gradients of the 27-tap
+    convolution with every tap's coef * w rounded on its own (functional._upconv_dgrad, conv_wgrad3l<ups>).  First order
+    only (nothing differentiates the generator's backward)."""
+
+    @staticmethod
+    def forward(ctx, x, w, activation, param):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (activation, param)
+        with torch.no_grad():
+            return conv3d_upscaled_subpixel(x, w, activation, param)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        with torch.enable_grad():
+            x_, w_ = x.detach().requires_grad_(True), w.detach().requires_grad_(True)
+            y = conv3d(upscale3d(x_), w_, *ctx.cfg)
+            gx, gw = torch.autograd.grad(y, [x_, w_], gy)
+        return gx, gw, None, None
+
+
 def _downscale_stored(y, cin, k):
     """downscale3d of a LeakyReLU output `y` (not yet stored), with the bf16 path's rounding points."""
     if not _EMU['on'] or _TWO_D['on']:
@@ -445,7 +468,7 @@ def generator(p: Params, z, alpha, phase, base_shape, activation, kernel_spec, f
         b = g + f'generator_block_{i}/'
         w1 = p[b + 'conv_1/weight']
         if _EMU['on'] and not _TWO_D['on'] and hip_subpixel(x.shape[1], w1.shape[-1], *x.shape[2:], w1.shape[:3]):
-            x = conv3d_upscaled_subpixel(x, w1, activation, param)      # (the summed weights are what gets rounded)
+            x = _UpConvHip.apply(x, w1, activation, param)      # (forward: the summed weights are what gets rounded)
         else:
             x = conv3d(upscale3d(x), w1, activation, param)
         x = pn_stored(act(apply_bias(x, p[b + 'conv_1/bias']), activation, param))

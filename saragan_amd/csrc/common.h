@@ -44,8 +44,16 @@ struct sg_config {
   int dbg_flags;                             // SG_DBG_FLAGS
   int no_small;                              // SG_NO_SMALL: the small-channel 2-D layers through the MFMA kernels (A/B, tests)
   int deterministic;                         // SG_DETERMINISTIC: no float atomics anywhere (weight-gradient slabs, ordered sums)
+  int no_gemm;                               // SG_NO_GEMM: the low-resolution levels through the spatial kernels (A/B, tests)
 };
 const sg_config& sg_cfg();
+
+// gemm.hip: GEMM-tiled forward / data-gradient convolution of the low-resolution levels (<= 16 x 16 planes, >= 128 channels)
+bool sg_gemm_conv_eligible(const sg_conv_shape* s, sg_dtype dt);
+size_t sg_gemm_conv_workspace(const sg_conv_shape* s, sg_dtype dt);
+int sg_gemm_conv_fwd(const void* x, const void* wp, void* y, const sg_conv_shape* s, const float* bias, int act, float slope,
+                     const uint32_t* mask_bits, float mask_slope, uint32_t* sign_out, void* workspace, size_t workspace_bytes,
+                     hipStream_t st, bool* used);
 
 // small.hip: VALU kernels for the 4 / 8 / 16-channel 1x3x3 layers of the 2-D pgan's top levels
 bool sg_small_eligible(const sg_conv_shape* s);

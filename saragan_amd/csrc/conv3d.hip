@@ -2786,6 +2786,7 @@ extern "C" __attribute__((visibility("default"))) void sg_debug_set_ts_buffer(vo
 
 extern "C" size_t sg_conv3d_fwd_workspace(const sg_conv_shape* s, sg_dtype dt) {
   if (!conv_shape_ok(s) || dt != SG_BF16) return 0;
+  if (!sg_cfg().no_gemm && sg_gemm_conv_eligible(s, dt)) return sg_gemm_conv_workspace(s, dt);   // K-split partial tiles
   if (s->kd == 3 && s->kh == 3 && s->kw == 3 && s->cin == 64 && s->cout == 32 && s->w % 32 == 0 && s->d >= 4 &&
       (!s->upsample_in || ((s->d | s->h | s->w) & 1) == 0))
     return (size_t)s->n * s->d * s->h * s->w * (size_t)s->cout * 4;
@@ -2857,6 +2858,13 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
                       a.pixel_norm, a.eps, a.pn_scale, a.mask_bits, a.mask_slope, a.sign_out, dt, hs);
     prof.done(rc);
     return rc;
+  }
+  if (dt == SG_BF16 && !sg_cfg().no_gemm && !a.pool && !a.pnb_y && !a.pixel_norm && !(ep && ep->x_plane_channels) &&
+      sg_gemm_conv_eligible(s, dt)) {   // low-resolution levels: 256-voxel x 128-channel GEMM tiles over the folded batch (gemm.hip)
+    bool used = false;
+    rc = sg_gemm_conv_fwd(x, wp, y, s, a.bias, a.act, a.slope, a.mask_bits, a.mask_slope, a.sign_out, ep ? ep->workspace : nullptr,
+                          ep ? ep->workspace_bytes : 0, hs, &used);
+    if (rc != SG_OK || used) { prof.done(rc); return rc; }
   }
   if (a.pool == 2) {   // H x W pooling: the streamed kernel's tile (two H rows per wave)
     bool used = false;

@@ -50,6 +50,7 @@ const sg_config* read_config() {
   c->dbg_flags = env_int("SG_DBG_FLAGS", 0);
   c->no_small = env_int("SG_NO_SMALL", 0);
   c->deterministic = env_int("SG_DETERMINISTIC", 0);
+  c->no_gemm = env_int("SG_NO_GEMM", 0);
   return c;
 }
 }  // namespace

@@ -165,8 +165,20 @@ def test_top_level_layers_exact_shapes(layer, dtype):
     yc = y.detach().double().cpu()
     assert torch.isfinite(yc).all()
     scale = float(yc.abs().max())
+    subpix = ups and dtype == torch.bfloat16 and O.hip_subpixel(cin, cout, *in_sp, k)
     for lo, hi in _boxes(sp, k):
-        ref = _oracle_box(xfull, wt, lo, hi, k) + b.double().reshape(1, -1, 1, 1, 1)
+        if subpix:
+            # the bf16 build evaluates this layer in sub-pixel form (csrc/subpix.hip): the SUMMED 2x2x2 weights are what
+            # it rounds to bf16.  Oracle: the same form (conv3d_upscaled_subpixel under bf16_emulation) on the low-resolution
+            # crop that covers the box with one voxel of margin, the margin then cut off
+            l0 = [max(lo[i] // 2 - 2, 0) for i in range(3)]
+            l1 = [min((hi[i] + 1) // 2 + 2, in_sp[i]) for i in range(3)]
+            with O.bf16_emulation():
+                rb = O.conv3d_upscaled_subpixel(x64[:, :, l0[0]:l1[0], l0[1]:l1[1], l0[2]:l1[2]], w.double(), 'leaky_relu', 0.2)
+            ref = rb[:, :, lo[0] - 2 * l0[0]:hi[0] - 2 * l0[0], lo[1] - 2 * l0[1]:hi[1] - 2 * l0[1], lo[2] - 2 * l0[2]:hi[2] - 2 * l0[2]]
+            ref = ref + b.double().reshape(1, -1, 1, 1, 1)
+        else:
+            ref = _oracle_box(xfull, wt, lo, hi, k) + b.double().reshape(1, -1, 1, 1, 1)
         ref = torch.maximum(ref, ref * 0.2)
         got = yc[:, :, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]]
         np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=rt, atol=at * scale, err_msg=f'{tag} fwd box {lo}')
@@ -195,7 +207,8 @@ def test_top_level_layers_exact_shapes(layer, dtype):
     # The LeakyReLU mask is the SIGN of y (ops.py:177).  Among ~10^5 activations a few lie within f32 summation error
     # of zero and may take the other sign on the GPU, which changes a whole 27-tap neighbourhood of dx and a slab of dw:
     # no upstream gradient flows into activations that close to zero (the mask itself is checked in test_kernels_gpu).
-    gbox = torch.where(yr_box.detach().abs() < 1e-3 * scale, torch.zeros_like(gbox), gbox)
+    # (sub-pixel forward: its pre-activations differ from this 27-tap reference's by bf16 rounding of the summed weights)
+    gbox = torch.where(yr_box.detach().abs() < (1e-2 if subpix else 1e-3) * scale, torch.zeros_like(gbox), gbox)
     gy = torch.zeros((n, cout, *sp), dtype=dtype)
     gy[:, :, lo[0]:hi[0], lo[1]:hi[1], lo[2]:hi[2]] = gbox
     gx, gw, gb = torch.autograd.grad(y, [xd, wd, bd], gy.to(dev).contiguous(memory_format=torch.channels_last_3d))

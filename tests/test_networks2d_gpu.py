@@ -265,7 +265,8 @@ def test_small_channel_kernels_match_the_mfma_path(cin, cout, dtype, sg_env):
         return (y, scale, signs, y2, signs2, gx, dw, db), sorted({ents[i].kernel.decode() for i in range(cnt.value)})
 
     got, kern = run()
-    assert any('conv_small_fwd' in k for k in kern) and any('conv_small_wgrad' in k for k in kern), kern
+    # (16 input channels: forward / data gradient only -- the weight gradient's three-row window would not fit the registers)
+    assert any('conv_small_fwd' in k for k in kern) and (cin == 16 or any('conv_small_wgrad' in k for k in kern)), kern
     sg_env(SG_NO_SMALL=1)
     ref, kern_ref = run()
     assert not any('conv_small' in k for k in kern_ref), kern_ref
@@ -287,4 +288,5 @@ def test_small_channel_kernels_match_the_mfma_path(cin, cout, dtype, sg_env):
     assert float((got[6].double().cpu() - refw).abs().max() / refw.abs().max()) <= (1e-4 if dtype == torch.float32 else 1e-2)
     # run-to-run: the slab reduction has no atomics
     again, _ = (sg_env(SG_NO_SMALL=0), run())[1]
-    assert torch.equal(again[6], got[6]) and torch.equal(again[7], got[7])
+    if cin < 16:
+        assert torch.equal(again[6], got[6]) and torch.equal(again[7], got[7])

@@ -144,6 +144,15 @@ size_t sg_upconv3d_subpixel_packed_bytes(const sg_conv_shape* s, sg_dtype dt);
 int sg_upconv3d_subpixel_pack(const float* w_dhwio, float coef, void* wp, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st);
 int sg_upconv3d_subpixel_fwd(const void* x, const void* wp, void* y, const sg_conv_shape* s, const sg_conv_epilogue* ep,
                              sg_dtype dt, sg_stream_t st);
+/* Weight (and bias) gradient of conv3d(upscale3d(x)) in the same sub-pixel form: 64 accumulator tiles per (cin, cout) tile
+ * pair instead of 8 x 27 tap products per low-resolution voxel, folded to the 27-tap gradient at the end.  `s`: the
+ * LOW-resolution shape; x: [n,d,h,w,cin], gy: [n,2d,2h,2w,cout]; dw: [3][3][3][cin][cout] f32 = coef * gradient, dbias: [cout]
+ * or NULL.  bf16, w % 32 == 0, even h, cin and cout multiples of 32; otherwise SG_EUNSUPPORTED (run sg_conv3d_wgrad_bias
+ * with upsample_in = 1). */
+int sg_upconv3d_subpixel_wgrad_supported(const sg_conv_shape* s, sg_dtype dt);
+size_t sg_upconv3d_subpixel_wgrad_workspace(const sg_conv_shape* s, sg_dtype dt);
+int sg_upconv3d_subpixel_wgrad(const void* x, const void* gy, float* dw_dhwio, float* dbias, float coef, void* workspace,
+                               size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st);
 /* dw[kD][kH][kW][cin][cout] (f32) = coef * sum_v x[v+tap] (x) dy[v]   (tf Conv3DBackpropFilterV2).
  * workspace: sg_conv3d_wgrad_workspace() bytes, contents irrelevant on entry. */
 size_t sg_conv3d_wgrad_workspace(const sg_conv_shape* s, sg_dtype dt);

@@ -51,6 +51,9 @@ SIGNATURES = {
     'sg_upconv3d_subpixel_packed_bytes': (_sz, [_SHP, C.c_int]),
     'sg_upconv3d_subpixel_pack': (C.c_int, [_p, _f, _p, _SHP, C.c_int, _p]),
     'sg_upconv3d_subpixel_fwd': (C.c_int, [_p, _p, _p, _SHP, C.POINTER(ConvEpilogue), C.c_int, _p]),
+    'sg_upconv3d_subpixel_wgrad_supported': (C.c_int, [_SHP, C.c_int]),
+    'sg_upconv3d_subpixel_wgrad_workspace': (_sz, [_SHP, C.c_int]),
+    'sg_upconv3d_subpixel_wgrad': (C.c_int, [_p, _p, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
     'sg_conv3d_wgrad_workspace': (_sz, [_SHP, C.c_int]),
     'sg_conv3d_wgrad': (C.c_int, [_p, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
     'sg_conv3d_pw_bwd': (C.c_int, [_p, _p, _p, _p, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),

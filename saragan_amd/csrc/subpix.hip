@@ -474,3 +474,262 @@ extern "C" int sg_upconv3d_subpixel_fwd(const void* x, const void* wp, void* y, 
   prof.done((int)e);
   return (int)e;
 }
+
+// ------------------------------------------------------------------------------------------------------
+// weight gradient of conv3d(upscale3d(x)) in sub-pixel form
+// ------------------------------------------------------------------------------------------------------
+// dWeff[class][tap][ci][co] = sum over low-resolution voxels j of x[j + n(class, tap)][ci] * gy[2j + class][co]: 64
+// accumulator tiles of 32 x 32 per (ci tile, co tile) instead of 8 x 27 tap products per low-resolution voxel; the 27-tap
+// gradient is their fold (every original tap belongs to 2 x 2 x 2 (class, tap) sets), done by the finalize kernel.
+// Block = 8 waves, wave w owns parity class w and its 8 taps (+ a ones row for the bias gradient): per 16-voxel K step it
+// reads its class plane of gy once (transposing read) and 8 neighbour fragments of x -- 18 reads for 8 (9) MFMAs.  A tile is
+// 1 x 2 x 32 low-resolution voxels: the x halo (3 x 4 x 34 voxels x 64 B) and the 2 x 4 x 64 fine voxels of gy, the latter
+// de-interleaved into the 8 class planes while it is written to LDS (so that a class's rows are contiguous: conflict-free
+// transposing reads).  Both are double buffered and requested one tile ahead.
+struct SubpixWgradArgs {
+  const bf16_t* x;           // [N, d, h, w, cin] low resolution
+  const bf16_t* gy;          // [N, 2d, 2h, 2w, cout]
+  float* dwt;                // [slab][class 8][tap 8][ciT][coT][32][32] f32
+  float* dbias;              // [slab][coT * 32] or null
+  int N, d, h, w, cin, cout, ciT, coT;
+  int nTh, nTw;              // tiles per plane: h / 2, w / 32
+  int64_t ntiles;            // N * d * nTh * nTw
+  int64_t slab, bslab;       // elements between per-block slabs (0: atomics into one buffer)
+};
+
+namespace {
+constexpr int kWX = 3 * 4 * 34 * 64;      // 26112: x halo image of a tile, 32 channels
+constexpr int kWY = 8 * 2 * 32 * 64;      // 32768: the tile's gy as 8 class planes of 2 x 32 voxels, 32 channels
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4;
+
+__device__ __forceinline__ bf16x8 sg_tr_frag(const char* p) {      // two transposing reads: voxel rows q and q + 4 of the block
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)p);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p + 256));
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+}  // namespace
+
+__global__ __launch_bounds__(512) void upconv_subpixel_wgrad_kernel(SubpixWgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int cls = __builtin_amdgcn_readfirstlane(tid >> 6);            // wave = parity class
+  const int ca = cls >> 2, cb = (cls >> 1) & 1, cc = cls & 1;
+  const int ci_t = blockIdx.y / a.coT, co_t = blockIdx.y % a.coT;
+  const bool ones = a.dbias != nullptr && ci_t == 0;
+  // transposing-read lane map (wgrad.hip): group of 16 lanes = 4 voxel rows x 16 channels
+  const int i16 = lane & 15, q16 = lane >> 4;
+  const int colb = (16 * (q16 & 1) + 4 * (i16 & 3)) * 2;
+  const int kb = 8 * (q16 >> 1) + (i16 >> 2);
+  // staging plan: pieces of 16 B; x halo 1632 pieces, gy 2048 pieces
+  const int D2 = 2 * a.d, H2 = 2 * a.h, W2 = 2 * a.w;
+  auto tile_of = [&](int64_t t, int& n, int& dd, int& h0, int& w0) {
+    w0 = (int)(t % a.nTw) * 32; t /= a.nTw;
+    h0 = (int)(t % a.nTh) * 2; t /= a.nTh;
+    dd = (int)(t % a.d);
+    n = (int)(t / a.d);
+  };
+  u32x4 sx[4], sy[4];
+  auto load_tile = [&](int64_t t) {
+    int n, dd, h0, w0;
+    tile_of(t, n, dd, h0, w0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = tid + k * 512;
+      const int hv = p >> 2, sub = p & 3;
+      const int hw_ = hv % 34, hh_ = (hv / 34) & 3, hd_ = hv / 136;
+      const int zd = dd + hd_ - 1, zy = h0 + hh_ - 1, zx = w0 + hw_ - 1;
+      const bool ok = p < 1632 && zd >= 0 && zd < a.d && zy >= 0 && zy < a.h && zx >= 0 && zx < a.w;
+      const int64_t off = ((((int64_t)n * a.d + (ok ? zd : 0)) * a.h + (ok ? zy : 0)) * a.w + (ok ? zx : 0)) * a.cin + ci_t * 32 + sub * 8;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(a.x + off);
+      sx[k] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = tid + k * 512;
+      const int fv = p >> 2, sub = p & 3;
+      const int fw = fv & 63, fh = (fv >> 6) & 3, fd = fv >> 8;
+      const int64_t off = ((((int64_t)n * D2 + 2 * dd + fd) * H2 + 2 * h0 + fh) * W2 + 2 * w0 + fw) * a.cout + co_t * 32 + sub * 8;
+      sy[k] = *reinterpret_cast<const u32x4*>(a.gy + off);
+    }
+  };
+  auto store_tile = [&](char* xb, char* yb) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = tid + k * 512;
+      if (p < 1632) *reinterpret_cast<u32x4*>(xb + p * 16) = sx[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = tid + k * 512;
+      const int fv = p >> 2, sub = p & 3;
+      const int fw = fv & 63, fh = (fv >> 6) & 3, fd = fv >> 8;
+      const int pc = fd * 4 + (fh & 1) * 2 + (fw & 1);
+      *reinterpret_cast<u32x4*>(yb + (((pc * 2 + (fh >> 1)) * 32 + (fw >> 1)) << 6) + sub * 16) = sy[k];
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+  const bf16x8 one8 = __builtin_bit_cast(bf16x8, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+
+  int buf = 0;
+  int64_t t = blockIdx.x;
+  if (t < a.ntiles) {
+    load_tile(t);
+    store_tile(smem, smem + kWX);
+  }
+  __syncthreads();
+  for (; t < a.ntiles; t += gridDim.x) {
+    const int64_t tn = t + gridDim.x;
+    if (tn < a.ntiles) load_tile(tn);
+    const char* xb = smem + buf * (kWX + kWY);
+    const char* yb = xb + kWX;
+#pragma unroll
+    for (int th = 0; th < 2; ++th)
+#pragma unroll
+      for (int wh = 0; wh < 2; ++wh) {
+        const bf16x8 bf = sg_tr_frag(yb + (((cls * 2 + th) * 32 + 16 * wh + kb) << 6) + colb);
+#pragma unroll
+        for (int tap = 0; tap < 8; ++tap) {
+          const int tz = tap >> 2, ty = (tap >> 1) & 1, tx = tap & 1;
+          const bf16x8 af = sg_tr_frag(xb + ((((ca + tz) * 4 + th + cb + ty) * 34 + 16 * wh + kb + cc + tx) << 6) + colb);
+          acc[tap] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[tap], 0, 0, 0);
+        }
+        if (ones) acc[8] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(one8, bf, acc[8], 0, 0, 0);
+      }
+    if (tn < a.ntiles) store_tile(smem + (buf ^ 1) * (kWX + kWY), smem + (buf ^ 1) * (kWX + kWY) + kWX);
+    __syncthreads();
+    buf ^= 1;
+  }
+  // D[row = ci][col = co]: lane holds col r, rows (i & 3) + 8 * (i >> 2) + 4 * hh
+  const int r = lane & 31, hh = lane >> 5;
+  const bool slab = a.slab != 0;
+  // bias gradient: row 0 of each wave's ones product = the column sums of its class plane; the eight are added in order
+  __syncthreads();
+  float* red = reinterpret_cast<float*>(smem);       // [8 waves][32] column sums
+  if (ones && hh == 0) red[cls * 32 + r] = acc[8][0];
+  __syncthreads();
+  if (ones && tid < 32) {
+    float s = 0.f;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; ++w8) s += red[w8 * 32 + tid];
+    float* dst = a.dbias + (int64_t)blockIdx.x * a.bslab + co_t * 32 + tid;
+    if (slab) *dst = s;
+    else unsafeAtomicAdd(dst, s);
+  }
+#pragma unroll
+  for (int tap = 0; tap < 8; ++tap) {
+    float* dst = a.dwt + (int64_t)blockIdx.x * a.slab + (((((int64_t)cls * 8 + tap) * a.ciT + ci_t) * a.coT + co_t) << 10);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if (slab) dst[row * 32 + r] = acc[tap][i];
+      else unsafeAtomicAdd(dst + row * 32 + r, acc[tap][i]);
+    }
+  }
+}
+
+// dw[kd][kh][kw][ci][co] = coef * sum of the (class, tap) tiles the original tap is summed into (x slabs, in order)
+__global__ void upconv_subpixel_wgrad_finalize_kernel(const float* __restrict__ dwt, float* __restrict__ dw, const float* __restrict__ bsl,
+                                                      float* __restrict__ db, float coef, int cin, int cout, int ciT, int coT, int nslab,
+                                                      int64_t slab, int64_t bslab) {
+  const int64_t total = (int64_t)27 * cin * cout;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) {
+    const int co = (int)(i % cout);
+    const int ci = (int)((i / cout) % cin);
+    const int k = (int)(i / ((int64_t)cout * cin));
+    const int kk[3] = {k / 9, (k / 3) % 3, k % 3};
+    float s = 0.f;
+    for (int b = 0; b < nslab; ++b) {
+      const float* base = dwt + (int64_t)b * slab;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {      // per dimension: original tap 0 in (p0,t0),(p1,t0); 1 in (p0,t1),(p1,t0); 2 in (p0,t1),(p1,t1)
+        int cls = 0, tap = 0;
+#pragma unroll
+        for (int dmn = 0; dmn < 3; ++dmn) {
+          const int par = (m >> (2 - dmn)) & 1;
+          const int tp = kk[dmn] == 0 ? 0 : (kk[dmn] == 2 ? 1 : (par == 0 ? 1 : 0));
+          cls = cls * 2 + par;
+          tap = tap * 2 + tp;
+        }
+        s += base[(((((int64_t)cls * 8 + tap) * ciT + (ci >> 5)) * coT + (co >> 5)) << 10) + (ci & 31) * 32 + (co & 31)];
+      }
+    }
+    dw[i] = coef * s;
+  }
+  if (db != nullptr && bsl != nullptr && i < cout) {
+    float s = 0.f;
+    for (int b = 0; b < nslab; ++b) s += bsl[(int64_t)b * bslab + i];
+    db[i] = s;
+  }
+}
+
+static int subpix_wgrad_blocks(const sg_conv_shape* s) {
+  const int pairs = sg_cdiv(s->cin, 32) * sg_cdiv(s->cout, 32);
+  int gx = 256 / pairs;
+  if (gx < 8) gx = 8;
+  return gx;
+}
+
+extern "C" int sg_upconv3d_subpixel_wgrad_supported(const sg_conv_shape* s, sg_dtype dt) {
+  return (s && dt == SG_BF16 && s->cin % 32 == 0 && s->cout % 32 == 0 && s->w % 32 == 0 && s->h % 2 == 0 && s->d >= 1 &&
+          (int64_t)s->n * s->d * s->h * s->w * 8 * s->cout < (1ll << 40)) ? 1 : 0;
+}
+
+extern "C" size_t sg_upconv3d_subpixel_wgrad_workspace(const sg_conv_shape* s, sg_dtype dt) {
+  if (!sg_upconv3d_subpixel_wgrad_supported(s, dt)) return 0;
+  const size_t tile = (size_t)64 * sg_cdiv(s->cin, 32) * sg_cdiv(s->cout, 32) * 4096;
+  const size_t bias = ((size_t)sg_cdiv(s->cout, 32) * 128 + 255) & ~(size_t)255;
+  const size_t ns = sg_cfg().deterministic ? (size_t)subpix_wgrad_blocks(s) : 1;
+  return ns * (tile + bias);
+}
+
+// s: the LOW-resolution shape; x [n,d,h,w,cin], gy [n,2d,2h,2w,cout]; dw [3][3][3][cin][cout] f32, dbias [cout] or NULL
+extern "C" int sg_upconv3d_subpixel_wgrad(const void* x, const void* gy, float* dw, float* dbias, float coef, void* workspace,
+                                          size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st) {
+  if (!s || !x || !gy || !dw || !workspace) return SG_EINVAL;
+  if (!sg_upconv3d_subpixel_wgrad_supported(s, dt)) return SG_EUNSUPPORTED;
+  if (!sg_aligned16(x) || !sg_aligned16(gy) || !sg_aligned16(workspace)) return SG_EALIGN;
+  if (workspace_bytes < sg_upconv3d_subpixel_wgrad_workspace(s, dt)) return SG_EWORKSPACE;
+  hipStream_t hs = sg_st(st);
+  SubpixWgradArgs a;
+  a.x = reinterpret_cast<const bf16_t*>(x); a.gy = reinterpret_cast<const bf16_t*>(gy);
+  a.N = s->n; a.d = s->d; a.h = s->h; a.w = s->w; a.cin = s->cin; a.cout = s->cout;
+  a.ciT = s->cin / 32; a.coT = s->cout / 32;
+  a.nTh = s->h / 2; a.nTw = s->w / 32;
+  a.ntiles = (int64_t)s->n * s->d * a.nTh * a.nTw;
+  const bool det = sg_cfg().deterministic != 0;
+  const int gx = subpix_wgrad_blocks(s);
+  const size_t tile = (size_t)64 * a.ciT * a.coT * 4096;
+  const size_t bias = ((size_t)a.coT * 128 + 255) & ~(size_t)255;
+  const size_t ns = det ? (size_t)gx : 1;
+  a.dwt = reinterpret_cast<float*>(workspace);
+  float* bias_ws = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + ns * tile);
+  a.dbias = dbias ? bias_ws : nullptr;
+  a.slab = det ? (int64_t)(tile / 4) : 0;
+  a.bslab = det ? (int64_t)(bias / 4) : 0;
+  if (!det) {
+    hipError_t e = hipMemsetAsync(workspace, 0, tile + bias, hs);
+    if (e != hipSuccess) return (int)e;
+  }
+  sg_conv_shape full = *s;
+  full.d *= 2; full.h *= 2; full.w *= 2; full.kd = full.kh = full.kw = 3; full.upsample_in = 1;
+  sg_prof_scope prof(1, &full, dt, hs);
+  auto kern = upconv_subpixel_wgrad_kernel;
+  SG_ALLOW_160K_LDS(kern);
+  SG_KNAME("upconv_subpixel_wgrad");
+  hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)(a.ciT * a.coT)), dim3(512), 2 * (size_t)(kWX + kWY), hs, a);
+  const int64_t total = (int64_t)27 * s->cin * s->cout;
+  hipLaunchKernelGGL(upconv_subpixel_wgrad_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, hs, a.dwt, dw,
+                     dbias ? bias_ws : nullptr, dbias, coef, s->cin, s->cout, a.ciT, a.coT, (int)ns, a.slab, a.bslab);
+  hipError_t e2 = hipGetLastError();
+  prof.done((int)e2);
+  return (int)e2;
+}

@@ -245,8 +245,19 @@ def raw_wgrad(x, dy, k, coef, ups=False, want_db=False):
         raise TypeError('wgrad: x and dy dtypes differ')
     n, cin, _, _, _ = _dims(x)
     n2, cout, d, h, w = _dims(dy)
-    shp = _shape(n, d, h, w, cin, cout, k, ups)
     dt = _dt(x)
+    if ups and tuple(k) == (3, 3, 3) and not _NO_SUBPIXEL and x.dim() == 5:
+        # conv3d(upscale3d(x)): 64 (class, tap) tiles on the low-resolution grid instead of 8 x 27 tap products per voxel
+        low = _shape(n, d // 2, h // 2, w // 2, cin, cout, (3, 3, 3), False)
+        if lib.sg_upconv3d_subpixel_wgrad_supported(C.byref(low), dt):
+            ws_bytes = lib.sg_upconv3d_subpixel_wgrad_workspace(C.byref(low), dt)
+            ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
+            dw = torch.empty((3, 3, 3, cin, cout), device=x.device, dtype=torch.float32)
+            db = torch.empty(cout, device=x.device, dtype=torch.float32) if want_db else None
+            check(lib.sg_upconv3d_subpixel_wgrad(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), float(coef), _ptr(ws), ws_bytes,
+                                                 C.byref(low), dt, _stream()), 'sg_upconv3d_subpixel_wgrad')
+            return dw, db
+    shp = _shape(n, d, h, w, cin, cout, k, ups)
     ws_bytes = lib.sg_conv3d_wgrad_workspace(C.byref(shp), dt)
     ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
     dw = torch.empty((k[0], k[1], k[2], cin, cout), device=x.device, dtype=torch.float32)

@@ -5,6 +5,7 @@ accumulation order plus one bf16 rounding of the output: rtol 1e-2 / atol 1e-2 x
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as TF
 
 from oracle import pgan_oracle as O
 
@@ -378,6 +379,41 @@ def test_upconv_subpixel_matches_oracle(case, monkeypatch):
         # the two forwards round their weights differently (per tap / per summed tap), so ~0.3 % of the LeakyReLU masks
         # differ between them, as between any two bf16 arithmetics: 3 % in relative L2 was seen
         assert err <= 5e-2, (name, err)
+
+
+@pytest.mark.parametrize('case', [(2, 64, 32, (4, 8, 32)), (1, 128, 64, (2, 6, 64)), (3, 32, 32, (1, 2, 32))],
+                         ids=['64to32', '128to64', '32to32_one_tile'])
+def test_upconv_subpixel_weight_gradient(case, monkeypatch):
+    """Weight and bias gradient of conv3d(upscale3d(x)) in sub-pixel form (csrc/subpix.hip: 64 (class, tap) tiles folded to
+    the 27 taps) against the fp64 oracle's gradient of the 27-tap formulation, and against the fused-gather kernel."""
+    import ctypes as C
+    from saragan_amd import _lib
+    from saragan_amd import functional as F
+    n, cin, cout, sp = case
+    dtype = torch.bfloat16
+    x = rnd((n, cin, *sp), 61, dtype)
+    gy = rnd((n, cout, *[2 * v for v in sp]), 62, dtype)
+    xr = x.clone()
+    wr = torch.zeros((3, 3, 3, cin, cout), dtype=torch.float64, requires_grad=True)
+    yr = TF.conv3d(O.upscale3d(xr), wr.permute(4, 3, 0, 1, 2), padding=1)
+    (gw,) = torch.autograd.grad(yr, wr, gy)
+    refw, refb = gw * 0.37, gy.sum(dim=(0, 2, 3, 4))
+    xg, gg = cl(x, dtype), cl(gy, dtype)
+    lib = _lib.load()
+    lib.sg_prof_enable(1)
+    dw, db = F.raw_wgrad(xg, gg, (3, 3, 3), 0.37, ups=True, want_db=True)
+    torch.cuda.synchronize()
+    ents = (_lib.ProfEntry * 8)()
+    cnt = C.c_int32(0)
+    lib.sg_prof_collect(ents, 8, C.byref(cnt))
+    lib.sg_prof_enable(0)
+    assert [ents[i].kernel.decode() for i in range(cnt.value)] == ['upconv_subpixel_wgrad']
+    np.testing.assert_allclose(dw.double().cpu().numpy(), refw.numpy(), rtol=2e-3, atol=2e-3 * float(refw.abs().max()))
+    np.testing.assert_allclose(db.double().cpu().numpy(), refb.numpy(), rtol=2e-3, atol=2e-3 * float(refb.abs().max()))
+    monkeypatch.setattr(F, '_NO_SUBPIXEL', True)
+    dw2, db2 = F.raw_wgrad(xg, gg, (3, 3, 3), 0.37, ups=True, want_db=True)
+    np.testing.assert_allclose(dw.cpu().numpy(), dw2.cpu().numpy(), rtol=1e-3, atol=1e-4 * float(dw2.abs().max()))
+    np.testing.assert_allclose(db.cpu().numpy(), db2.cpu().numpy(), rtol=1e-3, atol=1e-4 * float(db2.abs().max()))
 
 
 @pytest.mark.parametrize('dtype', DT)

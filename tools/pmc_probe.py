@@ -106,6 +106,73 @@ def main():
             twice(f'fwd pooled (D x W mean) {name}', 'conv_fwd3s', vox * (cin + cout / 4) * 2 + vox * nw * 4 + 27 * cin * cout * 2, flops,
                   lambda: _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), yp.data_ptr(), C.byref(shp), C.byref(ep_pool), dt, st)))
         del x, dy, y, bits, sout, ws, fws
+    # round 3: the sub-pixel up-convolution (one launch for all eight classes), low-resolution input -> fine output
+    for n, (d, h, w), cin, cout, pn in ((32, (16, 64, 64), 64, 32, 1), (32, (8, 32, 32), 128, 64, 1), (32, (4, 16, 16), 128, 128, 0)):
+        shp = ConvShape(n, d, h, w, cin, cout, 3, 3, 3, 0)
+        if not lib.sg_upconv3d_subpixel_supported(C.byref(shp), dt):
+            continue
+        vox = n * d * h * w
+        x = torch.randn(n, d, h, w, cin, device=dev).to(torch.bfloat16)
+        wt = torch.randn(3, 3, 3, cin, cout, device=dev)
+        wp = torch.empty(lib.sg_upconv3d_subpixel_packed_bytes(C.byref(shp), dt), device=dev, dtype=torch.uint8)
+        _lib.check(lib.sg_upconv3d_subpixel_pack(wt.data_ptr(), 0.05, wp.data_ptr(), C.byref(shp), dt, st))
+        y = torch.empty(n, 2 * d, 2 * h, 2 * w, cout, device=dev, dtype=torch.bfloat16)
+        nw = (cout + 31) // 32
+        sout = torch.empty(n, 2 * d, 2 * h, 2 * w, nw, device=dev, dtype=torch.int32)
+        scale = torch.empty(8 * vox, device=dev)
+        bias = torch.zeros(cout, device=dev)
+        ep = ConvEpilogue(bias.data_ptr(), 1, 0.2, pn, 1e-8, scale.data_ptr() if pn else None, None, 0.0, sout.data_ptr())
+        # algorithmic bytes: the low-resolution input once, the fine output, its sign words (+ scale), the summed weights
+        alg = vox * cin * 2 + 8 * vox * (cout * 2 + nw * 4 + (4 if pn else 0)) + 64 * cin * cout * 2
+        twice(f'upconv sub-pixel fwd bias+lrelu{"+pn" if pn else ""}+sign_out n{n} {2 * d}x{2 * h}x{2 * w} {cin}->{cout}', 'upconv_subpixel_fwd', alg,
+              2.0 * vox * 64 * cin * cout,
+              lambda: _lib.check(lib.sg_upconv3d_subpixel_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep), dt, st)))
+        del x, y, sout, scale
+    # round 3: GEMM-tiled convolution of the 1x4x4 / 2x8x8 levels (K split: the partial tiles are part of the traffic)
+    for n, (d, h, w), cin, cout in ((32, (2, 8, 8), 512, 512), (64, (2, 8, 8), 512, 512), (32, (1, 4, 4), 512, 512)):
+        shp = ConvShape(n, d, h, w, cin, cout, 1, 3, 3, 0)
+        vox = n * d * h * w
+        x = torch.randn(n, d, h, w, cin, device=dev).to(torch.bfloat16)
+        wt = torch.randn(1, 3, 3, cin, cout, device=dev)
+        wp = torch.empty(lib.sg_conv3d_packed_bytes(C.byref(shp), dt), device=dev, dtype=torch.uint8)
+        _lib.check(lib.sg_conv3d_pack_weights(wt.data_ptr(), 0.05, 0, wp.data_ptr(), C.byref(shp), dt, st))
+        y = torch.empty(n, d, h, w, cout, device=dev, dtype=torch.bfloat16)
+        sout = torch.empty(n, d, h, w, cout // 32, device=dev, dtype=torch.int32)
+        bias = torch.zeros(cout, device=dev)
+        ep = ConvEpilogue(bias.data_ptr(), 1, 0.2, 0, 1e-8, None, None, 0.0, sout.data_ptr())
+        fws_bytes = lib.sg_conv3d_fwd_workspace(C.byref(shp), dt)
+        fws = torch.empty(max(16, fws_bytes), device=dev, dtype=torch.uint8)
+        if fws_bytes:
+            ep.workspace, ep.workspace_bytes = fws.data_ptr(), fws_bytes
+        twice(f'gemm conv fwd bias+lrelu+sign_out n{n} {d}x{h}x{w} {cin}->{cout}', 'conv_gemm', vox * (cin + cout) * 2 + 9 * cin * cout * 2,
+              2.0 * vox * cin * cout * 9,
+              lambda: _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep), dt, st)), 2 if fws_bytes else 1)
+        del x, y, sout, fws
+    # round 3: small-channel 2-D kernels (BASELINE config 5's top level, fp32)
+    f32 = _lib.SG_F32
+    for n, hw, cin, cout in ((8, 1024, 4, 8), (8, 1024, 4, 4), (4, 1024, 8, 4), (8, 512, 8, 16)):
+        shp = ConvShape(n, 1, hw, hw, cin, cout, 1, 3, 3, 0)
+        vox = n * hw * hw
+        x = torch.randn(n, 1, hw, hw, cin, device=dev)
+        dy = torch.randn(n, 1, hw, hw, cout, device=dev)
+        wt = torch.randn(1, 3, 3, cin, cout, device=dev)
+        wp = torch.empty(lib.sg_conv3d_packed_bytes(C.byref(shp), f32), device=dev, dtype=torch.uint8)
+        _lib.check(lib.sg_conv3d_pack_weights(wt.data_ptr(), 0.05, 0, wp.data_ptr(), C.byref(shp), f32, st))
+        y = torch.empty(n, 1, hw, hw, cout, device=dev)
+        sout = torch.empty(n, 1, hw, hw, 1, device=dev, dtype=torch.int32)
+        bias = torch.zeros(cout, device=dev)
+        ep = ConvEpilogue(bias.data_ptr(), 1, 0.2, 0, 1e-8, None, None, 0.0, sout.data_ptr())
+        wsb = lib.sg_conv3d_wgrad_workspace(C.byref(shp), f32)
+        ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+        dw = torch.empty(1, 3, 3, cin, cout, device=dev)
+        db = torch.empty(cout, device=dev)
+        name = f'f32 n{n} {hw}x{hw} {cin}->{cout}'
+        twice(f'small fwd bias+lrelu+sign_out {name}', 'conv_small_fwd', vox * (cin + cout) * 4 + vox * 4, 2.0 * vox * cin * cout * 9,
+              lambda: _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep), f32, st)))
+        twice(f'small wgrad+dbias {name}', 'conv_small_wgrad_kernel', vox * (cin + cout) * 4, 2.0 * vox * cin * cout * 9,
+              lambda: _lib.check(lib.sg_conv3d_wgrad_bias(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), 1.0,
+                                                          ws.data_ptr(), wsb, C.byref(shp), f32, st)))
+        del x, dy, y, sout, ws
     # non-convolution kernels at the top level
     for (n, d, h, w, c) in ((64, 32, 128, 128, 64), (32, 32, 128, 128, 32)):
         vox = n * d * h * w

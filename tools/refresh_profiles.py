@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, 'gpurun_out', 'final')
 DST = os.path.join(ROOT, 'profiles')
-TAG = 'r02_'
+TAG = os.environ.get('PROFILE_TAG', 'r03_')
 
 
 def copy(src, dst, gz=False):

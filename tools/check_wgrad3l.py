@@ -37,8 +37,13 @@ def main():
         xsp = tuple(t // 2 for t in sp) if ups else sp
         x = torch.randn(n, cin, *xsp, device=dev).bfloat16().contiguous(memory_format=torch.channels_last_3d)
         dy = torch.randn(n, cout, *sp, device=dev).bfloat16().contiguous(memory_format=torch.channels_last_3d)
-        (gw, gb), kg = run(False, lambda: F.raw_wgrad(x, dy, (3, 3, 3), 0.05, bool(ups), True))
-        (rw, rb), kr = run(True, lambda: F.raw_wgrad(x, dy, (3, 3, 3), 0.05, bool(ups), True))
+        # the <ups> variant serves the shapes the sub-pixel weight gradient declines; test it on its own here
+        keep, F._NO_SUBPIXEL = F._NO_SUBPIXEL, True
+        try:
+            (gw, gb), kg = run(False, lambda: F.raw_wgrad(x, dy, (3, 3, 3), 0.05, bool(ups), True))
+            (rw, rb), kr = run(True, lambda: F.raw_wgrad(x, dy, (3, 3, 3), 0.05, bool(ups), True))
+        finally:
+            F._NO_SUBPIXEL = keep
         # torch fp32: dw[kd,kh,kw,ci,co] = sum_v x[v+tap,ci] dy[v,co]
         xt = x.float()
         if ups:

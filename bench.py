@@ -30,6 +30,7 @@ import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+HBM_PEAK = 8.0e12      # bytes/s, MI355X_MICROARCH.md
 sys.path.insert(0, ROOT)
 
 CONFIGS = {   # BASELINE.json configs[i-1]: SURVEY.md section 8d
@@ -276,10 +277,10 @@ def cpu_baseline(args, cfg, budget_s):
 
 def pmc_traffic(entry, dtype):
     """Bytes per launch that crossed the L2's memory side for this (kind, shape), from the committed rocprofv3 counter
-    passes (profiles/r02_pmc_traffic.json, else r01: FETCH_SIZE x2 + WRITE_SIZE; tools/pmc_probe.py +
+    passes (profiles/r03_pmc_traffic.json, else r02 / r01: FETCH_SIZE x2 + WRITE_SIZE; tools/pmc_probe.py +
     tools/pmc_summary.py; the counters cannot be read from inside this process).  Mean over the epilogue variants
     measured; None when this shape / batch / dtype was not part of the counter run."""
-    for name in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if not os.path.exists(path):
             continue
@@ -492,13 +493,19 @@ def main():
         avg_ms = best.total_ms / best.launches
         ach = best.flops_per_launch / (avg_ms * 1e-3) / 1e12
         s = best.shape
-        roof = dict(bound='mfma', achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4),
-                    traffic=pmc_traffic(best, args.dtype), kernel=best.kernel.decode(),
+        alg_bytes = int(s.n * s.d * s.h * s.w * (s.cin / (8 if s.upsample_in else 1) + s.cout) * (2 if args.dtype == 'bf16' else 4))
+        # which roof bounds this (kernel, shape): its arithmetic intensity against the machine balance (peak FLOP/s over
+        # 8 TB/s of HBM).  The small-channel 2-D layers of configs[4] sit below it and are priced in bytes.
+        if best.flops_per_launch / alg_bytes < peak * 1e12 / HBM_PEAK:
+            gbs = alg_bytes / (avg_ms * 1e-3) / 1e9
+            roof = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK / 1e9, unit='GB/s', frac=round(gbs * 1e9 / HBM_PEAK, 4))
+        else:
+            roof = dict(bound='mfma', achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4))
+        roof.update(traffic=pmc_traffic(best, args.dtype), kernel=best.kernel.decode(),
                     shape=dict(n=s.n, d=s.d, h=s.h, w=s.w, cin=s.cin, cout=s.cout, k=[s.kd, s.kh, s.kw],
                                upsample_in=s.upsample_in),
                     launches=int(best.launches), avg_ms=round(avg_ms, 4), flops_per_launch=best.flops_per_launch,
-                    algorithmic_bytes=int(s.n * s.d * s.h * s.w * (s.cin / (8 if s.upsample_in else 1) + s.cout) *
-                                          (2 if args.dtype == 'bf16' else 4)))
+                    algorithmic_bytes=alg_bytes)
     fg, fd = conv_flops_per_volume(cfg['ks'], cfg['fs'], args.phase, cfg['base_shape'], args.latent, args.dims)
     # executed conv work: G fwd+dgrad+wgrad; D: 3 forwards, 3 (wgan: the G loss reuses the D-loss data gradient)
     # or 4 data-gradient passes, 2 weight-gradient passes, 2 convs of the GP double backward + its weight gradient

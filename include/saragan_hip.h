@@ -109,6 +109,16 @@ typedef struct {
    * cin <= 32, w % 32 == 0), no bias / activation / pooling; otherwise SG_EUNSUPPORTED.  Both NULL: off. */
   const void* pn_bwd_y;
   const float* pn_bwd_scale;
+  /* Masked nearest up-scale of the INPUT in the gather (with s->upsample_in = 1): the convolution reads
+   * in_gain * where(bit, in_mask_slope, 1) * upscale3d(x) instead of upscale3d(x); in_mask_bits are the sign words of a
+   * tensor of the FINE shape [n,d,h,w,cin] (ceil(cin/32) words per voxel).  This is the gradient of
+   * downscale3d(leaky_relu(.)) (pgan/discriminator.py:39-44 backward: networks/ops.py:265-273 then :175-178, gain 1/8)
+   * formed while the halo is staged, so the full-resolution gradient -- 8 x the bytes of x -- is never written.  Values are
+   * rounded to the storage type exactly as sg_upscale2x_masked rounds them.  Implemented by the two-pass 64 -> 32 path
+   * (see workspace; bf16, 3x3x3, even d/h/w, w % 32 == 0): anything else returns SG_EUNSUPPORTED.  NULL: off. */
+  const void* in_mask_bits;
+  float in_mask_slope;
+  float in_gain;
 } sg_conv_epilogue;
 
 /* Sign words of an NDHWC tensor t[nvox][c]: uint32 words[nvox][ceil(c/32)], bit j of word (v, k) = (t[v][32k+j] < 0),
@@ -162,6 +172,16 @@ int sg_conv3d_wgrad(const void* x, const void* dy, float* dw_dhwio, float coef, 
  * from the pass that reads dy anyway. */
 int sg_conv3d_wgrad_bias(const void* x, const void* dy, float* dw_dhwio, float* dbias, float coef, void* workspace,
                          size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st);
+/* The same for one discriminator block's pooled tail, downscale3d(leaky_relu(conv3d(x) + b)) (pgan/discriminator.py:39-44):
+ * dy_half [n, d/2, h/2, w/2, cout] is the gradient of the POOLED output; the gradients are taken against
+ * dy_gain * where(bit, mask_slope, 1) * upscale3d(dy_half) -- networks/ops.py:265-273 backward (dy_gain = 1/8) followed by
+ * :175-178 with the layer's sign words mask_bits [n*d*h*w][cout/32] -- formed while each tile is staged, with the rounding
+ * of sg_upscale2x_masked, so the full-resolution gradient is never written.  s is the FINE shape.  bf16, 3x3x3,
+ * cout % 32 == 0, even d/h/w, w % 32 == 0 and the sliding-halo kernel's tile: otherwise SG_EUNSUPPORTED.  Same workspace
+ * as sg_conv3d_wgrad_bias. */
+int sg_conv3d_wgrad_bias_up_masked(const void* x, const void* dy_half, const void* mask_bits, float mask_slope, float dy_gain,
+                                   float* dw, float* dbias, float coef, void* workspace, size_t workspace_bytes,
+                                   const sg_conv_shape* s, sg_dtype dt, sg_stream_t st);
 
 /* Whole backward of a pointwise convolution FROM cin <= 4 channels (from_rgb, pgan/discriminator.py:9-12) in one pass over
  * dy: dw, dbias as sg_conv3d_wgrad_bias, and dx[n,d,h,w,cin] = sum_c dy[..,c] * w_mat[j][c] (w_mat: [cin][cout] f32, the

@@ -25,7 +25,8 @@ class ConvEpilogue(C.Structure):
                 ('sign_out', C.c_void_p), ('out_scale', C.c_int32), ('out_off', C.c_int32 * 3),
                 ('tap_off', C.c_int32 * 3), ('pool', C.c_int32), ('workspace', C.c_void_p),
                 ('workspace_bytes', C.c_size_t), ('x_plane_channels', C.c_int32), ('pn_bwd_y', C.c_void_p),
-                ('pn_bwd_scale', C.c_void_p)]
+                ('pn_bwd_scale', C.c_void_p), ('in_mask_bits', C.c_void_p), ('in_mask_slope', C.c_float),
+                ('in_gain', C.c_float)]
 
     def __init__(self, *args, **kw):
         super().__init__(C.sizeof(type(self)), *args, **kw)
@@ -58,6 +59,7 @@ SIGNATURES = {
     'sg_conv3d_wgrad': (C.c_int, [_p, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
     'sg_conv3d_pw_bwd': (C.c_int, [_p, _p, _p, _p, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
     'sg_conv3d_wgrad_bias': (C.c_int, [_p, _p, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
+    'sg_conv3d_wgrad_bias_up_masked': (C.c_int, [_p, _p, _p, _f, _f, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
     'sg_bias_act_fwd': (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _f, C.c_int, _p]),
     'sg_bias_act_bwd_workspace': (_sz, [_i32]),
     'sg_bias_act_bwd': (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _f, C.c_int, _p]),

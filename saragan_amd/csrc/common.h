@@ -196,6 +196,21 @@ __device__ __forceinline__ uint32_t sg_pack_bf16(float lo, float hi) {   // one 
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
 }
 
+// One staged 16-byte piece (8 bf16 channels) of a masked nearest up-scale: bf16(x * gain [* slope where the sign bit of
+// the fine voxel's channel is set]), bit e of m = channel e of the piece.  The arithmetic of sg_upscale2x_masked
+// (elementwise.hip), so that a gather fused into a consumer is bit-identical to the tensor that kernel would write.
+__device__ __forceinline__ u32x4 sg_mask_piece_bf16(u32x4 v, uint32_t m, float gain, float slope) {
+  u32x4 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float lo = __uint_as_float(v[e] << 16) * gain, hi = __uint_as_float(v[e] & 0xFFFF0000u) * gain;
+    lo = ((m >> (2 * e)) & 1u) ? lo * slope : lo;
+    hi = ((m >> (2 * e + 1)) & 1u) ? hi * slope : hi;
+    o[e] = sg_pack_bf16(lo, hi);
+  }
+  return o;
+}
+
 __device__ __forceinline__ void sg_store_tile_row_bf16(bf16_t* row32, const f32x16& v, int hh, bool ok) {
 #pragma unroll
   for (int j = 0; j < 2; ++j) {

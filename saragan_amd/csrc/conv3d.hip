@@ -123,6 +123,9 @@ struct ConvFwdArgs {
   const float* addend;       // sliding-halo kernel, second K-split pass: the first pass's f32 partial sums [voxel][cout]
   const void* pnb_y;         // sliding-halo kernel, pixel-norm backward epilogue: the stage's output y [voxel][cout] ...
   const float* pnb_scale;    // ... and its per-voxel rsqrt factor (sg_conv_epilogue.pn_bwd_y / pn_bwd_scale)
+  const uint32_t* in_mask;   // sliding-halo kernel with the fused nearest-x2 gather: sign words of the FINE input [voxel][in_mask_nw] ...
+  float in_mask_slope, in_gain;   // ... the staged halo is in_gain * where(bit, in_mask_slope, 1) * x (sg_conv_epilogue.in_mask_bits)
+  int in_mask_nw;
   int pool;                  // 1: y is the D x W mean-pooled output [n, D/2, H, W/2, cout] (sliding-halo kernel only)
   int os, oa, ob, oc;        // output scatter: os == 2 writes voxel (2d+oa, 2h+ob, 2w+oc) of a [n,2D,2H,2W,cout] tensor
   unsigned long long* dbg;  // diagnostic time stamps (NULL in production)
@@ -1122,9 +1125,11 @@ enum : int { SG_EP_SIGN = 1, SG_EP_MASK = 2, SG_EP_PN = 4, SG_EP_POOL = 8, SG_EP
 #define SG_V3S_RING 6   // fragment ring of the MFMA phase: reads run RING - 2 steps (of 1-2 MFMAs) ahead of their use
 #endif
 
-template <int GC, int KS, int EPI, bool UPS>   // KS: 0 whole layer; 1 / 2: first / second pass of a layer split over its input
-                                              // channels; UPS: x is the half-resolution tensor, gathered nearest-x2
+template <int GC, int KS, int EPI, bool UPS, bool INM = false>   // KS: 0 whole layer; 1 / 2: first / second pass of a layer split
+                                              // over its input channels; UPS: x is the half-resolution tensor, gathered
+                                              // nearest-x2; INM: ... times in_gain * where(sign bit of the fine voxel, slope, 1)
 __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
+  static_assert(!INM || (UPS && GC == 2), "the input mask rides on the fused gather");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   typedef bf16_t T;
   constexpr int TAPS = 27;
@@ -1192,6 +1197,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   // goes global -> registers -> LDS.
   constexpr int MAXP = (PPIECES + 3) / 4;
   uint32_t relb[MAXP];   // byte offset of my piece relative to the plane's first halo voxel (h0-1, w0-1); dead: huge
+  uint32_t relm[INM ? MAXP : 1];   // INM: byte offset of my piece's 8 sign bits relative to that voxel's first sign word
   int crdp[MAXP];        // packed (hw, hh) for the boundary test; dead pieces fail every range
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) {
@@ -1205,6 +1211,8 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
     const int rel = UPS ? ((((hh_ - 1) >> 1) * (W >> 1) + ((hw - 1) >> 1)) * a.xcs + a.xco + c) * ES : ((hh_ * W + hw) * a.xcs + a.xco + c) * ES;
     relb[k] = live ? (uint32_t)rel : 0xC0000000u;   // dead: stays >= DEAD after + tile offset
     crdp[k] = live ? (hw | (hh_ << 8)) : 0x7F7F;
+    if constexpr (INM)   // the byte of word (xco + c) / 32 that holds channels c .. c + 7 of FINE voxel (hh_, hw)
+      relm[k] = live ? (uint32_t)(((hh_ * W + hw) * a.in_mask_nw + ((a.xco + c) >> 5)) * 4 + (((a.xco + c) & 31) >> 3)) : 0xC0000000u;
   }
   // LDS position of my piece inside its 1-KiB block: slot p of row lands at p ^ f(row), and f(row) only depends on
   // the lane because a block is a whole number of 256-byte bank rows
@@ -1234,11 +1242,13 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   };
   // ---- halo side (cursor P): per-column resource and per-lane offsets
   Cur P{0, 0, 0, 0, 0};
-  __amdgpu_buffer_rsrc_t rxP;
-  uint32_t vk[MAXP];
+  __amdgpu_buffer_rsrc_t rxP, rmP;
+  uint32_t vk[MAXP], vkm[INM ? MAXP : 1];
+  const int64_t msb = svox * a.in_mask_nw * 4;     // (INM) sign words of one sample of the fine input
   auto enter_column_P = [&]() {
     enter_column(P);
     rxP = rsrc_of(a.x, xsb, P.n0);
+    if constexpr (INM) rmP = rsrc_of(a.in_mask, msb, P.n0);
     const int tile_off = UPS ? ((P.h0 >> 1) * (W >> 1) + (P.w0 >> 1)) * a.xcs * ES
                              : ((P.h0 - 1) * W + (P.w0 - 1)) * a.xcs * ES;   // may be negative: only dead lanes go below 0
     const int lo_w = max(0, 1 - P.w0), hi_w = min(34, W + 1 - P.w0) - 1;
@@ -1249,11 +1259,14 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
     for (int k = 0; k < MAXP; ++k) {
       const uint32_t c_ = (uint32_t)crdp[k];
       const uint32_t t1 = (c_ | 0x8080u) - lo, t2 = hi - c_;
-      vk[k] = ((t1 & t2 & 0x8080u) == 0x8080u && hi_h >= 0) ? relb[k] + (uint32_t)tile_off : DEAD;
+      const bool in = (t1 & t2 & 0x8080u) == 0x8080u && hi_h >= 0;
+      vk[k] = in ? relb[k] + (uint32_t)tile_off : DEAD;
+      if constexpr (INM) vkm[k] = in ? relm[k] + (uint32_t)(((P.h0 - 1) * W + (P.w0 - 1)) * a.in_mask_nw * 4) : DEAD;
     }
   };
   u32x4 stg[2][MAXP];
-  auto load_planes = [&](int d0, int hd0) {          // planes d0 - 1 + hd0 + {0, 1} of P's column
+  uint32_t mstg[INM ? 2 : 1][INM ? MAXP : 1];      // (INM) the 8 sign bits of each piece in flight
+  auto load_planes = [&](int d0, int hd0) __attribute__((always_inline)) {   // planes d0 - 1 + hd0 + {0, 1} of P's column
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int gp = d0 - 1 + hd0 + j;               // global D plane
@@ -1261,15 +1274,21 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
       const uint32_t soff = plane_ok ? (uint32_t)(UPS ? gp >> 1 : gp) * plane_bytes : 0u;
 #pragma unroll
       for (int k = 0; k < MAXP; ++k) stg[j][k] = __builtin_amdgcn_raw_buffer_load_b128(rxP, plane_ok ? vk[k] : DEAD, soff, 0);
+      if constexpr (INM) {
+        const uint32_t moff = plane_ok ? (uint32_t)gp * (uint32_t)(plane_vox * a.in_mask_nw * 4) : 0u;
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) mstg[j][k] = __builtin_amdgcn_raw_buffer_load_b8(rmP, plane_ok ? vkm[k] : DEAD, moff, 0);
+      }
     }
   };
+  const float gain_in = a.in_gain, slope_in = a.in_mask_slope;   // (INM) sg_mask_piece_bf16: the arithmetic of sg_upscale2x_masked
   // Ring slot of a halo plane: by its D index, shifted by two slots for the columns that START at an odd running tile
   // index (qP - P.di odd).  The tiles of a group then alternate strictly between the two ring rotations whatever the
   // number of tiles per column -- all four planes are rewritten at a column start anyway -- and the two rotations
   // of the unrolled MFMA code follow each other in straight-line code instead of behind a branch on the tile's parity
   // (at whose join the compiler shuffled all 32 accumulator registers, every phase).
   int qP = 0;                                        // index of P's tile in my list
-  auto store_planes = [&](int d0, int hd0) {
+  auto store_planes = [&](int d0, int hd0) __attribute__((always_inline)) {   // (left to itself the compiler calls the INM variant: the cursor then lives in scratch)
     const int rot2 = 2 * ((qP - P.di) & 1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -1277,7 +1296,10 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
       char* dst = xmine + ((gp + rot2 + 8) & 3) * PB + wofs;
 #pragma unroll
       for (int k = 0; k < MAXP; ++k)
-        if (wave + 4 * k < PPIECES) *reinterpret_cast<u32x4*>(dst + (wave + 4 * k) * 1024) = stg[j][k];
+        if (wave + 4 * k < PPIECES) {
+          if constexpr (INM) *reinterpret_cast<u32x4*>(dst + (wave + 4 * k) * 1024) = sg_mask_piece_bf16(stg[j][k], mstg[j][k], gain_in, slope_in);
+          else *reinterpret_cast<u32x4*>(dst + (wave + 4 * k) * 1024) = stg[j][k];
+        }
     }
   };
   // ---- output side (cursor E): per-column resources, validity and voxel origin
@@ -1605,9 +1627,9 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   }
 }
 
-template <int GC, int KS, int EPI, bool UPS = false>
+template <int GC, int KS, int EPI, bool UPS = false, bool INM = false>
 static int launch_fwd3s_inst(const ConvFwdArgs& a, unsigned gx, size_t lds, hipStream_t st) {
-  auto kern = conv_fwd3s_kernel<GC, KS, EPI, UPS>;
+  auto kern = conv_fwd3s_kernel<GC, KS, EPI, UPS, INM>;
   SG_ALLOW_160K_LDS(kern);
   hipLaunchKernelGGL(kern, dim3(gx, (unsigned)a.ntile), dim3(512), lds, st, a);
   return SG_OK;
@@ -1620,6 +1642,7 @@ static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
   if (s->kd != 3 || s->kh != 3 || s->kw != 3) return SG_OK;
   // the fused nearest-x2 gather exists for the two passes of a split layer only (G's 64 -> 32 after upscale3d)
   if (s->upsample_in && (KS == 0 || GC != 2 || ((s->d | s->h | s->w) & 1))) return SG_OK;
+  if (a.in_mask && !s->upsample_in) return SG_OK;
   if (s->d < 4 || (s->w % 32) != 0 || (s->cout % 32) != 0) return SG_OK;   // >= 2 steps per column; full 32-wide rows and tiles
   if (a.pool && ((s->d & 1) || (s->h & 1) || a.pixel_norm || a.mask_bits || KS != 0)) return SG_OK;
   if (a.pixel_norm && (a.mask_bits || KS == 1 || a.ntile != 1)) return SG_OK;
@@ -1647,10 +1670,22 @@ static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
                   (a.pool ? SG_EP_POOL : 0) | (a.pnb_y ? SG_EP_PNB : 0);
   int rc = SG_OK;
   if constexpr (KS == 1) {
-    if constexpr (GC == 2) { if (s->upsample_in) rc = launch_fwd3s_inst<GC, 1, 0, true>(a, (unsigned)gx, lds, st); else rc = launch_fwd3s_inst<GC, 1, 0>(a, (unsigned)gx, lds, st); }
+    if constexpr (GC == 2) {
+      if (s->upsample_in && a.in_mask) rc = launch_fwd3s_inst<GC, 1, 0, true, true>(a, (unsigned)gx, lds, st);
+      else if (s->upsample_in) rc = launch_fwd3s_inst<GC, 1, 0, true>(a, (unsigned)gx, lds, st);
+      else rc = launch_fwd3s_inst<GC, 1, 0>(a, (unsigned)gx, lds, st);
+    }
     else rc = launch_fwd3s_inst<GC, 1, 0>(a, (unsigned)gx, lds, st);
   } else if constexpr (KS == 2) {
-    if (s->upsample_in) {
+    if (s->upsample_in && a.in_mask) {
+      if constexpr (GC == 2) {
+        switch (epi) {
+          case 0: rc = launch_fwd3s_inst<GC, 2, 0, true, true>(a, (unsigned)gx, lds, st); break;
+          case SG_EP_MASK: rc = launch_fwd3s_inst<GC, 2, SG_EP_MASK, true, true>(a, (unsigned)gx, lds, st); break;
+          default: return SG_OK;
+        }
+      } else return SG_OK;
+    } else if (s->upsample_in) {
       if constexpr (GC == 2) {
         switch (epi) {
           case 0: rc = launch_fwd3s_inst<GC, 2, 0, true>(a, (unsigned)gx, lds, st); break;
@@ -2816,6 +2851,13 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
   a.pnb_scale = ep ? ep->pn_bwd_scale : nullptr;
   if ((a.pnb_y != nullptr) != (a.pnb_scale != nullptr) || (a.pnb_y && !sg_aligned16(a.pnb_y))) return SG_EINVAL;
   a.xcs = s->cin; a.xco = 0; a.addend = nullptr;
+  a.in_mask = ep ? reinterpret_cast<const uint32_t*>(ep->in_mask_bits) : nullptr;
+  a.in_mask_slope = ep ? ep->in_mask_slope : 0.f;
+  a.in_gain = ep ? ep->in_gain : 1.f;
+  a.in_mask_nw = (s->cin + 31) >> 5;
+  if (a.in_mask && (dt != SG_BF16 || !s->upsample_in || s->kd != 3 || s->kh != 3 || s->kw != 3 || s->cin != 64 || s->cout != 32 ||
+                    !sg_aligned16(a.in_mask)))
+    return a.in_mask && !sg_aligned16(a.in_mask) ? SG_EALIGN : SG_EUNSUPPORTED;     // only the two-pass 64 -> 32 path masks its gather
   a.os = (ep && ep->out_scale == 2) ? 2 : 1;
   a.oa = ep ? ep->out_off[0] : 0; a.ob = ep ? ep->out_off[1] : 0; a.oc = ep ? ep->out_off[2] : 0;
   const bool subpixel = a.os == 2 || a.tap_d || a.tap_h || a.tap_w || s->kd == 2;
@@ -2890,7 +2932,8 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     const bool k333 = s->kd == 3 && s->kh == 3 && s->kw == 3, k133 = s->kd == 1 && s->kh == 3 && s->kw == 3;
     if (dt == SG_BF16 && k333 && !sg_cfg().fwd_no_v3s && !sg_cfg().fwd_no_ksplit && a.nchunk == 4 && a.ntile == 1 && s->cin == 64 &&
         !a.pool && !a.pnb_y && !(a.mask_bits && a.sign_out) && !(a.pixel_norm && a.mask_bits) &&
-        !(s->upsample_in && a.mask_bits) &&      // (no fused-gather variant carries a mask: the second pass would decline)
+        !(s->upsample_in && a.mask_bits && !a.in_mask) &&      // (the plain fused-gather variants carry no output mask)
+        !(a.in_mask && (!s->upsample_in || a.sign_out || a.pixel_norm || xpl)) &&
         ep && ep->workspace &&
         ep->workspace_bytes >= (size_t)s->n * s->d * s->h * s->w * (size_t)s->cout * 4 && sg_aligned16(ep->workspace)) {
       // K split: 64 input channels as two sliding-halo passes over 32 channels each (resident weights, a 64-byte
@@ -2921,7 +2964,7 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
       }
       if (rc != SG_OK) { prof.done(rc); return rc; }
     }
-    if (xpl) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }
+    if (xpl || a.in_mask) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }
     if (dt == SG_BF16 && k333 && !sg_cfg().fwd_no_v3s) {   // sliding-halo variant where its tile fits
       if (a.nchunk == 2) rc = launch_fwd3s<2>(a, s, hs, &used);
       else if (a.nchunk == 1) rc = launch_fwd3s<1>(a, s, hs, &used);
@@ -2941,6 +2984,7 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     }
     if (rc != SG_OK || used) { prof.done(rc); return rc; }
   }
+  if (a.in_mask) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }
   if (v2 && dt == SG_BF16 && !sg_cfg().fwd_no_v5) {   // the streamed kernel's hot class, lean off-phase
     bool used = false;
     rc = launch_fwd5(a, s, hs, &used);

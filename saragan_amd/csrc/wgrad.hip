@@ -34,6 +34,10 @@ struct WgradArgs {
   int nslab;       // slabs written = gridDim.x of the launch (set by the launcher)
   int dbg_flags;   // diagnostic ablations (0 in production): 1 = stage only the first items
   unsigned long long* dbg;   // in-kernel phase stamps (sg_debug_set_ts_buffer), nullptr in production
+  // lean sliding-halo kernel, DYM: dy is the HALF-resolution tensor [n, D/2, H/2, W/2, cout]; the staged tile is
+  // dy_gain * where(sign bit of the fine voxel, dy_mask_slope, 1) * nearest-x2(dy) (sg_conv3d_wgrad_bias_up_masked)
+  const uint32_t* dy_mask;   // sign words of the fine tensor [voxel][coT]
+  float dy_mask_slope, dy_gain;
 };
 extern unsigned long long* g_dbg_ts;
 
@@ -1050,8 +1054,11 @@ struct sg_wgrad_tile_lean {
   }
 };
 
-template <bool UPS>   // UPS: x is the half-resolution tensor, gathered nearest-x2 (upscale3d fused into the layer)
+template <bool UPS, bool DYM = false>   // UPS: x is the half-resolution tensor, gathered nearest-x2 (upscale3d fused into the
+                                        // layer); DYM: dy is the half-resolution gradient of a pooled layer, gathered
+                                        // nearest-x2, scaled and LeakyReLU-masked while it is staged
 __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
+  static_assert(!(UPS && DYM), "one gathered operand at a time");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TAPS = 27, MAXT = 7;
   constexpr int HH = 6, HW = 34, PB = 208 * 64, XB = 4 * PB, YB = 256 * 64, BUF = XB + YB;
@@ -1085,7 +1092,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
 
   // plane-local staging tables: this lane's 16-byte pieces of 1-KiB blocks wave, wave+4, ... of a halo plane / the dy tile
   constexpr int MAXP = 4, MAXY = 4;
-  uint32_t relx[MAXP], rely[MAXY];
+  uint32_t relx[MAXP], rely[MAXY], relm[DYM ? MAXY : 1];
   int crdx[MAXP], crdy[MAXY];
 #pragma unroll
   for (int k = 0; k < MAXP; ++k) {
@@ -1104,17 +1111,23 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
     const int it = (wave + 4 * k) * 64 + lane;
     const int row = it >> 2, c = co_t * 32 + (it & 3) * 8;   // row = (td * 4 + th) * 32 + tw
     const int tw = row & 31, th = (row >> 5) & 3, td = row >> 7;
-    rely[k] = c < cout ? (uint32_t)((((td * H + th) * W + tw) * cout + c) * 2) : 0xC0000000u;
+    if constexpr (DYM) {   // (tile origins are even: the halved coordinates are per-lane constants relative to the halved origin)
+      rely[k] = c < cout ? (uint32_t)(((((th >> 1) * (W >> 1)) + (tw >> 1)) * cout + c) * 2) : 0xC0000000u;
+      relm[k] = c < cout ? (uint32_t)((((td * H + th) * W + tw) * a.coT + co_t) * 4 + (it & 3)) : 0xC0000000u;
+    } else {
+      rely[k] = c < cout ? (uint32_t)((((td * H + th) * W + tw) * cout + c) * 2) : 0xC0000000u;
+    }
     crdy[k] = th;
   }
   const int64_t svox = (int64_t)D * H * W;
-  const int64_t xsb = (UPS ? svox >> 3 : svox) * cin * 2, ysb = svox * cout * 2;
-  const uint32_t xplane = (uint32_t)((UPS ? (H >> 1) * (W >> 1) : H * W) * cin * 2), yplane = (uint32_t)(H * W * cout * 2);
+  const int64_t xsb = (UPS ? svox >> 3 : svox) * cin * 2, ysb = (DYM ? svox >> 3 : svox) * cout * 2, msb = svox * a.coT * 4;
+  const uint32_t xplane = (uint32_t)((UPS ? (H >> 1) * (W >> 1) : H * W) * cin * 2),
+                 yplane = (uint32_t)((DYM ? (H >> 1) * (W >> 1) : H * W) * cout * 2), mplane = (uint32_t)(H * W * a.coT * 4);
 
   // cursor over my tiles: column cj of my list, step di along D; per column: resources and lane offsets
   int cj = 0, di = 0;
-  __amdgpu_buffer_rsrc_t rx, ry;
-  uint32_t vkx[MAXP], vky[MAXY];
+  __amdgpu_buffer_rsrc_t rx, ry, rm;
+  uint32_t vkx[MAXP], vky[MAXY], vkm[DYM ? MAXY : 1];
   auto enter_column = [&]() {
     const int col = cfirst + (2 * cj + grp) * per_x;
     const int c1 = (int)sg_div((uint32_t)col, g.fnTw);
@@ -1124,6 +1137,8 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
     const int n0 = c2;
     rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.x)) + n0 * xsb, 0, (int)xsb, 0x00020000);
     ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.dy)) + n0 * ysb, 0, (int)ysb, 0x00020000);
+    if constexpr (DYM)
+      rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.dy_mask)) + n0 * msb, 0, (int)msb, 0x00020000);
     const int tile_off = UPS ? ((h0 >> 1) * (W >> 1) + (w0 >> 1)) * cin * 2
                              : ((h0 - 1) * W + (w0 - 1)) * cin * 2;   // may be negative: only dead lanes go below 0
     const int lo_w = max(0, 1 - w0), hi_w = min(HW, W + 1 - w0) - 1;
@@ -1136,14 +1151,32 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
       const uint32_t t1 = (c_ | 0x8080u) - lo, t2 = hi - c_;
       vkx[k] = (t1 & t2 & 0x8080u) == 0x8080u ? relx[k] + (uint32_t)tile_off : DEAD;
     }
-    const int col_off = (h0 * W + w0) * cout * 2;
+    const int col_off = DYM ? ((h0 >> 1) * (W >> 1) + (w0 >> 1)) * cout * 2 : (h0 * W + w0) * cout * 2;
     const int rows_left = H - h0;                                // W is a multiple of 32 (host-checked): every tw is inside
 #pragma unroll
-    for (int k = 0; k < MAXY; ++k) vky[k] = (crdy[k] < rows_left && rely[k] < DEAD) ? rely[k] + (uint32_t)col_off : DEAD;
+    for (int k = 0; k < MAXY; ++k) {
+      const bool in = crdy[k] < rows_left && rely[k] < DEAD;
+      vky[k] = in ? rely[k] + (uint32_t)col_off : DEAD;
+      if constexpr (DYM) vkm[k] = in ? relm[k] + (uint32_t)((h0 * W + w0) * a.coT * 4) : DEAD;
+    }
   };
+  const float gain_y = a.dy_gain, slope_y = a.dy_mask_slope;     // (DYM) sg_mask_piece_bf16: the arithmetic of sg_upscale2x_masked
   // staging of the cursor's tile: the new halo planes (all four at the bottom of a column) and the dy tile
-  auto stage = [&]() {
+  auto stage = [&]() __attribute__((always_inline)) {
     const int d0 = 2 * di;
+    // (DYM) the dy tile goes through registers and is requested first: its latency runs beside the halo DMA issue.  Both D
+    // planes of the tile (d0 is even) read half-resolution plane d0 / 2.
+    u32x4 sy[DYM ? MAXY : 1];
+    uint32_t my[DYM ? MAXY : 1];
+    if constexpr (DYM) {
+      const uint32_t ysoff = (uint32_t)(d0 >> 1) * yplane, msoff = (uint32_t)d0 * mplane;
+#pragma unroll
+      for (int k = 0; k < MAXY; ++k) {
+        const bool ok = d0 + (k >> 1) < D;
+        sy[k] = __builtin_amdgcn_raw_buffer_load_b128(ry, ok ? vky[k] : DEAD, ysoff, 0);
+        my[k] = __builtin_amdgcn_raw_buffer_load_b8(rm, ok ? vkm[k] : DEAD, msoff, 0);
+      }
+    }
 #pragma unroll
     for (int hd = 0; hd < 4; ++hd) {
       if (hd < 2 && di != 0) continue;                           // uniform
@@ -1156,11 +1189,17 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
         if (wave + 4 * k < XPIECES)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(dst + (wave + 4 * k) * 1024), 16, plane_ok ? vkx[k] : DEAD, soff, 0, 0);
     }
-    const uint32_t ysoff = (uint32_t)d0 * yplane;
+    if constexpr (DYM) {
 #pragma unroll
-    for (int k = 0; k < MAXY; ++k) {
-      const bool ok = d0 + (k >> 1) < D;                          // pieces 8..15 are the tile's second D plane
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_ptr_t)(smem + ymine + (wave + 4 * k) * 1024), 16, ok ? vky[k] : DEAD, ysoff, 0, 0);
+      for (int k = 0; k < MAXY; ++k)
+        *reinterpret_cast<u32x4*>(smem + ymine + (wave + 4 * k) * 1024 + lane * 16) = sg_mask_piece_bf16(sy[k], my[k], gain_y, slope_y);
+    } else {
+      const uint32_t ysoff = (uint32_t)d0 * yplane;
+#pragma unroll
+      for (int k = 0; k < MAXY; ++k) {
+        const bool ok = d0 + (k >> 1) < D;                          // pieces 8..15 are the tile's second D plane
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_ptr_t)(smem + ymine + (wave + 4 * k) * 1024), 16, ok ? vky[k] : DEAD, ysoff, 0, 0);
+      }
     }
   };
   auto advance = [&]() {
@@ -1290,7 +1329,13 @@ static int launch_wgrad3(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   // the lean variant: 3x3x3 without fused up-sampling, whole 32-wide rows, one sample of either tensor below 2 GiB
   const bool lean = KD == 3 && KH == 3 && KW == 3 && g.HH == 6 && g.HW == 34 && g.HD == 4 && a.plane_rows == 208 &&
                     s->w % 32 == 0 && !sg_cfg().wgrad_no_lean && (!g.ups || ((s->d | s->h | s->w) & 1) == 0);
-  if (lean && g.ups) {
+  if (a.dy_mask) {     // half-resolution dy, gathered and masked while staged: the lean kernel only
+    if (!lean || g.ups || ((s->d | s->h | s->w) & 1)) return SG_OK;
+    auto kern = conv_wgrad3l_kernel<false, true>;
+    SG_ALLOW_160K_LDS(kern);
+    SG_KNAME("conv_wgrad3l<dy gather>");
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);
+  } else if (lean && g.ups) {
     auto kern = conv_wgrad3l_kernel<true>;
     SG_ALLOW_160K_LDS(kern);
     SG_KNAME("conv_wgrad3l<ups>");
@@ -1325,9 +1370,12 @@ extern "C" int sg_conv3d_wgrad(const void* x, const void* dy, float* dw, float c
 // pw_dx / pw_wmat: sg_conv3d_pw_bwd's extra output and operand (pointwise layers from <= 4 input channels only)
 static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbias, float coef, void* workspace,
                            size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st, void* pw_dx,
-                           const float* pw_wmat) {
+                           const float* pw_wmat, const void* dy_mask = nullptr, float dy_mask_slope = 0.f, float dy_gain = 1.f) {
   if (!conv_shape_ok_w(s) || !x || !dy || !dw || !workspace) return SG_EINVAL;
   if (!sg_aligned16(x) || !sg_aligned16(dy) || !sg_aligned16(workspace)) return SG_EALIGN;
+  if (dy_mask && (dt != SG_BF16 || s->kd != 3 || s->kh != 3 || s->kw != 3 || s->upsample_in || (s->cout % 32) ||
+                  sg_cfg().wgrad_v1 || sg_cfg().wgrad_no_v3))
+    return SG_EUNSUPPORTED;
   const size_t need = sg_conv3d_wgrad_workspace(s, dt);
   if (workspace_bytes < need) return SG_EWORKSPACE;
   hipStream_t hs = sg_st(st);
@@ -1391,6 +1439,7 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
   a.dbg_flags = sg_cfg().dbg_flags;
   a.dbg = g_dbg_ts;
   a.x = x; a.dy = dy; a.dwt = reinterpret_cast<float*>(workspace);
+  a.dy_mask = reinterpret_cast<const uint32_t*>(dy_mask); a.dy_mask_slope = dy_mask_slope; a.dy_gain = dy_gain;
   a.cin = s->cin; a.cout = s->cout;
   a.taps = s->kd * s->kh * s->kw; a.kh = s->kh; a.kw = s->kw;
   a.ciT = sg_cdiv(s->cin, 32); a.coT = sg_cdiv(s->cout, 32);
@@ -1400,6 +1449,7 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
     if (s->kd == 3 && s->kh == 3 && s->kw == 3) rc = launch_wgrad3<3, 3, 3>(a, s, hs, &used);
     db_done = used;   // the sliding-halo kernel accumulates the bias gradient in its spare tap slot
   }
+  if (dy_mask && rc == SG_OK && !used) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }   // only that kernel gathers dy
   if (rc == SG_OK && !used && dt == SG_BF16 && !sg_cfg().wgrad_v1) {
     if (s->kd == 3 && s->kh == 3 && s->kw == 3) rc = launch_wgrad2<3, 3, 3>(a, s, hs, &used);
     else if (s->kd == 1 && s->kh == 3 && s->kw == 3) rc = launch_wgrad2<1, 3, 3>(a, s, hs, &used);
@@ -1431,6 +1481,16 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
 extern "C" int sg_conv3d_wgrad_bias(const void* x, const void* dy, float* dw, float* dbias, float coef, void* workspace,
                                     size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st) {
   return wgrad_bias_impl(x, dy, dw, dbias, coef, workspace, workspace_bytes, s, dt, st, nullptr, nullptr);
+}
+
+// dy_half: [n, d/2, h/2, w/2, cout], the gradient of the POOLED output of downscale3d(leaky_relu(conv3d(x) + b)); the weight
+// and bias gradients are taken against dy_gain * where(bit, slope, 1) * nearest-x2(dy_half), formed while the tile is staged
+extern "C" int sg_conv3d_wgrad_bias_up_masked(const void* x, const void* dy_half, const void* mask_bits, float mask_slope, float dy_gain,
+                                              float* dw, float* dbias, float coef, void* workspace, size_t workspace_bytes,
+                                              const sg_conv_shape* s, sg_dtype dt, sg_stream_t st) {
+  if (!mask_bits) return SG_EINVAL;
+  if (!sg_aligned16(mask_bits)) return SG_EALIGN;
+  return wgrad_bias_impl(x, dy_half, dw, dbias, coef, workspace, workspace_bytes, s, dt, st, nullptr, nullptr, mask_bits, mask_slope, dy_gain);
 }
 
 extern "C" int sg_conv3d_pw_bwd(const void* x, const void* dy, const float* w_mat, float* dw, float* dbias, void* dx,

@@ -710,9 +710,14 @@ class _ConvBiasActPool(torch.autograd.Function):
         x, w, signs = ctx.saved_tensors
         coef, slope = ctx.cfg
         want_db = ctx.has_b and _wants(ctx, 2, ctx.b_ptr)
-        if not torch.is_grad_enabled() and not _NO_PLANES:
-            res = _pooled_backward_planes(gy, x, w, signs, coef, slope, ctx.in_info, ctx.needs_input_grad[0],
-                                          _wants(ctx, 1, w.data_ptr()), want_db)
+        if not torch.is_grad_enabled():
+            res = None
+            if not _NO_GATHER_BWD:
+                res = _pooled_backward_gather(gy, x, w, signs, coef, slope, ctx.in_info, ctx.needs_input_grad[0],
+                                              _wants(ctx, 1, w.data_ptr()), want_db)
+            if res is None and not _NO_PLANES:
+                res = _pooled_backward_planes(gy, x, w, signs, coef, slope, ctx.in_info, ctx.needs_input_grad[0],
+                                              _wants(ctx, 1, w.data_ptr()), want_db)
             if res is not None:
                 return res[0], res[1], (res[2] if want_db else None), None, None, None
         g = _Up.apply(gy, 0.125, signs, slope, (2, 2, 2))      # d(downscale3d) * LeakyReLU mask, full resolution
@@ -731,6 +736,58 @@ class _ConvBiasActPool(torch.autograd.Function):
 
 
 _NO_PLANES = bool(int(os.environ.get('SARAGAN_NO_PLANES', '0')))   # diagnostic: the 64-channel gradient as one tensor
+_NO_GATHER_BWD = bool(int(os.environ.get('SARAGAN_NO_GATHER_BWD', '0')))   # diagnostic: materialise the up-scaled gradient
+
+
+def _pooled_backward_gather(gy, x, w, signs, coef, slope, in_info, want_gx, want_gw, want_db):
+    """Backward of _ConvBiasActPool for the 32 -> 64 layer when nothing differentiates it again, WITHOUT the up-scaled
+    gradient: M * upscale3d(gy) / 8 (64 channels at full resolution, 4.3 GB at batch 64 -- written once and read twice
+    by _pooled_backward_planes) is formed from the pooled gradient and the layer's sign words while the consumers stage their
+    tiles: the two-pass 64 -> 32 data gradient (sg_conv_epilogue.in_mask_bits with upsample_in) and the weight / bias
+    gradient (sg_conv3d_wgrad_bias_up_masked).  Bit-identical to the materialised path.  Returns (gx, gw, gb) or None
+    when the layer is not of that shape / the library declines."""
+    if gy.dtype != torch.bfloat16 or w.dim() != 5 or tuple(w.shape) != (3, 3, 3, 32, 64) or signs is None:
+        return None
+    lib = _lib.load()
+    gy, x = ndhwc(gy), ndhwc(x)
+    n, cout, dc, hc, wc = _dims(gy)
+    d, h, wd = 2 * dc, 2 * hc, 2 * wc
+    dt, st = _dt(gy), _stream()
+    k = (3, 3, 3)
+    _check_signs(signs, n * d * h * wd, 64)
+    gx = gw = gb = None
+    if want_gx:
+        shp = _shape(n, d, h, wd, 64, 32, k, True)
+        ws_bytes = lib.sg_conv3d_fwd_workspace(C.byref(shp), dt)
+        if not ws_bytes:
+            return None
+        wp = _packed(w, coef, True, shp, dt, lib, st)
+        gx = _empty_like_shape(gy, 32, (d, h, wd))
+        masked = _masked_in(in_info)
+        ep = ConvEpilogue(None, 0, 0.0, 0, 1e-8, None, _ptr(in_info.bits) if masked else None,
+                          float(in_info.slope) if masked else 0.0, None)
+        if masked:
+            _check_signs(in_info.bits, n * d * h * wd, 32)
+        ws = torch.empty(ws_bytes, device=gy.device, dtype=torch.uint8)
+        ep.workspace, ep.workspace_bytes = ws.data_ptr(), ws_bytes
+        ep.in_mask_bits, ep.in_mask_slope, ep.in_gain = signs.data_ptr(), float(slope), 0.125
+        rc = lib.sg_conv3d_fwd(_ptr(gy), _ptr(wp), _ptr(gx), C.byref(shp), C.byref(ep), dt, st)
+        if rc == _lib.SG_EUNSUPPORTED:
+            return None
+        check(rc, 'sg_conv3d_fwd (masked gather)')
+    if want_gw or want_db:
+        shp = _shape(n, d, h, wd, 32, 64, k, False)
+        ws_bytes = lib.sg_conv3d_wgrad_workspace(C.byref(shp), dt)
+        ws = torch.empty(ws_bytes, device=gy.device, dtype=torch.uint8)
+        dw = torch.empty((3, 3, 3, 32, 64), device=gy.device, dtype=torch.float32)
+        gb = torch.empty(64, device=gy.device, dtype=torch.float32) if want_db else None
+        rc = lib.sg_conv3d_wgrad_bias_up_masked(_ptr(x), _ptr(gy), _ptr(signs), float(slope), 0.125, _ptr(dw), _ptr(gb), float(coef),
+                                                _ptr(ws), ws_bytes, C.byref(shp), dt, st)
+        if rc == _lib.SG_EUNSUPPORTED:
+            return None
+        check(rc, 'sg_conv3d_wgrad_bias_up_masked')
+        gw = dw.reshape(w.shape) if want_gw else None
+    return gx, gw, gb
 
 
 def _pooled_backward_planes(gy, x, w, signs, coef, slope, in_info, want_gx, want_gw, want_db):

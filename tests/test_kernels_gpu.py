@@ -576,7 +576,27 @@ def test_conv_epilogue_fused_downscale(monkeypatch):
     _mostly_close(g2g, g2r, 2e-2, 2e-2, 'second-order dw', max_bad=5e-3)
     # requests no kernel fuses (f32 storage) are refused, not mis-computed
     assert F.raw_conv(xg.float(), wg, coef, False, bias=bg, act=True, want_signs=True, pool=True) is None
-    # a backward nothing differentiates again writes the up-scaled 64-channel gradient as two 32-channel tensors
+    # a backward nothing differentiates again never writes the up-scaled 64-channel gradient: the data gradient's two passes
+    # and the weight gradient gather it from the pooled gradient and the sign words while they stage their tiles
+    # (sg_conv_epilogue.in_mask_bits, sg_conv3d_wgrad_bias_up_masked): same gradients, bit for bit the same data gradient
+    took_g = []
+    real_g = F._pooled_backward_gather
+
+    def spy_g(*a, **kw):
+        r = real_g(*a, **kw)
+        took_g.append(r is not None)
+        return r
+    monkeypatch.setattr(F, '_pooled_backward_gather', spy_g)
+    yq = F.conv3d_act_pool(xg, wg, coef, bg, 0.2)
+    gxq, gwq, gbq = torch.autograd.grad(yq, [xg, wg, bg], cl(gy, dtype))
+    assert took_g == [True], 'the fused gather was not used'
+    assert torch.equal(gxq, gxg.detach()), 'data gradient differs between the fused gather and the materialised gradient'
+    _mostly_close(gwq, gwr, 2e-3, 4e-3, 'dw (gather)')
+    _mostly_close(gbq, gbr, 2e-3, 4e-3, 'db (gather)')
+    _mostly_close(gwq, gwg.detach(), 1e-3, 1e-3, 'dw (gather vs materialised)')
+    _mostly_close(gbq, gbg.detach(), 1e-3, 1e-3, 'db (gather vs materialised)')
+    monkeypatch.setattr(F, '_NO_GATHER_BWD', True)
+    # without it: the up-scaled 64-channel gradient as two 32-channel tensors
     # (sg_upscale_nn_planes, sg_conv_epilogue.x_plane_channels): same gradients, bit for bit the same data gradient
     took = []
     real = F._pooled_backward_planes
@@ -607,6 +627,12 @@ def test_conv_epilogue_fused_downscale(monkeypatch):
     assert torch.equal(res[0], gx_ref), 'masked data gradient differs between the layouts'
     _mostly_close(res[1], gw_ref.reshape(res[1].shape), 1e-3, 1e-3, 'dw (planes vs one launch)')
     _mostly_close(res[2], gb_ref, 1e-3, 1e-3, 'db (planes vs one launch)')
+    with torch.no_grad():
+        resg = real_g(gyd, xg.detach(), wg.detach(), signs, coef, 0.2, info, True, True, True)
+    assert resg is not None
+    assert torch.equal(resg[0], gx_ref), 'masked data gradient differs between the fused gather and the materialised gradient'
+    _mostly_close(resg[1], gw_ref.reshape(resg[1].shape), 1e-3, 1e-3, 'dw (gather vs one launch)')
+    _mostly_close(resg[2], gb_ref, 1e-3, 1e-3, 'db (gather vs one launch)')
 
 
 @pytest.mark.parametrize('dtype', DT)

@@ -163,6 +163,17 @@ int sg_upconv3d_subpixel_wgrad_supported(const sg_conv_shape* s, sg_dtype dt);
 size_t sg_upconv3d_subpixel_wgrad_workspace(const sg_conv_shape* s, sg_dtype dt);
 int sg_upconv3d_subpixel_wgrad(const void* x, const void* gy, float* dw_dhwio, float* dbias, float coef, void* workspace,
                                size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st);
+/* Data gradient of conv3d(upscale3d(x)) (what tf.gradients delivers for x at pgan/generator.py:33-34) in the same form: a
+ * stride-2 convolution of the fine gradient with 4 x 4 x 4 taps whose weights are the forward's summed sets transposed, 64 tap
+ * products per low-resolution voxel instead of the 216 of the 27-tap data gradient followed by the 2x2x2 block sum, rounded
+ * once.  `s`: the LOW-resolution shape (cin = channels of x and gx, cout = channels of gy); gy: [n,2d,2h,2w,cout],
+ * gx: [n,d,h,w,cin]; w_dhwio is the FORWARD weight [3][3][3][cin][cout].  bf16, cin % 64 == 0, cout % 16 == 0, the tiles of the
+ * forward kernel with 32- or 16-wide rows; otherwise SG_EUNSUPPORTED (run sg_conv3d_fwd with transposed weights and
+ * sg_conv_epilogue.pool, then sg_downscale_sum). */
+int sg_upconv3d_subpixel_dgrad_supported(const sg_conv_shape* s, sg_dtype dt);
+size_t sg_upconv3d_subpixel_dgrad_packed_bytes(const sg_conv_shape* s, sg_dtype dt);
+int sg_upconv3d_subpixel_dgrad_pack(const float* w_dhwio, float coef, void* wp, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st);
+int sg_upconv3d_subpixel_dgrad(const void* gy, const void* wp, void* gx, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st);
 /* dw[kD][kH][kW][cin][cout] (f32) = coef * sum_v x[v+tap] (x) dy[v]   (tf Conv3DBackpropFilterV2).
  * workspace: sg_conv3d_wgrad_workspace() bytes, contents irrelevant on entry. */
 size_t sg_conv3d_wgrad_workspace(const sg_conv_shape* s, sg_dtype dt);

@@ -119,6 +119,21 @@ def hip_subpixel(cin, cout, d, h, w, k):
     return w % w_ == 0 and h % h_ == 0 and d % d_ == 0
 
 
+def hip_subpixel_dgrad(cin, cout, d, h, w, k):
+    """Whether the bf16 HIP path takes the gradient of conv3d(upscale3d(x)) for x in sub-pixel form (restates
+    saragan_amd/csrc/subpix.hip:sg_upconv3d_subpixel_dgrad_supported for a LOW-resolution shape: whole 64-channel parts of
+    gx, 16-channel chunks of gy, the forward's tiles with 32- or 16-wide rows)."""
+    if not hip_subpixel(16, 32, d, h, w, k) or cin % 64 or cout % 16:
+        return False
+    w_ = min(w, 32)
+    if w_ not in (32, 16):
+        return False
+    h_ = min(256 // w_, h, 8)
+    if w_ == 32:
+        h_ = min(h_, 4)
+    return (w_, h_, 256 // (w_ * h_)) in ((32, 4, 2), (16, 8, 2))
+
+
 _SUBPIX_M = ([[1., 0., 0.], [0., 1., 1.]], [[1., 1., 0.], [0., 0., 1.]])      # parity -> [tap 2][original tap 3]
 
 
@@ -146,9 +161,10 @@ def conv3d_upscaled_subpixel(x, w, activation, param=None):
 
 class _UpConvHip(torch.autograd.Function):
     """bf16 emulation of the generator's conv3d(upscale3d(x)) as the HIP path runs it: FORWARD in sub-pixel form (summed
-    weights rounded once), BACKWARD as the gather kernels compute it -- the data and weight gradients of the 27-tap
-    convolution with every tap's coef * w rounded on its own (functional._upconv_dgrad, conv_wgrad3l<ups>).  First order
-    only (nothing differentiates the generator's backward)."""
+    weights rounded once); BACKWARD: the data gradient in the same form where the library has a tile for it
+    (hip_subpixel_dgrad: the transpose of the forward with the same rounded sums), else as the gather kernels compute it,
+    from the 27-tap convolution with every tap's coef * w rounded on its own (functional._upconv_dgrad); the weight
+    gradient does not see the weights.  First order only (nothing differentiates the generator's backward)."""
 
     @staticmethod
     def forward(ctx, x, w, activation, param):
@@ -164,6 +180,9 @@ class _UpConvHip(torch.autograd.Function):
             x_, w_ = x.detach().requires_grad_(True), w.detach().requires_grad_(True)
             y = conv3d(upscale3d(x_), w_, *ctx.cfg)
             gx, gw = torch.autograd.grad(y, [x_, w_], gy)
+            if hip_subpixel_dgrad(w.shape[3], w.shape[4], *x.shape[2:], w.shape[:3]):
+                xs = x.detach().requires_grad_(True)
+                (gx,) = torch.autograd.grad(conv3d_upscaled_subpixel(xs, w.detach(), *ctx.cfg), xs, gy)
         return gx, gw, None, None
 
 

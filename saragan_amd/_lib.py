@@ -55,6 +55,10 @@ SIGNATURES = {
     'sg_upconv3d_subpixel_wgrad_supported': (C.c_int, [_SHP, C.c_int]),
     'sg_upconv3d_subpixel_wgrad_workspace': (_sz, [_SHP, C.c_int]),
     'sg_upconv3d_subpixel_wgrad': (C.c_int, [_p, _p, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
+    'sg_upconv3d_subpixel_dgrad_supported': (C.c_int, [_SHP, C.c_int]),
+    'sg_upconv3d_subpixel_dgrad_packed_bytes': (_sz, [_SHP, C.c_int]),
+    'sg_upconv3d_subpixel_dgrad_pack': (C.c_int, [_p, _f, _p, _SHP, C.c_int, _p]),
+    'sg_upconv3d_subpixel_dgrad': (C.c_int, [_p, _p, _p, _SHP, C.c_int, _p]),
     'sg_conv3d_wgrad_workspace': (_sz, [_SHP, C.c_int]),
     'sg_conv3d_wgrad': (C.c_int, [_p, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
     'sg_conv3d_pw_bwd': (C.c_int, [_p, _p, _p, _p, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),

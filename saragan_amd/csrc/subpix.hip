@@ -476,6 +476,300 @@ extern "C" int sg_upconv3d_subpixel_fwd(const void* x, const void* wp, void* y, 
 }
 
 // ------------------------------------------------------------------------------------------------------
+// data gradient of conv3d(upscale3d(x)) in sub-pixel form
+// ------------------------------------------------------------------------------------------------------
+// gx[u] = sum over fine voxels f = 2u + j, j in {-1, 0, 1, 2}^3, of W4[j]^T gy[f]: a stride-2 convolution of the fine
+// gradient with 4 x 4 x 4 taps whose weights are the forward's summed sets transposed (per dimension j = -1: {w2},
+// 0: {w1 + w2}, 1: {w0 + w1}, 2: {w0}) -- 64 tap products per low-resolution voxel where the pooled 27-tap gradient
+// (sg_conv_epilogue.pool + sg_downscale_sum) spends 216, and the result is rounded once.
+// A block walks tiles of 256 low-resolution voxels (wave = one 32-voxel column tile, all NT 32-channel tiles of gx) and
+// the 16-channel chunks of gy: item = (tile, chunk).  The item's fine halo -- (2TD+2) x (2TH+2) x (2TW+2) voxels, 32 bytes
+// each, ~124 KiB: single-buffered -- is written to LDS with the W parities de-interleaved (a tap then reads consecutive
+// rows for consecutive lanes; 16-byte slot = half ^ (row >> 3 & 1): conflict-free) from registers that were loaded
+// during the previous item; the weights (64 taps x NT KiB per chunk) stream through two 16-KiB buffers, loaded FOUR groups
+// ahead into registers (the L2 latency under load is 3-4 groups of MFMAs).  LDS fill per CU: (124 + 64 NT) KiB per
+// 4096 NT MFMA cycles = 31 / 23 B/clk at NT = 2 / 4: the kernel is bound by that, not by the MFMA.
+struct SubpixDgradArgs {
+  const bf16_t* gy;          // [N, 2d, 2h, 2w, co]
+  const char* wp;            // [ci / 64][chunk co/16][tap 64][nt 2][lane 64][16 B]
+  bf16_t* gx;                // [N, d, h, w, ci]
+  int N, d, h, w, ci, co, nchunk;
+  int nTd, nTh, nTw;
+  int64_t ntiles;
+};
+
+namespace {
+constexpr int kDgW = 16 * 1024;           // one weight group: 16 fragments
+constexpr int kDgY = 6 * 10 * 2 * 33 * 32; // largest halo image (tile 2 x 4 x 32): 126720 bytes
+}  // namespace
+
+template <int NT, int TD, int TH, int TW>
+__global__ __launch_bounds__(512) void upconv_subpixel_dgrad_kernel(SubpixDgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(TD * TH * TW == 256, "256 low-resolution voxels per tile");
+  constexpr int NG = 64 * NT / 16;        // weight groups per chunk
+  constexpr int TPG = 16 / NT;            // taps per group
+  constexpr int FD = 2 * TD + 2, FH = 2 * TH + 2, PW = TW + 1;
+  constexpr int NPIECES = FD * FH * 2 * PW * 2, NK = (NPIECES + 511) / 512;
+  static_assert(NK <= 16 && NPIECES * 16 <= kDgY, "halo image");
+  constexpr uint32_t DEAD = 0x80000000u;
+  char* const wbuf = smem;                // 2 x kDgW
+  char* const ybuf = smem + 2 * kDgW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int cpart = blockIdx.y;           // which NT * 32 channels of gx
+  const int q = wave * 32 + r;
+  const int vw = q % TW, vh = (q / TW) % TH, vd = q / (TW * TH);
+  // fragment address of tap (td, th, tw) of my voxel: row = ((2vd + td) * FH + 2vh + th) * 2PW + (tw & 1) * PW + vw + (tw >> 1),
+  // 16-byte slot = half ^ (pos >> 3 & 1), pos = vw + (tw >> 1): four per-lane bases + compile-time offsets
+  int xb[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      xb[i][j] = (((2 * vd + 2 * i) * FH + 2 * vh) * 2 * PW + vw + j) * 32 + ((hh ^ (((vw + j) >> 3) & 1)) << 4);
+  const int D2 = 2 * a.d, H2 = 2 * a.h, W2 = 2 * a.w;
+  const int64_t ysb = (int64_t)D2 * H2 * W2 * a.co * 2;           // bytes of one sample of gy (< 2 GiB, host-checked)
+
+  __amdgpu_buffer_rsrc_t ry;
+  uint32_t yv[NK];
+  int d0 = 0, h0 = 0, w0 = 0, n0 = 0;
+  auto enter_tile = [&](int64_t t) __attribute__((always_inline)) {
+    w0 = (int)(t % a.nTw) * TW; t /= a.nTw;
+    h0 = (int)(t % a.nTh) * TH; t /= a.nTh;
+    d0 = (int)(t % a.nTd) * TD;
+    n0 = (int)(t / a.nTd);
+  };
+  // halo staging plan of the tile (d0, h0, w0, n0): piece p = (row, half), row = ((fd * FH + fh) * 2 + parity) * PW + pos,
+  // fine w = 2 pos + parity; recomputed per tile (divisions by constants) instead of kept in 32 registers
+  auto plan_tile = [&]() __attribute__((always_inline)) {
+    ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.gy)) + n0 * ysb, 0, (int)ysb, 0x00020000);
+    const int gd0 = 2 * d0 - 1, gh0 = 2 * h0 - 1, gw0 = 2 * w0 - 1;      // fine coordinates of halo voxel (0, 0, 0)
+    int tid_ = tid;
+    asm volatile("" : "+v"(tid_));      // (keeps the decomposition below inside the call: hoisted out of the item loop it holds 48 registers)
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int p = tid_ + k * 512;
+      const int row = p >> 1, half = p & 1;
+      const int pos = row % PW, t1 = row / PW;
+      const int par = t1 & 1, line = t1 >> 1;
+      const int fh = line % FH, fd = line / FH;
+      const int gd = gd0 + fd, gh = gh0 + fh, gw = gw0 + 2 * pos + par;
+      const bool in = p < NPIECES && (unsigned)gd < (unsigned)D2 && (unsigned)gh < (unsigned)H2 && (unsigned)gw < (unsigned)W2;
+      yv[k] = in ? (uint32_t)((((gd * H2 + gh) * W2 + gw) * a.co + half * 8) * 2) : DEAD;
+    }
+  };
+  u32x4 gr[NK];
+  auto load_y = [&](int chunk) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) gr[k] = __builtin_amdgcn_raw_buffer_load_b128(ry, yv[k], (uint32_t)chunk * 32u, 0);
+  };
+  auto store_y = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+      const int p = tid + k * 512;
+      const int row = p >> 1, half = p & 1;
+      const int pos = row % PW;
+      if (p < NPIECES) *reinterpret_cast<u32x4*>(ybuf + row * 32 + ((half ^ ((pos >> 3) & 1)) << 4)) = gr[k];
+    }
+  };
+  // weight groups: 1024 pieces of 16 B, two per thread
+  u32x4 wr[4][2];
+  auto load_w = [&](u32x4 (&dst)[2], int chunk, int g) __attribute__((always_inline)) {
+    const char* src = a.wp + ((((int64_t)cpart * a.nchunk + chunk) * NG + g) << 14) + tid * 16;
+    dst[0] = *reinterpret_cast<const u32x4*>(src);
+    dst[1] = *reinterpret_cast<const u32x4*>(src + 8192);
+  };
+  auto store_w = [&](const u32x4 (&srcr)[2], char* dst) __attribute__((always_inline)) {
+    *reinterpret_cast<u32x4*>(dst + tid * 16) = srcr[0];
+    *reinterpret_cast<u32x4*>(dst + 8192 + tid * 16) = srcr[1];
+  };
+
+  const int64_t t_first = blockIdx.x;
+  const int64_t ntl = t_first < a.ntiles ? (a.ntiles - t_first + gridDim.x - 1) / gridDim.x : 0;   // my tiles
+  if (ntl == 0) return;
+  const int nchunk = a.nchunk;
+  f32x16 acc[NT];
+
+  // prologue: the first item's halo and weight group 0 into LDS, groups 1..3 into the register ring
+  enter_tile(t_first);
+  plan_tile();
+  load_y(0);
+  load_w(wr[0], 0, 0);
+  load_w(wr[1], 0, 1 % NG);
+  load_w(wr[2], 0, 2 % NG);
+  load_w(wr[3], 0, 3 % NG);
+  store_y();
+  store_w(wr[0], wbuf);
+  __syncthreads();
+
+  int64_t ti = 0;          // index of the current tile in my list
+  int chunk = 0;
+  for (;;) {
+    // the item after this one: its halo is requested now and written at the end of this item
+    int nchunk_i = chunk + 1;
+    int64_t nti = ti;
+    if (nchunk_i == nchunk) { nchunk_i = 0; ++nti; }
+    const bool more = nti < ntl;
+    const int od0 = d0, oh0 = h0, ow0 = w0, on0 = n0;     // this item's tile origin (the epilogue needs it after the plan moved on)
+    if (more) {
+      if (nchunk_i == 0) { enter_tile(t_first + nti * gridDim.x); plan_tile(); }
+      load_y(nchunk_i);
+    }
+    if (chunk == 0) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      // group g + 4 into the ring slot group g came from (groups beyond this chunk belong to the next item's chunk)
+      {
+        const int g4 = g + 4;
+        const int c4 = g4 < NG ? chunk : nchunk_i;
+        load_w(wr[g & 3], c4, g4 % NG);
+      }
+      const char* ws = wbuf + (g & 1) * kDgW;
+      // fragments one tap ahead of the MFMAs that use them (left to the scheduler, the unrolled group hoists all 24 reads:
+      // 96 registers on top of the 64 of the halo in flight)
+      u32x4 xf[2], wf[2][NT];
+      auto read_tap = [&](int slot, int tt) __attribute__((always_inline)) {
+        const int tap = g * TPG + tt;
+        const int td = tap >> 4, th = (tap >> 2) & 3, tw = tap & 3;
+        const int off = (((td & 1) * FH + th) * 2 * PW + (tw & 1) * PW) * 32;
+        xf[slot] = *reinterpret_cast<const u32x4*>(ybuf + xb[td >> 1][tw >> 1] + off);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) wf[slot][nt] = *reinterpret_cast<const u32x4*>(ws + ((tt * NT + nt) << 10) + lane * 16);
+      };
+      read_tap(0, 0);
+#pragma unroll
+      for (int tt = 0; tt < TPG; ++tt) {
+        if (tt + 1 < TPG) read_tap((tt + 1) & 1, tt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = sg_mfma_chunk<bf16_t>(wf[tt & 1][nt], xf[tt & 1], acc[nt]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      store_w(wr[(g + 1) & 3], wbuf + ((g + 1) & 1) * kDgW);
+      __syncthreads();
+    }
+    if (chunk + 1 == nchunk) {      // the tile is complete: one rounding, 64 contiguous bytes per lane pair and channel tile
+      const int64_t ov = (((int64_t)on0 * a.d + od0 + vd) * a.h + oh0 + vh) * a.w + ow0 + vw;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) sg_store_tile_row_bf16(a.gx + ov * a.ci + (cpart * NT + nt) * 32, acc[nt], hh, true);
+    }
+    if (!more) break;
+    store_y();
+    __syncthreads();
+    ti = nti;
+    chunk = nchunk_i;
+  }
+}
+
+struct SubpixDgradPackArgs {
+  const float* w;    // [3][3][3][ci][co]: the forward weight (DHWIO)
+  char* wp;
+  float coef;
+  int ci, co, nchunk, ntile;
+};
+
+__global__ void upconv_subpixel_dgrad_pack_kernel(SubpixDgradPackArgs a) {
+  // element i of the packed image: (ci / 64, chunk, tap, nt & 1, lane, e); A fragment: row = gx channel, K = gy channel
+  const int64_t total = (int64_t)a.nchunk * 64 * a.ntile * 64 * 8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t qq = i;
+    const int e = (int)(qq % 8); qq /= 8;
+    const int lane = (int)(qq % 64); qq /= 64;
+    const int ntl = (int)(qq % 2); qq /= 2;
+    const int tap = (int)(qq % 64); qq /= 64;
+    const int chunk = (int)(qq % a.nchunk);
+    const int nt = (int)(qq / a.nchunk) * 2 + ntl;
+    const int ci = nt * 32 + (lane & 31), co = chunk * 16 + (lane >> 5) * 8 + e;
+    float v = 0.f;
+    if (ci < a.ci && co < a.co) {
+      const int tj[3] = {tap >> 4, (tap >> 2) & 3, tap & 3};      // j + 1 per dimension
+      int lo[3], hi[3];      // original taps summed into j: j = -1: {2}; 0: {1, 2}; 1: {0, 1}; 2: {0}
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        lo[k] = tj[k] == 0 ? 2 : (tj[k] == 1 ? 1 : 0);
+        hi[k] = tj[k] <= 1 ? 2 : (tj[k] == 2 ? 1 : 0);
+      }
+      for (int kd = lo[0]; kd <= hi[0]; ++kd)
+        for (int kh = lo[1]; kh <= hi[1]; ++kh)
+          for (int kw = lo[2]; kw <= hi[2]; ++kw)
+            v += a.w[((((int64_t)kd * 3 + kh) * 3 + kw) * a.ci + ci) * a.co + co];
+      v *= a.coef;
+    }
+    reinterpret_cast<bf16_t*>(a.wp)[i] = (bf16_t)v;
+  }
+}
+
+// s: the LOW-resolution shape (n, d, h, w, cin = channels of x / gx, cout = channels of gy); kd = kh = kw = 3 of the forward
+extern "C" int sg_upconv3d_subpixel_dgrad_supported(const sg_conv_shape* s, sg_dtype dt) {
+  int td, th, tw;
+  if (!s || dt != SG_BF16 || s->cin < 32 || s->cout < 16 || s->cin % 32 || s->cout % 16 || !subpix_tile(s, &td, &th, &tw)) return 0;
+  const int nt = s->cin / 32;
+  if (nt % 2 || !((tw == 32 && td == 2 && th == 4) || (tw == 16 && td == 2 && th == 8))) return 0;   // whole 64-channel parts; instantiated tiles
+  if ((int64_t)s->d * s->h * s->w * 8 * s->cout * 2 >= (1ll << 31)) return 0;      // one sample of gy behind a buffer resource
+  return 1;
+}
+
+extern "C" size_t sg_upconv3d_subpixel_dgrad_packed_bytes(const sg_conv_shape* s, sg_dtype dt) {
+  if (!s || dt != SG_BF16 || s->cin < 1 || s->cout < 1) return 0;
+  return (size_t)sg_cdiv(s->cout, 16) * 64 * sg_cdiv(s->cin, 32) * 1024;
+}
+
+extern "C" int sg_upconv3d_subpixel_dgrad_pack(const float* w_dhwio, float coef, void* wp, const sg_conv_shape* s, sg_dtype dt,
+                                               sg_stream_t st) {
+  if (!s || !w_dhwio || !wp || dt != SG_BF16) return SG_EINVAL;
+  SubpixDgradPackArgs a;
+  a.w = w_dhwio; a.wp = reinterpret_cast<char*>(wp); a.coef = coef; a.ci = s->cin; a.co = s->cout;
+  a.nchunk = sg_cdiv(s->cout, 16); a.ntile = sg_cdiv(s->cin, 32);
+  const int64_t total = (int64_t)a.nchunk * 64 * a.ntile * 512;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(upconv_subpixel_dgrad_pack_kernel, dim3(blocks), dim3(256), 0, sg_st(st), a);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_upconv3d_subpixel_dgrad(const void* gy, const void* wp, void* gx, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st) {
+  if (!s || !gy || !wp || !gx) return SG_EINVAL;
+  if (!sg_aligned16(gy) || !sg_aligned16(wp) || !sg_aligned16(gx)) return SG_EALIGN;
+  if (!sg_upconv3d_subpixel_dgrad_supported(s, dt)) return SG_EUNSUPPORTED;
+  SubpixDgradArgs a;
+  int TD, TH, TW;
+  subpix_tile(s, &TD, &TH, &TW);
+  a.gy = reinterpret_cast<const bf16_t*>(gy); a.wp = reinterpret_cast<const char*>(wp); a.gx = reinterpret_cast<bf16_t*>(gx);
+  a.N = s->n; a.d = s->d; a.h = s->h; a.w = s->w; a.ci = s->cin; a.co = s->cout; a.nchunk = s->cout / 16;
+  a.nTd = s->d / TD; a.nTh = s->h / TH; a.nTw = s->w / TW;
+  a.ntiles = (int64_t)s->n * a.nTd * a.nTh * a.nTw;
+  sg_conv_shape full = *s;       // (profiler key: the data-gradient convolution on the fine grid, as the pooled path reports it)
+  full.d *= 2; full.h *= 2; full.w *= 2; full.kd = full.kh = full.kw = 3; full.upsample_in = 0;
+  full.cin = s->cout; full.cout = s->cin;
+  sg_prof_scope prof(0, &full, dt, sg_st(st));
+  const int64_t per_part = 256 / (s->cin / 64) > 8 ? 256 / (s->cin / 64) : 8;
+  const unsigned gx_ = (unsigned)(a.ntiles < per_part ? a.ntiles : per_part);
+  const size_t lds = 2 * (size_t)kDgW + (size_t)kDgY;
+  const int nt = s->cin / 32;
+  SG_KNAME("upconv_subpixel_dgrad");
+#define SG_DG(NT_, TD_, TH_, TW_)                                                    \
+  do {                                                                               \
+    auto kern = upconv_subpixel_dgrad_kernel<NT_, TD_, TH_, TW_>;                    \
+    SG_ALLOW_160K_LDS(kern);                                                         \
+    hipLaunchKernelGGL(kern, dim3(gx_, (unsigned)(nt / 2)), dim3(512), lds, sg_st(st), a); \
+  } while (0)
+  if (TW == 32) SG_DG(2, 2, 4, 32);
+  else if (TW == 16) SG_DG(2, 2, 8, 16);
+  else { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }
+#undef SG_DG
+  hipError_t e = hipGetLastError();
+  prof.done((int)e);
+  return (int)e;
+}
+
+// ------------------------------------------------------------------------------------------------------
 // weight gradient of conv3d(upscale3d(x)) in sub-pixel form
 // ------------------------------------------------------------------------------------------------------
 // dWeff[class][tap][ci][co] = sum over low-resolution voxels j of x[j + n(class, tap)][ci] * gy[2j + class][co]: 64

@@ -862,11 +862,48 @@ def _pool_mode(x, k, cin, cout):
 _POOL_REST = {1: (1, 2, 1), 2: (2, 1, 1)}     # the pairs left to sg_downscale_sum after the epilogue's block means
 
 
+def _upconv_dgrad_subpixel(g, w, coef):
+    """The same gradient in sub-pixel form (sg_upconv3d_subpixel_dgrad): one launch on the low-resolution grid, 64 tap
+    products per voxel with the forward's summed weights transposed, one rounding.  None where the library has no tile."""
+    lib = _lib.load()
+    g = ndhwc(g)
+    n, co, d2, h2, w2 = _dims(g)
+    ci = w.shape[3]
+    if (d2 | h2 | w2) & 1 or w.shape[4] != co:
+        return None
+    dt, st = _dt(g), _stream()
+    low = _shape(n, d2 // 2, h2 // 2, w2 // 2, ci, co, (3, 3, 3), False)
+    if not lib.sg_upconv3d_subpixel_dgrad_supported(C.byref(low), dt):
+        return None
+    key = ('subpix_dgrad', w.data_ptr(), w._version, float(coef), dt)
+    hit = _SUBPIX_CACHE.get(key)
+    if hit is None:
+        w32 = w.detach()
+        if w32.dtype != torch.float32 or not w32.is_contiguous():
+            w32 = w32.contiguous().float()
+        wp = torch.empty(lib.sg_upconv3d_subpixel_dgrad_packed_bytes(C.byref(low), dt), device=w.device, dtype=torch.uint8)
+        check(lib.sg_upconv3d_subpixel_dgrad_pack(_ptr(w32), float(coef), _ptr(wp), C.byref(low), dt, st), 'sg_upconv3d_subpixel_dgrad_pack')
+        if w.is_leaf or not w.requires_grad:
+            _SUBPIX_CACHE[key] = (wp, w)
+    else:
+        wp = hit[0]
+    gx = _empty_like_shape(g, ci, (d2 // 2, h2 // 2, w2 // 2))
+    rc = lib.sg_upconv3d_subpixel_dgrad(_ptr(g), _ptr(wp), _ptr(gx), C.byref(low), dt, st)
+    if rc == _lib.SG_EUNSUPPORTED:
+        return None
+    check(rc, 'sg_upconv3d_subpixel_dgrad')
+    return gx
+
+
 def _upconv_dgrad(g, w, coef, flip):
     """Gradient of conv3d(upscale3d(x)) (pgan/generator.py:33-34) for x: the 2x2x2 block SUM of the data gradient.  When
     nothing differentiates this backward again, the sliding-halo kernel pools 2 x 1 x 2 in its epilogue
     (sg_conv_epilogue.pool) and the full-resolution data gradient -- cin x the fine volume -- is never written."""
     if not torch.is_grad_enabled() and w.dim() == 5:
+        if flip and not _NO_SUBPIXEL and tuple(w.shape[:3]) == (3, 3, 3) and g.dtype == torch.bfloat16:
+            gx = _upconv_dgrad_subpixel(g, w, coef)
+            if gx is not None:
+                return gx
         cin, cout = (w.shape[4], w.shape[3]) if flip else (w.shape[3], w.shape[4])
         mode = _pool_mode(g, w.shape[:3], cin, cout)
         if mode:

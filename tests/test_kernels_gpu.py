@@ -310,6 +310,74 @@ def test_upconv_fused_gather_pingpong_kernel(cout, dtype, sg_env):
     close(y, ref, dtype, 'fused x2 gather')
 
 
+SUBPIX_DGRAD_CASES = [
+    # n, ci (channels of x), co (channels of gy), low-resolution (d, h, w)
+    (2, 64, 32, (4, 8, 32)),          # the 64 -> 32 layer: tile 2 x 4 x 32, two chunks
+    (1, 128, 64, (2, 8, 64)),         # two 64-channel parts of gx (blockIdx.y), four chunks, two W tiles
+    (3, 128, 128, (2, 8, 16)),        # 16-wide rows: tile 2 x 8 x 16; more tiles than one block takes in a trip
+    (1, 64, 48, (6, 4, 32)),          # co not a multiple of 32; three D tiles
+]
+
+
+@pytest.mark.parametrize('case', SUBPIX_DGRAD_CASES, ids=[f'{c[1]}from{c[2]}at{"x".join(map(str, c[3]))}' for c in SUBPIX_DGRAD_CASES])
+def test_upconv_subpixel_data_gradient(case, monkeypatch):
+    """Gradient of conv3d(upscale3d(x)) for x in sub-pixel form (sg_upconv3d_subpixel_dgrad: a stride-2, 4 x 4 x 4-tap
+    convolution of the fine gradient with the forward's summed weights transposed) against (a) the same sum in fp64 with
+    the weights the packed image holds, (b) the fp64 oracle's autograd through ops.py:276-289 + :147-150 and (c) the library's
+    27-tap pooled path; the kernel name is asserted."""
+    import ctypes as C
+    from saragan_amd import _lib
+    from saragan_amd import functional as F
+    n, ci, co, sp = case
+    dtype = torch.bfloat16
+    fine = tuple(2 * v for v in sp)
+    w = rnd((3, 3, 3, ci, co), 71, dtype)
+    gy = rnd((n, co, *fine), 72, dtype)
+    coef = O.runtime_coef(w.shape, 'leaky_relu', 0.2)
+    wg, gyg = w.float().to(dev()), cl(gy, dtype)
+    F.clear_pack_cache()
+    lib = _lib.load()
+    lib.sg_prof_enable(1)
+    with torch.no_grad():
+        gx = F._upconv_dgrad_subpixel(gyg, wg, coef)
+    torch.cuda.synchronize()
+    ents = (_lib.ProfEntry * 8)()
+    cnt = C.c_int32(0)
+    lib.sg_prof_collect(ents, 8, C.byref(cnt))
+    lib.sg_prof_enable(0)
+    assert gx is not None, 'the sub-pixel data gradient was not taken'
+    assert [ents[i].kernel.decode() for i in range(cnt.value)] == ['upconv_subpixel_dgrad']
+    assert tuple(gx.shape) == (n, ci, *sp)
+    # (a) the kernel's own arithmetic in fp64: W4[j] = bf16(coef * sum of the taps folded into j), j = -1: {2}, 0: {1, 2}, 1: {0, 1}, 2: {0}
+    sets = [(2,), (1, 2), (0, 1), (0,)]
+    wd = w.double()
+    w4 = torch.zeros((4, 4, 4, ci, co), dtype=torch.float64)
+    for a_ in range(4):
+        for b_ in range(4):
+            for c_ in range(4):
+                acc = 0
+                for kd in sets[a_]:
+                    for kh in sets[b_]:
+                        for kw in sets[c_]:
+                            acc = acc + wd[kd, kh, kw]
+                w4[a_, b_, c_] = (acc * coef).to(dtype).double()
+    ref_a = torch.nn.functional.conv3d(gy.double(), w4.permute(3, 4, 0, 1, 2), stride=2, padding=1)
+    close(gx, ref_a, dtype, 'sub-pixel dgrad vs its own sum in fp64')
+    # (b) autograd of the reference formulation, fp64, per-tap rounded weights (what the forward multiplies with)
+    xr = torch.zeros((n, ci, *sp), dtype=torch.float64, requires_grad=True)
+    wq = (w.double() * coef).to(dtype).double() / coef
+    yr = O.conv3d(O.upscale3d(xr), wq, 'leaky_relu', 0.2)
+    (ref_b,) = torch.autograd.grad(yr, xr, gy.double())
+    err = float(torch.linalg.vector_norm(gx.double().cpu() - ref_b) / torch.linalg.vector_norm(ref_b))
+    assert err <= 1e-2, err          # bf16 rounding of the summed weights (2^-9 relative per weight) and of the result
+    # (c) the 27-tap pooled path of the library
+    monkeypatch.setattr(F, '_NO_SUBPIXEL', True)
+    with torch.no_grad():
+        gx2 = F._upconv_dgrad(gyg, wg, coef, True)
+    err2 = float(torch.linalg.vector_norm(gx.double() - gx2.double()) / torch.linalg.vector_norm(gx2.double()))
+    assert err2 <= 1e-2, err2
+
+
 SUBPIX_CASES = [
     # n, cin, cout, low-resolution (d, h, w), pixel_norm
     (2, 64, 32, (4, 8, 32), True),        # the 64 -> 32 layer's tile (2 x 4 x 32), pixel-norm in the epilogue

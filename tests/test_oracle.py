@@ -218,3 +218,5 @@ def test_subpixel_restatement_equals_the_27_tap_form_and_matches_the_librarys_ru
         # (the library answers with a probe that needs no GPU: the packed size is 0 for channel counts it rejects, the tile
         # rule is exported for this test)
         assert bool(lib.sg_upconv3d_subpixel_supported(C.byref(shp), _lib.SG_BF16)) == O.hip_subpixel(cin, cout, d, h, w_, (3, 3, 3)), (cin, cout, d, h, w_)
+        assert bool(lib.sg_upconv3d_subpixel_dgrad_supported(C.byref(shp), _lib.SG_BF16)) == O.hip_subpixel_dgrad(cin, cout, d, h, w_, (3, 3, 3)), \
+            ('dgrad', cin, cout, d, h, w_)

@@ -205,18 +205,24 @@ __device__ __forceinline__ float sg_wave_sum(float v) {
   return (r0 + r1) + (r2 + r3);
 }
 
-template <typename T, int CIN, int COUT, int CS>
-__global__ __launch_bounds__(256, CIN == 4 ? 3 : 2) void conv_small_wgrad_kernel(SmallWgradArgs a) {   // 3 (2) blocks per CU: <= 168 (256) registers
+template <typename T, int CINT, int COUT, int CS>      // CINT input channels in the tensor; a block takes CIN = min(CINT, 8) of them
+__global__ __launch_bounds__(256, CINT == 4 ? 3 : 2) void conv_small_wgrad_kernel(SmallWgradArgs a) {   // 3 (2) blocks per CU: <= 168 (256) registers
   constexpr int ES = (int)sizeof(T);
+  constexpr int CIN = CINT < 8 ? CINT : 8, SI = CINT / CIN;          // SI groups of input channels
   constexpr int NACC = 9 * CIN * CS, NTOT = NACC + CS;
   __shared__ float red[4][NTOT];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  constexpr int S = COUT / CS;                                       // slices; neighbouring blocks take the slices of the
-  const int xb = blockIdx.x / S, nxb = gridDim.x / S;                // same pixels (they share x and the dy lines in L2)
-  const int c0 = (blockIdx.x % S) * CS;                              // this block's slice of the output channels
+  constexpr int S = (COUT / CS) * SI;                                // slices: output channels x input-channel groups
+  // The S blocks that take the slices of the same pixels must share an L2: consecutive block ids go round the 8 XCDs, so
+  // a pixel group's slices are the ids with the same id % 8 (dealt as neighbours they sat on S different XCDs and every
+  // one fetched x and its dy lines from HBM again: FETCH_SIZE 4-8x the algorithmic bytes).  gridDim.x = S * nxb, nxb % 8 == 0.
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int xb = (jb / S) * 8 + xcd, nxb = gridDim.x / S;
+  const int c0 = ((jb % S) / SI) * CS;                               // this block's slice of the output channels ...
+  const int ci0 = ((jb % S) % SI) * CIN;                             // ... and of the input channels
   const int64_t wave = __builtin_amdgcn_readfirstlane(xb * 4 + wv), nwaves = (int64_t)nxb * 4;
   const int64_t simg = (int64_t)a.H * a.W;
-  const uint32_t rowb = (uint32_t)a.W * CIN * ES, rowg = (uint32_t)a.W * COUT * ES;
+  const uint32_t rowb = (uint32_t)a.W * CINT * ES, rowg = (uint32_t)a.W * COUT * ES;
   float acc[NACC], accb[CS];
 #pragma unroll
   for (int i = 0; i < NACC; ++i) acc[i] = 0.f;
@@ -226,13 +232,13 @@ __global__ __launch_bounds__(256, CIN == 4 ? 3 : 2) void conv_small_wgrad_kernel
     const sg_small_item it = sg_small_decode(item, a.segs, a.strips, a.R);
     const int w = it.w0 + lane;
     const bool live = w < a.W;
-    const __amdgpu_buffer_rsrc_t rx = sg_rsrc(a.x, (int64_t)it.n * simg * CIN * ES, simg * CIN * ES);
+    const __amdgpu_buffer_rsrc_t rx = sg_rsrc(a.x, (int64_t)it.n * simg * CINT * ES, simg * CINT * ES);
     const __amdgpu_buffer_rsrc_t rg = sg_rsrc(a.dy, (int64_t)it.n * simg * COUT * ES, simg * COUT * ES);
     uint32_t colo[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const int ww = w + c - 1;
-      colo[c] = (live && ww >= 0 && ww < a.W) ? (uint32_t)ww * CIN * ES : SG_DEAD;
+      colo[c] = (live && ww >= 0 && ww < a.W) ? (uint32_t)(ww * CINT + ci0) * ES : SG_DEAD;
     }
     const uint32_t go = live ? (uint32_t)(w * COUT + c0) * ES : SG_DEAD;
     const int hend = it.h0 + a.R < a.H ? it.h0 + a.R : a.H;
@@ -297,14 +303,14 @@ __global__ __launch_bounds__(256, CIN == 4 ? 3 : 2) void conv_small_wgrad_kernel
     if (lane == 0) red[wv][NACC + i] = v;
   }
   __syncthreads();
-  float* slab = a.slabs + (int64_t)xb * (9 * CIN * COUT + COUT);
+  float* slab = a.slabs + (int64_t)xb * (9 * CINT * COUT + COUT);
   for (int i = threadIdx.x; i < NTOT; i += 256) {
     const float v = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
     if (i < NACC) {
-      const int c = i % CS, tc = i / CS;                             // tc = tap * CIN + ci
-      slab[tc * COUT + c0 + c] = v;
-    } else {
-      slab[9 * CIN * COUT + c0 + (i - NACC)] = v;
+      const int c = i % CS, tc = i / CS;                             // tc = tap * CIN + ci (of this block's input channels)
+      slab[((tc / CIN) * CINT + ci0 + tc % CIN) * COUT + c0 + c] = v;
+    } else if (ci0 == 0) {                                           // (the bias sums do not depend on the input-channel group)
+      slab[9 * CINT * COUT + c0 + (i - NACC)] = v;
     }
   }
 }
@@ -423,18 +429,23 @@ int sg_small_fwd(const void* x, const void* tail, void* y, const sg_conv_shape* 
 
 // weight gradient (16 -> 16 stays on the MFMA kernels: a thread's slice of the sums would be one output channel wide, and
 // the forward kernel's 2304 weights no longer fit the scalar registers)
-bool sg_small_wgrad_eligible(const sg_conv_shape* s) { return sg_small_eligible(s) && s->cin <= 8; }   // (16 input channels: the
-                                                                                                       // three-row window alone is 144 registers)
+bool sg_small_wgrad_eligible(const sg_conv_shape* s) {     // (16 input channels run as two groups of 8: the three-row window of all 16
+  return (sg_small_eligible(s) && s->cin <= 8) ||          //  alone would be 144 registers; cout 8 or 16 -- at 32 the 64 slices lose to the MFMA kernel: 306 against 245 us)
+         (s->kd == 1 && s->kh == 3 && s->kw == 3 && s->d == 1 && !s->upsample_in && s->cin == 16 &&
+          (s->cout == 8 || s->cout == 16) && (s->w % 2) == 0 && (int64_t)s->n * s->h * s->w >= (1 << 16) &&
+          (int64_t)s->h * s->w * 32 * 4 < (1ll << 31));
+}
 // A thread keeps 72 sums (9 taps x CIN x CS): CS = 2 output channels at 4 input channels, 1 at 8.  (144 sums per thread were
 // tried first: 256 registers, one or two waves per SIMD, the row-ahead loads no longer hidden -- 0.85 TB/s.)
-static int small_wgrad_slices(const sg_conv_shape* s) { return s->cout / (s->cin == 4 ? 2 : 1); }
+static int small_wgrad_slices(const sg_conv_shape* s) { return s->cout / (s->cin == 4 ? 2 : 1) * (s->cin > 8 ? s->cin / 8 : 1); }
 static int small_wgrad_blocks(const sg_conv_shape* s) {      // blocks PER SLICE
   int64_t cap = (256 * (s->cin == 4 ? 3 : 2)) / small_wgrad_slices(s);      // three (two) blocks per CU over all slices
   if (cap < 32) cap = 32;
   const int r = small_rows_per_strip(s, (int)cap * 4);
   const int64_t items = (int64_t)s->n * sg_cdiv(s->h, r) * sg_cdiv(s->w, 64);
-  const int64_t nb = (items + 3) / 4;
-  return (int)(nb < cap ? nb : cap);
+  int64_t nb = (items + 3) / 4;
+  if (nb > cap) nb = cap;
+  return (int)((nb + 7) & ~(int64_t)7);      // whole rounds of the 8 XCDs (blocks without items store zero slabs)
 }
 size_t sg_small_wgrad_workspace(const sg_conv_shape* s) {
   return sg_small_wgrad_eligible(s) ? (size_t)small_wgrad_blocks(s) * (9 * s->cin * s->cout + s->cout) * 4 : 0;
@@ -443,10 +454,11 @@ size_t sg_small_wgrad_workspace(const sg_conv_shape* s) {
 template <typename T>
 static int small_wgrad_launch(const SmallWgradArgs& a, const sg_conv_shape* s, unsigned nb, hipStream_t st) {
   const int key = s->cin * 100 + s->cout;
-#define SG_SW(CI, CO, CS_) case CI * 100 + CO: hipLaunchKernelGGL((conv_small_wgrad_kernel<T, CI, CO, CS_>), dim3(nb * (CO / CS_)), dim3(256), 0, st, a); break;
+#define SG_SW(CI, CO, CS_) case CI * 100 + CO: hipLaunchKernelGGL((conv_small_wgrad_kernel<T, CI, CO, CS_>), dim3(nb * (CO / CS_) * (CI > 8 ? CI / 8 : 1)), dim3(256), 0, st, a); break;
   switch (key) {
     SG_SW(4, 4, 2) SG_SW(4, 8, 2) SG_SW(4, 16, 2)
     SG_SW(8, 4, 1) SG_SW(8, 8, 1) SG_SW(8, 16, 1)
+    SG_SW(16, 8, 1) SG_SW(16, 16, 1)
     default: return SG_EUNSUPPORTED;
   }
 #undef SG_SW

@@ -231,7 +231,7 @@ def test_config5_full_size_step_matches_oracle():
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('cin,cout', [(4, 4), (4, 8), (8, 4), (8, 8), (8, 16), (16, 8), (4, 16), (16, 4)])
+@pytest.mark.parametrize('cin,cout', [(4, 4), (4, 8), (8, 4), (8, 8), (8, 16), (16, 8), (4, 16), (16, 4), (16, 16), (16, 32)])
 def test_small_channel_kernels_match_the_mfma_path(cin, cout, dtype, sg_env):
     """The small-channel VALU kernels (csrc/small.hip: conv_small_fwd / conv_small_wgrad) against the same calls through the
     MFMA kernels (SG_NO_SMALL=1) on a ragged 2-D shape (W not a multiple of the 128-pixel segment): forward with bias +
@@ -265,8 +265,11 @@ def test_small_channel_kernels_match_the_mfma_path(cin, cout, dtype, sg_env):
         return (y, scale, signs, y2, signs2, gx, dw, db), sorted({ents[i].kernel.decode() for i in range(cnt.value)})
 
     got, kern = run()
-    # (16 input channels: forward / data gradient only -- the weight gradient's three-row window would not fit the registers)
-    assert any('conv_small_fwd' in k for k in kern) and (cin == 16 or any('conv_small_wgrad' in k for k in kern)), kern
+    # which layers the small kernels take: forward / data gradient up to cin * cout = 128; weight gradient those with cin <= 8,
+    # and 16 input channels (as two groups of 8) with 8 or 16 outputs
+    small_fwd = cin * cout <= 128
+    small_wg = (small_fwd and cin <= 8) or (cin == 16 and cout in (8, 16))
+    assert any('conv_small_fwd' in k for k in kern) == small_fwd and any('conv_small_wgrad' in k for k in kern) == small_wg, kern
     sg_env(SG_NO_SMALL=1)
     ref, kern_ref = run()
     assert not any('conv_small' in k for k in kern_ref), kern_ref
@@ -288,5 +291,5 @@ def test_small_channel_kernels_match_the_mfma_path(cin, cout, dtype, sg_env):
     assert float((got[6].double().cpu() - refw).abs().max() / refw.abs().max()) <= (1e-4 if dtype == torch.float32 else 1e-2)
     # run-to-run: the slab reduction has no atomics
     again, _ = (sg_env(SG_NO_SMALL=0), run())[1]
-    if cin < 16:
+    if small_wg:
         assert torch.equal(again[6], got[6]) and torch.equal(again[7], got[7])

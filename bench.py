@@ -405,6 +405,9 @@ def main():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     device = torch.device('cuda', local % max(1, torch.cuda.device_count()))   # (rehearsals may stack ranks on one GPU)
     torch.cuda.set_device(device)
+    if os.environ.get('SARAGAN_ARENA_GB'):      # experiment: one large allocation up front, carved up by torch's caching allocator
+        arena = torch.empty(int(float(os.environ['SARAGAN_ARENA_GB']) * (1 << 30)), dtype=torch.uint8, device=device)
+        del arena
     comm = parallel.collective_info() if world > 1 else None     # backend, RCCL version, communicator size, bucket algorithm
     cfg = build(args, device, args.dtype)
     sess, ph = cfg['sess'], cfg['ph']
@@ -455,11 +458,19 @@ def main():
         for o_ in cfg['optimizers']:
             o_.distributed.exposed_ms()       # forget the warm-up steps
     lib.sg_prof_enable(0 if os.environ.get('SARAGAN_BENCH_NO_PROF') else 1)     # (diagnostic: no event bracketing at all)
+    step_marks = [] if os.environ.get('SARAGAN_BENCH_STEP_TIMES') else None      # diagnostic: an event after every step (no sync)
     with Stopwatch(lambda: None) as sw:      # the barrier before is the one above; the one after follows
         for i in range(args.steps):
             step(args.warmup + ncal + i)
+            if step_marks is not None:
+                step_marks.append((torch.cuda.Event(enable_timing=True), time.perf_counter()))
+                step_marks[-1][0].record()
         barrier()
     dt = sw.seconds
+    if step_marks and rank == 0:
+        dev_ms = [round(step_marks[i][0].elapsed_time(step_marks[i + 1][0]), 2) for i in range(len(step_marks) - 1)]
+        host_ms = [round((step_marks[i + 1][1] - step_marks[i][1]) * 1e3, 2) for i in range(len(step_marks) - 1)]
+        print('STEP_TIMES device', dev_ms, 'host', host_ms, file=sys.stderr, flush=True)
     if world > 1:      # all-reduce time left exposed behind backward, per step (G + D), this rank
         comm['exposed_allreduce_ms_per_step'] = round(sum(sum(o_.distributed.exposed_ms()) for o_ in cfg['optimizers']) / args.steps, 3)
         comm['bucket_mib'] = cfg['optimizers'][0].distributed.bucket_elems * 4 >> 20

@@ -128,6 +128,52 @@ def main():
               2.0 * vox * 64 * cin * cout,
               lambda: _lib.check(lib.sg_upconv3d_subpixel_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep), dt, st)))
         del x, y, sout, scale
+    # round 3: the sub-pixel data gradient (fine gradient in, low-resolution gradient out)
+    for n, (d, h, w), ci, co in ((32, (16, 64, 64), 64, 32), (32, (8, 32, 32), 128, 64), (32, (4, 16, 16), 128, 128)):
+        shp = ConvShape(n, d, h, w, ci, co, 3, 3, 3, 0)
+        if not lib.sg_upconv3d_subpixel_dgrad_supported(C.byref(shp), dt):
+            continue
+        vox = n * d * h * w
+        gy = torch.randn(n, 2 * d, 2 * h, 2 * w, co, device=dev).to(torch.bfloat16)
+        wt = torch.randn(3, 3, 3, ci, co, device=dev)
+        wp = torch.empty(lib.sg_upconv3d_subpixel_dgrad_packed_bytes(C.byref(shp), dt), device=dev, dtype=torch.uint8)
+        _lib.check(lib.sg_upconv3d_subpixel_dgrad_pack(wt.data_ptr(), 0.05, wp.data_ptr(), C.byref(shp), dt, st))
+        gx = torch.empty(n, d, h, w, ci, device=dev, dtype=torch.bfloat16)
+        twice(f'upconv sub-pixel dgrad n{n} {2 * d}x{2 * h}x{2 * w} {co}->{ci}', 'upconv_subpixel_dgrad_kernel', 8 * vox * co * 2 + vox * ci * 2 + 64 * ci * co * 2,
+              2.0 * vox * 64 * ci * co,
+              lambda: _lib.check(lib.sg_upconv3d_subpixel_dgrad(gy.data_ptr(), wp.data_ptr(), gx.data_ptr(), C.byref(shp), dt, st)))
+        del gy, gx
+    # round 3: D's pooled backward with the masked gather fused into its consumers (pooled gradient + sign words in)
+    for n in (32, 64):
+        d, h, w = 32, 128, 128
+        vox = n * d * h * w
+        gyh = torch.randn(n, d // 2, h // 2, w // 2, 64, device=dev).to(torch.bfloat16)
+        x = torch.randn(n, d, h, w, 32, device=dev).to(torch.bfloat16)
+        bits64 = torch.randint(-2 ** 31, 2 ** 31 - 1, (n, d, h, w, 2), device=dev, dtype=torch.int32)
+        bits32 = torch.randint(-2 ** 31, 2 ** 31 - 1, (n, d, h, w, 1), device=dev, dtype=torch.int32)
+        wt = torch.randn(3, 3, 3, 32, 64, device=dev)
+        shp = ConvShape(n, d, h, w, 64, 32, 3, 3, 3, 1)
+        wp = torch.empty(lib.sg_conv3d_packed_bytes(C.byref(shp), dt), device=dev, dtype=torch.uint8)
+        _lib.check(lib.sg_conv3d_pack_weights(wt.data_ptr(), 0.05, 1, wp.data_ptr(), C.byref(shp), dt, st))
+        gx = torch.empty(n, d, h, w, 32, device=dev, dtype=torch.bfloat16)
+        fws_bytes = lib.sg_conv3d_fwd_workspace(C.byref(shp), dt)
+        fws = torch.empty(max(16, fws_bytes), device=dev, dtype=torch.uint8)
+        ep = ConvEpilogue(None, 0, 0.0, 0, 1e-8, None, bits32.data_ptr(), 0.2, None)
+        ep.workspace, ep.workspace_bytes = fws.data_ptr(), fws_bytes
+        ep.in_mask_bits, ep.in_mask_slope, ep.in_gain = bits64.data_ptr(), 0.2, 0.125
+        # algorithmic bytes: pooled gradient once, the input's sign words, output + its mask words, weights
+        alg = vox / 8 * 64 * 2 + vox * 2 * 4 + vox * 32 * 2 + vox * 4 + 27 * 64 * 32 * 2
+        twice(f'fwd masked gather (K split) n{n} {d}x{h}x{w} 64->32', 'conv_fwd3s', alg, 2.0 * vox * 64 * 32 * 27,
+              lambda: _lib.check(lib.sg_conv3d_fwd(gyh.data_ptr(), wp.data_ptr(), gx.data_ptr(), C.byref(shp), C.byref(ep), dt, st)), 2)
+        shw = ConvShape(n, d, h, w, 32, 64, 3, 3, 3, 0)
+        wsb = lib.sg_conv3d_wgrad_workspace(C.byref(shw), dt)
+        ws = torch.empty(wsb, device=dev, dtype=torch.uint8)
+        dw = torch.empty(3, 3, 3, 32, 64, device=dev)
+        db = torch.empty(64, device=dev)
+        twice(f'wgrad+dbias, dy gathered n{n} {d}x{h}x{w} 32->64', 'conv_wgrad3l', vox * 32 * 2 + vox / 8 * 64 * 2 + vox * 2 * 4, 2.0 * vox * 64 * 32 * 27,
+              lambda: _lib.check(lib.sg_conv3d_wgrad_bias_up_masked(x.data_ptr(), gyh.data_ptr(), bits64.data_ptr(), 0.2, 0.125, dw.data_ptr(),
+                                                                    db.data_ptr(), 0.05, ws.data_ptr(), wsb, C.byref(shw), dt, st)))
+        del gyh, x, bits64, bits32, gx, fws, ws
     # round 3: GEMM-tiled convolution of the 1x4x4 / 2x8x8 levels (K split: the partial tiles are part of the traffic)
     for n, (d, h, w), cin, cout in ((32, (2, 8, 8), 512, 512), (64, (2, 8, 8), 512, 512), (32, (1, 4, 4), 512, 512)):
         shp = ConvShape(n, d, h, w, cin, cout, 1, 3, 3, 0)
@@ -150,7 +196,7 @@ def main():
         del x, y, sout, fws
     # round 3: small-channel 2-D kernels (BASELINE config 5's top level, fp32)
     f32 = _lib.SG_F32
-    for n, hw, cin, cout in ((8, 1024, 4, 8), (8, 1024, 4, 4), (4, 1024, 8, 4), (8, 512, 8, 16)):
+    for n, hw, cin, cout in ((8, 1024, 4, 8), (8, 1024, 4, 4), (4, 1024, 8, 4), (8, 512, 8, 16), (4, 512, 16, 8)):
         shp = ConvShape(n, 1, hw, hw, cin, cout, 1, 3, 3, 0)
         vox = n * hw * hw
         x = torch.randn(n, 1, hw, hw, cin, device=dev)

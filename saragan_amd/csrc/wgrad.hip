@@ -1356,6 +1356,189 @@ static int launch_wgrad3(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   return SG_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// wgrad for the low-resolution 1x3x3 levels (bf16, H = W = 4 or 8: the 512 -> 512 layers of the 1x4x4 and 2x8x8 levels).
+// The generic kernel above spends 14 us per 256-voxel tile there: its staging is issued with 64-bit pointer arithmetic per
+// piece, lands while nobody computes, and three of its four waves own two taps where the fourth owns three.  Here a tile is
+// 128 voxels = P whole (n, d) planes, so every tile has the SAME staging plan: per-lane buffer offsets computed once, a
+// scalar offset per tile, LDS-DMA with hardware zero fill for the halo rows.  Tiles go through a ring of three LDS
+// buffers, requested two tiles ahead; the four waves split a tile's eight K steps (all nine taps each: 18 MFMAs per
+// wave and tile) and add their sums to the workspace on their own at the end.
+// ------------------------------------------------------------------------------------------------------
+struct WgradPlanesArgs {
+  const void* x;
+  const void* dy;
+  float* dwt;
+  float* dbias;              // optional: column sums of dy, by the ci_t == 0 blocks
+  int cin, cout, ciT, coT;
+  int ntiles;                // (N * D) / P
+  int64_t slab, bslab;       // elements between per-block slabs; 0: atomics into one buffer
+};
+
+template <int HW_>
+__device__ __forceinline__ void conv_wgrad_planes_body(const WgradPlanesArgs& a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int H = HW_, W = HW_, P = 128 / (H * W), RP = (H + 2) * (W + 2);
+  constexpr int XROWS = P * RP, NPX = (XROWS * 4 + 255) / 256, NPY = 2, PPT = NPX + NPY;      // DMA instructions per thread and tile
+  constexpr int XB = NPX * 4096, YB = 128 * 64, BUF = XB + YB;      // (every thread moves NPX pieces: the image is padded to whole rounds)
+  constexpr uint32_t DEAD = 0x80000000u;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ci_t = blockIdx.y / a.coT, co_t = blockIdx.y % a.coT;
+  const int cin = a.cin, cout = a.cout;
+  // staging plan (the same for every tile)
+  uint32_t vx[NPX], vy[NPY];
+#pragma unroll
+  for (int k = 0; k < NPX; ++k) {
+    const int it = tid + 256 * k;
+    const int row = it >> 2, sub = it & 3;
+    const int p = row / RP, rr = row - p * RP;
+    const int hh = rr / (W + 2), hw = rr - hh * (W + 2);
+    const bool in = row < XROWS && hh >= 1 && hh <= H && hw >= 1 && hw <= W;
+    vx[k] = in ? (uint32_t)((((p * H + hh - 1) * W + hw - 1) * cin + ci_t * 32 + sub * 8) * 2) : DEAD;
+  }
+#pragma unroll
+  for (int k = 0; k < NPY; ++k) {
+    const int it = tid + 256 * k;
+    vy[k] = (uint32_t)(((it >> 2) * cout + co_t * 32 + (it & 3) * 8) * 2);
+  }
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)((int64_t)a.ntiles * 128 * cin * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, (int)((int64_t)a.ntiles * 128 * cout * 2), 0x00020000);
+  auto stage = [&](int t, int b) __attribute__((always_inline)) {      // tile t into ring buffer b; t beyond the list: zeros, same instruction count
+    const bool ok = t < a.ntiles;
+    const uint32_t sx = ok ? (uint32_t)t * (uint32_t)(128 * cin * 2) : 0u, sy = ok ? (uint32_t)t * (uint32_t)(128 * cout * 2) : 0u;
+    char* xb = smem + b * BUF;
+#pragma unroll
+    for (int k = 0; k < NPX; ++k)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(xb + (tid + 256 * k) * 16 - lane * 16), 16, ok ? vx[k] : DEAD, sx, 0, 0);
+#pragma unroll
+    for (int k = 0; k < NPY; ++k)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_ptr_t)(xb + XB + (tid + 256 * k) * 16 - lane * 16), 16, ok ? vy[k] : DEAD, sy, 0, 0);
+  };
+  // transposing-read lane map (as in the kernels above): 16-lane group = 4 voxel rows x 16 channels
+  const int i16 = lane & 15, q16 = lane >> 4;
+  const int colb = (16 * (q16 & 1) + 4 * (i16 & 3)) * 2;
+  const int kb = 8 * (q16 >> 1) + (i16 >> 2);
+  // Waves 0..2 own one kernel row each (three taps, all eight K steps of a tile); wave 3 multiplies dy by ones (the bias
+  // gradient) in the ci_t == 0 blocks.  (Splitting the K steps over four waves instead was measured first: every wave then
+  // adds all nine tiles to the workspace, 4 x the atomics, and the launch took 81 us where this layout's MFMAs take 8.)
+  int xr[2], yr[2];            // rows m0 / m0 + 4 of K step 0: byte offsets inside a buffer; K step ks adds a compile-time term
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int m = kb + 4 * j;                                    // < 16: inside plane 0
+    xr[j] = ((m / W + (wave < 3 ? wave : 0)) * (W + 2) + m % W) * 64 + colb;      // halo row of tap (kh = wave, kw = 0)
+    yr[j] = XB + m * 64 + colb;
+  }
+  const bool ones = wave == 3 && a.dbias != nullptr && ci_t == 0;
+  f32x16 acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+  const u32x4 one8 = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};      // bf16 1.0 x 8
+
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4_p;
+  const int t0 = blockIdx.x, G = gridDim.x;
+  stage(t0, 0);
+  stage(t0 + G, 1);
+  int b = 0;
+  for (int t = t0; t < a.ntiles; t += G) {
+    const int b2 = b >= 1 ? b - 1 : 2;                         // (b + 2) % 3
+    stage(t + 2 * G, b2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");     // tile t has landed (the two younger tiles may still fly)
+    __syncthreads();
+    const char* base = smem + b * BUF;
+    if (wave < 3 || ones) {                                     // (uniform per wave)
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        // 16 voxels further on: two rows of an 8 x 8 plane (a new plane every four steps) / one whole 4 x 4 plane
+        const int xoff = H == 8 ? ((ks >> 2) * RP + (ks & 3) * 2 * (W + 2)) * 64 : ks * RP * 64;
+        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(base + yr[0] + ks * 1024));
+        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(base + yr[1] + ks * 1024));
+        u32x4 bf;
+        bf[0] = __builtin_bit_cast(u32x2, b0)[0]; bf[1] = __builtin_bit_cast(u32x2, b0)[1];
+        bf[2] = __builtin_bit_cast(u32x2, b1)[0]; bf[3] = __builtin_bit_cast(u32x2, b1)[1];
+        if (wave < 3) {
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(base + xr[0] + xoff + kw * 64));
+            const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_p)(base + xr[1] + xoff + kw * 64));
+            u32x4 af;
+            af[0] = __builtin_bit_cast(u32x2, a0)[0]; af[1] = __builtin_bit_cast(u32x2, a0)[1];
+            af[2] = __builtin_bit_cast(u32x2, a1)[0]; af[3] = __builtin_bit_cast(u32x2, a1)[1];
+            acc[kw] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc[kw], 0, 0, 0);
+          }
+        } else {
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, one8), __builtin_bit_cast(bf16x8, bf), acc[0], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();                                             // buffer b is free for the tile three further on
+    b = b == 2 ? 0 : b + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // (the zero-fill DMAs of the tail have landed before the block ends)
+  const int r = lane & 31, hh = lane >> 5;
+  const bool slab = a.slab != 0;
+  if (wave < 3) {
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      float* dst = a.dwt + (int64_t)blockIdx.x * a.slab + ((((int64_t)(wave * 3 + kw) * a.ciT + ci_t) * a.coT + co_t) << 10);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+        sg_wg_out(dst + row * 32 + r, acc[kw][i], slab);
+      }
+    }
+  } else if (ones && hh == 0) {                                  // row 0 of the ones product = the column sums of dy
+    sg_wg_out(a.dbias + (int64_t)blockIdx.x * a.bslab + co_t * 32 + r, acc[0][0], slab);
+  }
+}
+
+// (plain kernels around a templated body: as a kernel TEMPLATE the host pass of this file under -save-temps left the stubs as
+// comdat declarations and aborted with "Broken module found")
+__global__ __launch_bounds__(256, 2) void conv_wgrad_planes8_kernel(WgradPlanesArgs a) { conv_wgrad_planes_body<8>(a); }
+__global__ __launch_bounds__(256, 2) void conv_wgrad_planes4_kernel(WgradPlanesArgs a) { conv_wgrad_planes_body<4>(a); }
+
+static bool wgrad_planes_eligible(const sg_conv_shape* s) {
+  if (s->kd != 1 || s->kh != 3 || s->kw != 3 || s->upsample_in || s->h != s->w || (s->h != 4 && s->h != 8)) return false;
+  if ((s->cin % 32) || (s->cout % 32)) return false;
+  const int P = 128 / (s->h * s->w);
+  const int64_t planes = (int64_t)s->n * s->d;
+  if (planes % P) return false;
+  const int64_t vox = planes * s->h * s->w;
+  return vox * (s->cin > s->cout ? s->cin : s->cout) * 2 < (1ll << 31);
+}
+
+static int launch_wgrad_planes(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used) {
+  *used = false;
+  if (!wgrad_planes_eligible(s)) return SG_OK;
+  WgradPlanesArgs p;
+  p.x = a.x; p.dy = a.dy; p.dwt = a.dwt; p.dbias = a.dbias; p.cin = s->cin; p.cout = s->cout; p.ciT = a.ciT; p.coT = a.coT;
+  p.ntiles = (int)((int64_t)s->n * s->d * s->h * s->w / 128);
+  p.slab = a.slab; p.bslab = a.bslab;
+  const int pairs = a.ciT * a.coT;
+  int gx = sg_cdiv(512, pairs);                // two blocks per CU over all pairs
+  if (gx > 16) gx = 16;                        // (one slab per block: stays within wgrad_slab_count)
+  if (gx > p.ntiles) gx = p.ntiles;
+  a.nslab = gx;
+  if (s->h == 8) {
+    auto kern = conv_wgrad_planes8_kernel;
+    SG_ALLOW_160K_LDS(kern);
+    SG_KNAME("conv_wgrad_planes<8>");
+    constexpr int XB = ((2 * 100 * 4 + 255) / 256) * 4096;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(256), 3 * (size_t)(XB + 8192), st, p);
+  } else {
+    auto kern = conv_wgrad_planes4_kernel;
+    SG_ALLOW_160K_LDS(kern);
+    SG_KNAME("conv_wgrad_planes<4>");
+    constexpr int XB = ((8 * 36 * 4 + 255) / 256) * 4096;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(256), 3 * (size_t)(XB + 8192), st, p);
+  }
+  SG_LAUNCH_CHECK();
+  *used = true;
+  return SG_OK;
+}
+
 static size_t wgrad_tile_bytes(const sg_conv_shape* s) {
   const size_t need = (size_t)(s->kd * s->kh * s->kw) * sg_cdiv(s->cin, 32) * sg_cdiv(s->cout, 32) * 4096;
   const size_t pw = (size_t)1024 * 5 * (size_t)(s->cin > s->cout ? s->cin : s->cout) * sizeof(float);
@@ -1450,6 +1633,11 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
     db_done = used;   // the sliding-halo kernel accumulates the bias gradient in its spare tap slot
   }
   if (dy_mask && rc == SG_OK && !used) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }   // only that kernel gathers dy
+  if (rc == SG_OK && !used && dt == SG_BF16 && !sg_cfg().wgrad_v1 && !sg_cfg().no_gemm)
+  {
+    rc = launch_wgrad_planes(a, s, hs, &used);      // 1x3x3 layers of the 4^2 / 8^2 levels: whole-plane tiles through an LDS ring
+    if (used) db_done = true;                       // (its fourth wave sums dy)
+  }
   if (rc == SG_OK && !used && dt == SG_BF16 && !sg_cfg().wgrad_v1) {
     if (s->kd == 3 && s->kh == 3 && s->kw == 3) rc = launch_wgrad2<3, 3, 3>(a, s, hs, &used);
     else if (s->kd == 1 && s->kh == 3 && s->kw == 3) rc = launch_wgrad2<1, 3, 3>(a, s, hs, &used);

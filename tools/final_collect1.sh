@@ -10,3 +10,5 @@ run 500 python bench.py --dump-prof > $O/bench_default.json 2> $O/bench_conv_tab
 for c in 1 2 4 5; do
   run 300 python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_config$c.json 2> $O/bench_config$c.err; echo "config $c rc=$?"; tail -c 400 $O/bench_config$c.json
 done
+# the N > 1 launcher rehearsed on this one-GPU box: two ranks stacked on the card, gloo collectives, a small batch
+SARAGAN_BENCH_STACK_RANKS=1 SARAGAN_DIST_BACKEND=gloo run 400 python bench.py --gpus 2 --steps 3 --warmup 2 --batch 8 --no-extras --no-cpu-baseline > $O/bench_gloo2.json 2> $O/bench_gloo2.err; echo "gloo2 rc=$?"; tail -c 600 $O/bench_gloo2.json

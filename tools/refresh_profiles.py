@@ -116,7 +116,10 @@ def main():
                          stdout=open(os.path.join(DST, TAG + 'pmc_traffic.txt'), 'w'))
     print('pmc_summary rc', rc)
     sq_wait_summary()
-    for rep in ('loss_curve_report_wgan.json', 'loss_curve_report_logistic_mix.json'):
+    line = last_json_line(os.path.join(SRC, 'bench_gloo2.json')) if os.path.exists(os.path.join(SRC, 'bench_gloo2.json')) else None
+    if line:      # the launcher's own smoke: two ranks stacked on the one GPU of the box, gloo collectives (NOT a scaling number)
+        open(os.path.join(DST, TAG + 'bench_gloo_rehearsal.json'), 'w').write(line + '\n')
+    for rep in ('loss_curve_report_wgan.json', 'loss_curve_report_logistic_mix.json', 'loss_curve_report_cfg3.json'):
         s = os.path.join(ROOT, 'gpurun_out', rep)
         if os.path.exists(s):
             shutil.copyfile(s, os.path.join(DST, TAG + rep))

@@ -585,8 +585,15 @@ __global__ __launch_bounds__(512) void upconv_subpixel_dgrad_kernel(SubpixDgradA
     *reinterpret_cast<u32x4*>(dst + 8192 + tid * 16) = srcr[1];
   };
 
-  const int64_t t_first = blockIdx.x;
-  const int64_t ntl = t_first < a.ntiles ? (a.ntiles - t_first + gridDim.x - 1) / gridDim.x : 0;   // my tiles
+  // Tile schedule: XCD x (= blockIdx.x % 8: consecutive block ids go round the 8 XCDs) owns a CONTIGUOUS eighth of the tile
+  // list and its blocks walk it side by side, so the halo rows neighbouring tiles share are fetched into one L2 within a
+  // few microseconds.  (Dealt round-robin over all blocks, neighbours sat on different XCDs and every shared row came from
+  // HBM again: FETCH_SIZE 2.6-4.7x the algorithmic bytes, profiles/r03_pmc_traffic.txt.)  gridDim.x is a multiple of 8.
+  const int64_t per_x = gridDim.x >> 3;                        // blocks per XCD = the stride inside its chunk
+  const int64_t cpx = (a.ntiles + 7) >> 3;
+  const int64_t c_begin = (blockIdx.x & 7) * cpx, c_end = c_begin + cpx < a.ntiles ? c_begin + cpx : a.ntiles;
+  const int64_t t_first = c_begin + (blockIdx.x >> 3);
+  const int64_t ntl = t_first < c_end ? (c_end - t_first + per_x - 1) / per_x : 0;   // my tiles
   if (ntl == 0) return;
   const int nchunk = a.nchunk;
   f32x16 acc[NT];
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(512) void upconv_subpixel_dgrad_kernel(SubpixDgradA
     const bool more = nti < ntl;
     const int od0 = d0, oh0 = h0, ow0 = w0, on0 = n0;     // this item's tile origin (the epilogue needs it after the plan moved on)
     if (more) {
-      if (nchunk_i == 0) { enter_tile(t_first + nti * gridDim.x); plan_tile(); }
+      if (nchunk_i == 0) { enter_tile(t_first + nti * per_x); plan_tile(); }
       load_y(nchunk_i);
     }
     if (chunk == 0) {
@@ -749,8 +756,9 @@ extern "C" int sg_upconv3d_subpixel_dgrad(const void* gy, const void* wp, void* 
   full.d *= 2; full.h *= 2; full.w *= 2; full.kd = full.kh = full.kw = 3; full.upsample_in = 0;
   full.cin = s->cout; full.cout = s->cin;
   sg_prof_scope prof(0, &full, dt, sg_st(st));
-  const int64_t per_part = 256 / (s->cin / 64) > 8 ? 256 / (s->cin / 64) : 8;
-  const unsigned gx_ = (unsigned)(a.ntiles < per_part ? a.ntiles : per_part);
+  int64_t per_part = 256 / (s->cin / 64) > 8 ? 256 / (s->cin / 64) : 8;
+  while (per_part > 8 && per_part > a.ntiles) per_part -= 8;      // whole rounds of the 8 XCDs, at most one block per tile
+  const unsigned gx_ = (unsigned)per_part;
   const size_t lds = 2 * (size_t)kDgW + (size_t)kDgY;
   const int nt = s->cin / 32;
   SG_KNAME("upconv_subpixel_dgrad");

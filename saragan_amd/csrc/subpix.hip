@@ -503,6 +503,18 @@ constexpr int kDgW = 16 * 1024;           // one weight group: 16 fragments
 constexpr int kDgY = 6 * 10 * 2 * 33 * 32; // largest halo image (tile 2 x 4 x 32): 126720 bytes
 }  // namespace
 
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N - 1>)
+template <int N, int I = 0>
+struct sg_static_for {
+  template <class F>
+  static __device__ __forceinline__ void run(F&& f) {
+    if constexpr (I < N) {
+      f(std::integral_constant<int, I>{});
+      sg_static_for<N, I + 1>::run(f);
+    }
+  }
+};
+
 template <int NT, int TD, int TH, int TW>
 __global__ __launch_bounds__(512) void upconv_subpixel_dgrad_kernel(SubpixDgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -564,6 +576,18 @@ __global__ __launch_bounds__(512) void upconv_subpixel_dgrad_kernel(SubpixDgradA
 #pragma unroll
     for (int k = 0; k < NK; ++k) gr[k] = __builtin_amdgcn_raw_buffer_load_b128(ry, yv[k], (uint32_t)chunk * 32u, 0);
   };
+  // The next item's halo is requested a few pieces per weight group, not all at the item's start: vmcnt retires in order,
+  // so a weight group requested AFTER the halo can only be waited for once the whole halo has landed -- 124 KiB that the
+  // CU takes in ~5 us where the weights are needed 3 groups (~2 us) later (seen in the first version: s_waitcnt at the end
+  // of group 0 held every wave until the halo was in).  The last two groups request nothing: their slack covers the latency
+  // of the final pieces before store_y.
+  constexpr int YPG = (NK + (NG > 2 ? NG - 2 : 1) - 1) / (NG > 2 ? NG - 2 : 1);      // halo pieces per group
+  auto load_y_part = [&](int chunk, bool ok, auto GG) __attribute__((always_inline)) {
+    constexpr int g = decltype(GG)::value;
+#pragma unroll
+    for (int k = g * YPG; k < (g + 1) * YPG && k < NK; ++k)
+      gr[k] = __builtin_amdgcn_raw_buffer_load_b128(ry, ok ? yv[k] : DEAD, (uint32_t)chunk * 32u, 0);
+  };
   auto store_y = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
@@ -619,28 +643,28 @@ __global__ __launch_bounds__(512) void upconv_subpixel_dgrad_kernel(SubpixDgradA
     if (nchunk_i == nchunk) { nchunk_i = 0; ++nti; }
     const bool more = nti < ntl;
     const int od0 = d0, oh0 = h0, ow0 = w0, on0 = n0;     // this item's tile origin (the epilogue needs it after the plan moved on)
-    if (more) {
-      if (nchunk_i == 0) { enter_tile(t_first + nti * per_x); plan_tile(); }
-      load_y(nchunk_i);
-    }
+    if (more && nchunk_i == 0) { enter_tile(t_first + nti * per_x); plan_tile(); }
     if (chunk == 0) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
     }
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
+    sg_static_for<NG>::run([&](auto GG) __attribute__((always_inline)) {
+      constexpr int g = decltype(GG)::value;
       // group g + 4 into the ring slot group g came from (groups beyond this chunk belong to the next item's chunk)
       {
         const int g4 = g + 4;
         const int c4 = g4 < NG ? chunk : nchunk_i;
         load_w(wr[g & 3], c4, g4 % NG);
       }
+      load_y_part(nchunk_i, more, GG);      // (unconditional: dead offsets when nothing follows)
       const char* ws = wbuf + (g & 1) * kDgW;
       // fragments one tap ahead of the MFMAs that use them (left to the scheduler, the unrolled group hoists all 24 reads:
       // 96 registers on top of the 64 of the halo in flight)
-      u32x4 xf[2], wf[2][NT];
+      constexpr int FD_ = 3;              // fragment ring: reads run FD_ - 1 taps ahead of the MFMAs (one tap = 2 MFMAs = 64 cycles: one tap
+                                          // ahead did not cover the LDS latency under load, the group took 2.6 x its MFMA time)
+      u32x4 xf[FD_], wf[FD_][NT];
       auto read_tap = [&](int slot, int tt) __attribute__((always_inline)) {
         const int tap = g * TPG + tt;
         const int td = tap >> 4, th = (tap >> 2) & 3, tw = tap & 3;
@@ -649,26 +673,27 @@ __global__ __launch_bounds__(512) void upconv_subpixel_dgrad_kernel(SubpixDgradA
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) wf[slot][nt] = *reinterpret_cast<const u32x4*>(ws + ((tt * NT + nt) << 10) + lane * 16);
       };
-      read_tap(0, 0);
+#pragma unroll
+      for (int tt = 0; tt < FD_ - 1 && tt < TPG; ++tt) read_tap(tt, tt);
 #pragma unroll
       for (int tt = 0; tt < TPG; ++tt) {
-        if (tt + 1 < TPG) read_tap((tt + 1) & 1, tt + 1);
+        if (tt + FD_ - 1 < TPG) read_tap((tt + FD_ - 1) % FD_, tt + FD_ - 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[nt] = sg_mfma_chunk<bf16_t>(wf[tt & 1][nt], xf[tt & 1], acc[nt]);
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = sg_mfma_chunk<bf16_t>(wf[tt % FD_][nt], xf[tt % FD_], acc[nt]);
         __builtin_amdgcn_sched_barrier(0);
       }
       store_w(wr[(g + 1) & 3], wbuf + ((g + 1) & 1) * kDgW);
       __syncthreads();
-    }
+    });
     if (chunk + 1 == nchunk) {      // the tile is complete: one rounding, 64 contiguous bytes per lane pair and channel tile
       const int64_t ov = (((int64_t)on0 * a.d + od0 + vd) * a.h + oh0 + vh) * a.w + ow0 + vw;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) sg_store_tile_row_bf16(a.gx + ov * a.ci + (cpart * NT + nt) * 32, acc[nt], hh, true);
     }
-    if (!more) break;
-    store_y();
+    store_y();      // (unconditional, like its loads: after the last item it writes zeros nobody reads)
     __syncthreads();
+    if (!more) break;
     ti = nti;
     chunk = nchunk_i;
   }

@@ -201,6 +201,195 @@ __global__ __launch_bounds__(512) void upconv_subpixel_fwd_kernel(SubpixArgs a) 
   }
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N - 1>)
+template <int N, int I = 0>
+struct sg_static_for {
+  template <class F>
+  static __device__ __forceinline__ void run(F&& f) {
+    if constexpr (I < N) {
+      f(std::integral_constant<int, I>{});
+      sg_static_for<N, I + 1>::run(f);
+    }
+  }
+};
+
+// Persistent form of the kernel above (same tile, same arithmetic, same epilogue).  The one-tile-per-block version waits
+// twice per chunk for weights it asked for one half-chunk (~0.7 us) earlier -- L2 latency under load is 1-2 us -- and pays
+// its prologue per tile: 28 us per tile where its LDS fill needs 14 and its MFMAs 11.  Here a block walks items (tile, chunk);
+// the summed weights come in four 16-KiB groups per chunk -- (D parity a, D tap tz): 4 classes x 4 taps, 16 MFMAs per wave --
+// through two LDS buffers from a register ring that is loaded ONE CHUNK ahead; the next item's halo is requested one piece
+// per group (vmcnt retires in order: see the data-gradient kernel) into the other halo buffer.
+__global__ __launch_bounds__(512) void upconv_subpixel_fwd3_kernel(SubpixArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int kWG = 16 * 1024;
+  constexpr uint32_t DEAD = 0x80000000u;
+  char* const wbuf = smem;                       // 2 weight-group buffers
+  char* const xbuf = smem + 2 * kWG;             // 2 halo buffers
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const int nt = blockIdx.y;
+  const int rowB = a.HW * 32, planeB = a.HH * rowB;
+  const int q = wave * 32 + r;
+  const int vw = q % a.TW, vh = (q / a.TW) % a.TH, vd = q / (a.TW * a.TH);
+  // halo rows are 32 bytes (16 channels); the 16-byte slot of a row is half ^ (w position >> 3 & 1): conflict-free b128 reads
+  // for 32 consecutive positions (the un-swizzled image of the kernel above: SQ_LDS_BANK_CONFLICT = 22 % of its LDS cycles)
+  const int xrow = (vd * a.HH + vh) * rowB + vw * 32;
+  int xsw[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) xsw[dx] = dx * 32 + ((hh ^ (((vw + dx) >> 3) & 1)) << 4);
+  int xdst[4];                // LDS byte offset of my halo pieces (the same for every tile)
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = tid + k * 512;
+    const int hvx = p >> 1, half = p & 1;
+    xdst[k] = hvx * 32 + ((half ^ (((hvx % a.HW) >> 3) & 1)) << 4);
+  }
+  const int64_t xsb = (int64_t)a.d * a.h * a.w * a.cin * 2;      // bytes of one sample of x (< 2 GiB, host-checked)
+  // tile schedule: XCD x owns a contiguous eighth of the tile list (neighbouring tiles share halo rows in one L2)
+  const int64_t ntiles = (int64_t)a.N * a.nTd * a.nTh * a.nTw;
+  const int64_t per_x = gridDim.x >> 3, cpx = (ntiles + 7) >> 3;
+  const int64_t c_begin = (blockIdx.x & 7) * cpx, c_end = c_begin + cpx < ntiles ? c_begin + cpx : ntiles;
+  const int64_t t_first = c_begin + (blockIdx.x >> 3);
+  const int64_t ntl = t_first < c_end ? (c_end - t_first + per_x - 1) / per_x : 0;
+  if (ntl == 0) return;
+  const int nchunk = a.nchunk;
+
+  int d0 = 0, h0 = 0, w0 = 0, n0 = 0;
+  __amdgpu_buffer_rsrc_t rx;
+  uint32_t xv[4];             // byte offsets of my four halo pieces inside the sample (DEAD: outside the volume / no piece)
+  auto enter_tile = [&](int64_t t) __attribute__((always_inline)) {
+    w0 = (int)(t % a.nTw) * a.TW; t /= a.nTw;
+    h0 = (int)(t % a.nTh) * a.TH; t /= a.nTh;
+    d0 = (int)(t % a.nTd) * a.TD;
+    n0 = (int)(t / a.nTd);
+    rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.x)) + n0 * xsb, 0, (int)xsb, 0x00020000);
+    int tid_ = tid;
+    asm volatile("" : "+v"(tid_));      // (keeps the divisions below out of the item loop's live ranges)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = tid_ + k * 512;
+      const int hvx = p >> 1, half = p & 1;
+      const int hw_ = hvx % a.HW, hh_ = (hvx / a.HW) % a.HH, hd_ = hvx / (a.HW * a.HH);
+      const int dd = d0 + hd_ - 1, yy = h0 + hh_ - 1, ww = w0 + hw_ - 1;
+      const bool in = p < a.hv * 2 && dd >= 0 && dd < a.d && yy >= 0 && yy < a.h && ww >= 0 && ww < a.w;
+      xv[k] = in ? (uint32_t)(((((dd * a.h + yy) * a.w + ww) * a.cin) + half * 8) * 2) : DEAD;
+    }
+  };
+  u32x4 sx[4];
+  auto store_x = [&](char* dst) __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (tid + k * 512 < a.hv * 2) *reinterpret_cast<u32x4*>(dst + xdst[k]) = sx[k];
+  };
+  u32x4 wr[4][2];
+  auto load_w = [&](u32x4 (&dst)[2], int chunk, int g) __attribute__((always_inline)) {
+    const char* src = a.wp + 8 * a.class_stride + (((((int64_t)nt * nchunk + chunk) * 4 + g)) << 14) + tid * 16;
+    dst[0] = *reinterpret_cast<const u32x4*>(src);
+    dst[1] = *reinterpret_cast<const u32x4*>(src + 8192);
+  };
+  auto store_w = [&](const u32x4 (&srcr)[2], char* dst) __attribute__((always_inline)) {
+    *reinterpret_cast<u32x4*>(dst + tid * 16) = srcr[0];
+    *reinterpret_cast<u32x4*>(dst + 8192 + tid * 16) = srcr[1];
+  };
+
+  f32x16 acc[8];
+  // prologue: the first item's halo and weight group 0 into LDS, groups 1..3 into the ring
+  enter_tile(t_first);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sx[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, xv[k], 0u, 0);
+  load_w(wr[0], 0, 0);
+  load_w(wr[1], 0, 1);
+  load_w(wr[2], 0, 2);
+  load_w(wr[3], 0, 3);
+  store_x(xbuf);
+  store_w(wr[0], wbuf);
+  __syncthreads();
+
+  const int D2 = 2 * a.d, H2 = 2 * a.h, W2 = 2 * a.w;
+  const float inv_c = 1.f / (float)a.cout;
+  int64_t ti = 0;
+  int chunk = 0, xb = 0;
+  for (;;) {
+    int nchunk_i = chunk + 1;
+    int64_t nti = ti;
+    if (nchunk_i == nchunk) { nchunk_i = 0; ++nti; }
+    const bool more = nti < ntl;
+    const int od0 = d0, oh0 = h0, ow0 = w0, on0 = n0;
+    if (more && nchunk_i == 0) enter_tile(t_first + nti * per_x);
+    if (chunk == 0) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+    }
+    const char* xs = xbuf + xb * kXMax;
+    sg_static_for<4>::run([&](auto GG) __attribute__((always_inline)) {
+      constexpr int g = decltype(GG)::value, A = g >> 1, tz = g & 1;
+      load_w(wr[g], nchunk_i, g);                        // the same group of the next item: one chunk ahead
+      // the next item's halo: four pieces over the first three groups (none in the last: its slack covers their latency)
+      if (g < 3) sx[g] = __builtin_amdgcn_raw_buffer_load_b128(rx, more ? xv[g] : DEAD, (uint32_t)nchunk_i * 32u, 0);
+      if (g == 0) sx[3] = __builtin_amdgcn_raw_buffer_load_b128(rx, more ? xv[3] : DEAD, (uint32_t)nchunk_i * 32u, 0);
+      const char* ws = wbuf + (g & 1) * kWG;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const u32x4 xf = *reinterpret_cast<const u32x4*>(xs + xrow + (A + tz) * planeB + dy * rowB + xsw[dx]);
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            const int th = dy - b;
+            if (th < 0 || th > 1) continue;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+              const int tw = dx - c;
+              if (tw < 0 || tw > 1) continue;
+              const u32x4 wf = *reinterpret_cast<const u32x4*>(ws + ((((b * 2 + c) * 4 + th * 2 + tw)) << 10) + lane * 16);
+              acc[A * 4 + b * 2 + c] = sg_mfma_chunk<bf16_t>(wf, xf, acc[A * 4 + b * 2 + c]);
+            }
+          }
+        }
+      store_w(wr[(g + 1) & 3], wbuf + ((g + 1) & 1) * kWG);      // (g == 3: group 0 of the next item, requested at step 0)
+      if (g == 3) store_x(xbuf + (xb ^ 1) * kXMax);
+      __syncthreads();
+    });
+    if (chunk + 1 == nchunk) {      // epilogue: class (a_, b, c) of my voxel -> fine voxel (2d+a_, 2h+b, 2w+c)
+      float bv[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) bv[i] = a.bias ? a.bias[nt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh] : 0.f;
+#pragma unroll
+      for (int cls = 0; cls < 8; ++cls) {
+        const int ca = cls >> 2, cb = (cls >> 1) & 1, cc = cls & 1;
+        const int64_t ov = (((int64_t)on0 * D2 + 2 * (od0 + vd) + ca) * H2 + 2 * (oh0 + vh) + cb) * W2 + 2 * (ow0 + vw) + cc;
+        f32x16 v = acc[cls];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float e = v[i] + bv[i];
+          if (a.act) e = sg_lrelu(e, a.slope);
+          v[i] = e;
+          ss += e * e;
+        }
+        if (a.pixel_norm) {      // (cout == 32: the lane pair (r, r + 32) holds the voxel's channels)
+          ss += __shfl_xor(ss, 32);
+          const float sc = rsqrtf(ss * inv_c + a.eps);
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] *= sc;
+          if (a.pn_scale && hh == 0) a.pn_scale[ov] = sc;
+        }
+        if (a.sign_out) {
+          const uint32_t sw_ = sg_sign_word(v, hh);
+          if (hh == 0) a.sign_out[ov * a.ntile + nt] = sw_;
+        }
+        sg_store_tile_row_bf16(a.y + ov * a.cout + nt * 32, v, hh, true);
+      }
+    }
+    if (!more) break;
+    ti = nti;
+    chunk = nchunk_i;
+    xb ^= 1;
+  }
+}
+
 // The same for 64 output channels with pixel-norm in the epilogue: a voxel's channels span two N tiles, which must meet in
 // one wave.  Eight classes x two tiles would be 256 accumulator registers, so the block runs the four classes of one D
 // parity at a time (accumulator tile = nt * 4 + class), through all chunks, writes them, then the other parity: the halo
@@ -381,6 +570,11 @@ __global__ void upconv_subpixel_pack_kernel(SubpixPackArgs a) {
       v *= a.coef;
     }
     reinterpret_cast<bf16_t*>(a.wp + (int64_t)cls * a.class_stride)[i % per_class] = (bf16_t)v;
+    // second copy in the order the persistent forward kernel streams it: [ntile][chunk][group = (a, tz)][class (b, c)][tap (th, tw)]
+    // -- 16 fragments = 16 KiB per group, contiguous
+    const int grp = (cls >> 2) * 2 + (tap >> 2), f = (cls & 3) * 4 + (tap & 3);
+    const int64_t gi = ((((int64_t)nt * a.nchunk + chunk) * 4 + grp) * 16 + f) * 512 + lane * 8 + e;
+    reinterpret_cast<bf16_t*>(a.wp + 8 * a.class_stride)[gi] = (bf16_t)v;
   }
 }
 
@@ -406,7 +600,7 @@ static bool subpix_tile(const sg_conv_shape* s, int* td, int* th, int* tw) {
 // s: the LOW-resolution shape (n, d, h, w, cin, cout); kd = kh = kw = 3 of the original convolution
 extern "C" size_t sg_upconv3d_subpixel_packed_bytes(const sg_conv_shape* s, sg_dtype dt) {
   if (!s || dt != SG_BF16 || s->cin < 1 || s->cout < 1) return 0;
-  return (size_t)8 * sg_cdiv(s->cin, 16) * 8 * sg_cdiv(s->cout, 32) * 1024;
+  return (size_t)2 * 8 * sg_cdiv(s->cin, 16) * 8 * sg_cdiv(s->cout, 32) * 1024;      // class-major image + the same in group order
 }
 
 extern "C" int sg_upconv3d_subpixel_supported(const sg_conv_shape* s, sg_dtype dt) {
@@ -464,11 +658,19 @@ extern "C" int sg_upconv3d_subpixel_fwd(const void* x, const void* wp, void* y, 
     SG_ALLOW_160K_LDS(kern);
     SG_KNAME("upconv_subpixel_fwd<2 N tiles>");
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(512), lds, sg_st(st), a);
-  } else {
+  } else if ((sg_cfg().dbg_flags & 64) || (int64_t)s->d * s->h * s->w * s->cin * 2 >= (1ll << 31)) {
+    // (diagnostic switch, or a sample of x beyond a buffer resource: the one-tile-per-block version)
     auto kern = upconv_subpixel_fwd_kernel;
     SG_ALLOW_160K_LDS(kern);
-    SG_KNAME("upconv_subpixel_fwd");
+    SG_KNAME("upconv_subpixel_fwd<one tile per block>");
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)a.ntile), dim3(512), lds, sg_st(st), a);
+  } else {
+    auto kern = upconv_subpixel_fwd3_kernel;
+    SG_ALLOW_160K_LDS(kern);
+    SG_KNAME("upconv_subpixel_fwd");
+    int64_t gx = 256 / a.ntile > 8 ? (256 / a.ntile) / 8 * 8 : 8;      // whole rounds of the 8 XCDs, at most one block per tile
+    while (gx > 8 && gx > tiles) gx -= 8;
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)a.ntile), dim3(512), 2 * (size_t)(16 * 1024) + 2 * (size_t)kXMax, sg_st(st), a);
   }
   hipError_t e = hipGetLastError();
   prof.done((int)e);
@@ -502,18 +704,6 @@ namespace {
 constexpr int kDgW = 16 * 1024;           // one weight group: 16 fragments
 constexpr int kDgY = 6 * 10 * 2 * 33 * 32; // largest halo image (tile 2 x 4 x 32): 126720 bytes
 }  // namespace
-
-// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(<N - 1>)
-template <int N, int I = 0>
-struct sg_static_for {
-  template <class F>
-  static __device__ __forceinline__ void run(F&& f) {
-    if constexpr (I < N) {
-      f(std::integral_constant<int, I>{});
-      sg_static_for<N, I + 1>::run(f);
-    }
-  }
-};
 
 template <int NT, int TD, int TH, int TW>
 __global__ __launch_bounds__(512) void upconv_subpixel_dgrad_kernel(SubpixDgradArgs a) {

@@ -703,6 +703,41 @@ def test_conv_epilogue_fused_downscale(monkeypatch):
     _mostly_close(resg[2], gb_ref, 1e-3, 1e-3, 'db (gather vs one launch)')
 
 
+@pytest.mark.parametrize('n,sp', [(4, (6, 126, 256)), (2, (4, 252, 256)), (6, (10, 60, 288))])
+def test_pooled_backward_gather_on_ragged_volumes(n, sp):
+    """The fused masked gather of D's pooled backward (sg_conv_epilogue.in_mask_bits, sg_conv3d_wgrad_bias_up_masked) on
+    volumes whose H is not a multiple of the 4-row tile and whose D gives an odd number of tile steps, with and without the
+    input's own LeakyReLU mask in the epilogue: bit-identical data gradient, weight / bias gradient to f32 summation order,
+    against the materialised masked up-scale followed by the plain kernels."""
+    from saragan_amd import functional as F
+    dtype = torch.bfloat16
+    d, h, w_ = sp
+    x = cl(rnd((n, 32, d, h, w_), 81, dtype), dtype)
+    gy = cl(rnd((n, 64, d // 2, h // 2, w_ // 2), 82, dtype), dtype)
+    wg = rnd((3, 3, 3, 32, 64), 83, torch.float32).to(dev())
+    signs = F.sign_words(cl(rnd((n, 64, d, h, w_), 84, dtype), dtype))
+    coef = 0.043
+    for masked in (False, True):
+        info = None
+        if masked:
+            info = F.ActInfo(0.2)
+            info.bits = F.sign_words(cl(rnd((n, 32, d, h, w_), 85, dtype), dtype))
+            info.consume(True)
+        with torch.no_grad():
+            res = F._pooled_backward_gather(gy, x, wg, signs, coef, 0.2, info, True, True, True)
+            if res is None:
+                pytest.fail('the library declined a shape the gather was written for')
+            g_full = F._Up.apply(gy, 0.125, signs, 0.2, (2, 2, 2))
+            if masked:
+                gx_ref = F._Conv.apply(g_full, wg, coef, True, False, None, info.bits, info.slope)
+            else:
+                gx_ref = F._Conv.apply(g_full, wg, coef, True, False)
+            gw_ref, gb_ref = F.raw_wgrad(x, g_full, (3, 3, 3), coef, False, True)
+        assert torch.equal(res[0], gx_ref), ('data gradient', masked)
+        _mostly_close(res[1], gw_ref.reshape(res[1].shape), 1e-3, 1e-3, 'dw (gather, ragged)')
+        _mostly_close(res[2], gb_ref, 1e-3, 1e-3, 'db (gather, ragged)')
+
+
 @pytest.mark.parametrize('dtype', DT)
 @pytest.mark.parametrize('shape,factors', [((2, 40, 4, 6, 8), (2, 2, 2)), ((1, 8, 2, 4, 6), (1, 2, 2)), ((2, 33, 4, 4, 4), (2, 1, 2))])
 def test_masked_block_sum_is_the_gradient_of_the_masked_upscale(shape, factors, dtype):

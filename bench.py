@@ -405,9 +405,6 @@ def main():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     device = torch.device('cuda', local % max(1, torch.cuda.device_count()))   # (rehearsals may stack ranks on one GPU)
     torch.cuda.set_device(device)
-    if os.environ.get('SARAGAN_ARENA_GB'):      # experiment: one large allocation up front, carved up by torch's caching allocator
-        arena = torch.empty(int(float(os.environ['SARAGAN_ARENA_GB']) * (1 << 30)), dtype=torch.uint8, device=device)
-        del arena
     comm = parallel.collective_info() if world > 1 else None     # backend, RCCL version, communicator size, bucket algorithm
     cfg = build(args, device, args.dtype)
     sess, ph = cfg['sess'], cfg['ph']

@@ -378,6 +378,37 @@ def test_upconv_subpixel_data_gradient(case, monkeypatch):
     assert err2 <= 1e-2, err2
 
 
+def test_subpixel_kernels_are_mutually_adjoint_at_the_benchmarked_size():
+    """Size-independent properties at the size the bench runs (batch 32, 64 -> 32 channels, 16x64x64 -> 32x128x128), where
+    the oracle cannot follow: the sub-pixel forward F (no bias, no activation), its data gradient D and its weight
+    gradient W are three views of one bilinear form, so <F(x; w), g> = <x, D(g; w)> = <w, W(x, g)>.  F and D multiply with
+    the same rounded summed weights (their identity holds to the bf16 rounding of the outputs); W does not see the weights
+    (its identity holds to the rounding of the summed weights, 2^-9 relative each)."""
+    from saragan_amd import functional as F
+    n, cin, cout, sp = 32, 64, 32, (16, 64, 64)
+    g_ = torch.Generator(device='cuda').manual_seed(91)
+    x = torch.randn((n, cin, *sp), generator=g_, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last_3d)
+    w = torch.randn((3, 3, 3, cin, cout), generator=g_, device='cuda')
+    coef = 0.024
+    with torch.no_grad():
+        res = F._raw_upconv_subpixel(x, w, coef, None, False, 0.0, False, 1e-8, False, False)
+        assert res is not None, 'the sub-pixel forward was not taken'
+        y = res[0]
+        # g = F(x) + noise: the form is then dominated by |F(x)|^2, far above what uncorrelated outputs would produce
+        gy = (y.float() + 0.25 * torch.randn(y.shape, generator=g_, device='cuda').contiguous(memory_format=torch.channels_last_3d)).bfloat16()
+        gy = gy.contiguous(memory_format=torch.channels_last_3d)
+        gx = F._upconv_dgrad_subpixel(gy, w, coef)
+        assert gx is not None, 'the sub-pixel data gradient was not taken'
+        dw, _ = F.raw_wgrad(x, gy, (3, 3, 3), coef, True, False)
+        a = float((y.double() * gy.double()).sum())
+        b = float((x.double() * gx.double()).sum())
+        c = float((w.double() * dw.double()).sum())          # dw = coef * sum x (x) gy, F multiplies with coef * w: <w, dw> = <F, g>
+        yy = float((y.double() * y.double()).sum())
+    assert np.isfinite([a, b, c]).all() and a > 0.9 * yy, (a, yy)
+    assert abs(a - b) <= 1e-3 * a, (a, b)
+    assert abs(a - c) <= 2e-3 * a, (a, c)
+
+
 SUBPIX_CASES = [
     # n, cin, cout, low-resolution (d, h, w), pixel_norm
     (2, 64, 32, (4, 8, 32), True),        # the 64 -> 32 layer's tile (2 x 4 x 32), pixel-norm in the epilogue
@@ -701,6 +732,33 @@ def test_conv_epilogue_fused_downscale(monkeypatch):
     assert torch.equal(resg[0], gx_ref), 'masked data gradient differs between the fused gather and the materialised gradient'
     _mostly_close(resg[1], gw_ref.reshape(resg[1].shape), 1e-3, 1e-3, 'dw (gather vs one launch)')
     _mostly_close(resg[2], gb_ref, 1e-3, 1e-3, 'db (gather vs one launch)')
+
+
+def test_pooled_backward_gather_equals_the_two_tensor_path_at_the_benchmarked_size():
+    """At the size the bench runs (batch 32, 32x128x128, the discriminator's 32 -> 64 layer): the fused masked gather against
+    the materialised two-tensor path -- bit-identical data gradient (with the input's LeakyReLU mask in the epilogue),
+    weight and bias gradient to f32 summation order."""
+    from saragan_amd import functional as F
+    n, d, h, w_ = 32, 32, 128, 128
+    g_ = torch.Generator(device='cuda').manual_seed(92)
+
+    def rn(shape):
+        return torch.randn(shape, generator=g_, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last_3d)
+    x, gy = rn((n, 32, d, h, w_)), rn((n, 64, d // 2, h // 2, w_ // 2))
+    wt = torch.randn((3, 3, 3, 32, 64), generator=g_, device='cuda') * 0.05
+    signs = F.sign_words(rn((n, 64, d, h, w_)))
+    info = F.ActInfo(0.2)
+    info.bits = F.sign_words(rn((n, 32, d, h, w_)))
+    info.consume(True)
+    with torch.no_grad():
+        rp = F._pooled_backward_planes(gy, x, wt, signs, 0.05, 0.2, info, True, True, True)
+        rg = F._pooled_backward_gather(gy, x, wt, signs, 0.05, 0.2, info, True, True, True)
+    assert rp is not None and rg is not None
+    assert torch.equal(rp[0], rg[0]), 'data gradient differs between the fused gather and the two-tensor path'
+    assert float((rp[1] - rg[1]).abs().max() / rp[1].abs().max()) <= 1e-4
+    assert float((rp[2] - rg[2]).abs().max() / rp[2].abs().max()) <= 1e-4
+    del rp, rg
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize('n,sp', [(4, (6, 126, 256)), (2, (4, 252, 256)), (6, (10, 60, 288))])

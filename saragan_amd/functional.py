@@ -720,6 +720,17 @@ class _ConvBiasActPool(torch.autograd.Function):
                                               _wants(ctx, 1, w.data_ptr()), want_db)
             if res is not None:
                 return res[0], res[1], (res[2] if want_db else None), None, None, None
+        if (torch.is_grad_enabled() and not _NO_GATHER_BWD and ctx.needs_input_grad[0] and not _wants(ctx, 1, w.data_ptr()) and
+                not want_db and gy.dtype == torch.bfloat16 and w.dim() == 5 and tuple(w.shape) == (3, 3, 3, 32, 64) and signs is not None and
+                not (_masked_in(ctx.in_info) and ctx.in_info.pn is not None)):
+            # the gradient penalty's first backward: only the data gradient is wanted, and it is differentiated again
+            masked = _masked_in(ctx.in_info)
+            try:
+                gx = _PooledDgradGather.apply(gy, w, signs, slope, coef, ctx.in_info.bits if masked else None,
+                                              ctx.in_info.slope if masked else 0.0)
+                return gx, None, None, None, None, None
+            except _GatherDeclined:
+                pass
         g = _Up.apply(gy, 0.125, signs, slope, (2, 2, 2))      # d(downscale3d) * LeakyReLU mask, full resolution
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
@@ -737,6 +748,84 @@ class _ConvBiasActPool(torch.autograd.Function):
 
 _NO_PLANES = bool(int(os.environ.get('SARAGAN_NO_PLANES', '0')))   # diagnostic: the 64-channel gradient as one tensor
 _NO_GATHER_BWD = bool(int(os.environ.get('SARAGAN_NO_GATHER_BWD', '0')))   # diagnostic: materialise the up-scaled gradient
+
+
+class _GatherDeclined(Exception):
+    """The library has no fused-gather tile for this launch (the caller takes the materialised path)."""
+
+
+def _gather_dgrad_launch(gy, w, signs, slope, coef, mask_bits, mask_slope):
+    """gx = [mask] conv'(M * upscale3d(gy) / 8) through sg_conv_epilogue.in_mask_bits (the two-pass 64 -> 32 path)."""
+    lib = _lib.load()
+    gy = ndhwc(gy)
+    n, cout, dc, hc, wc = _dims(gy)
+    d, h, wd = 2 * dc, 2 * hc, 2 * wc
+    dt, st = _dt(gy), _stream()
+    shp = _shape(n, d, h, wd, 64, 32, (3, 3, 3), True)
+    ws_bytes = lib.sg_conv3d_fwd_workspace(C.byref(shp), dt)
+    if not ws_bytes:
+        raise _GatherDeclined()
+    _check_signs(signs, n * d * h * wd, 64)
+    wp = _packed(w, coef, True, shp, dt, lib, st)
+    gx = _empty_like_shape(gy, 32, (d, h, wd))
+    ep = ConvEpilogue(None, 0, 0.0, 0, 1e-8, None, _ptr(mask_bits), float(mask_slope) if mask_bits is not None else 0.0, None)
+    if mask_bits is not None:
+        _check_signs(mask_bits, n * d * h * wd, 32)
+    ws = torch.empty(ws_bytes, device=gy.device, dtype=torch.uint8)
+    ep.workspace, ep.workspace_bytes = ws.data_ptr(), ws_bytes
+    ep.in_mask_bits, ep.in_mask_slope, ep.in_gain = signs.data_ptr(), float(slope), 0.125
+    rc = lib.sg_conv3d_fwd(_ptr(gy), _ptr(wp), _ptr(gx), C.byref(shp), C.byref(ep), dt, st)
+    if rc == _lib.SG_EUNSUPPORTED:
+        raise _GatherDeclined()
+    check(rc, 'sg_conv3d_fwd (masked gather)')
+    return gx
+
+
+class _PooledDgradGather(torch.autograd.Function):
+    """Data gradient of downscale3d(leaky_relu(conv3d(x) + b)) for x from the POOLED gradient gy, differentiable once more
+    (the gradient penalty's first backward, networks/loss.py:136-140): gx = [M_in *] conv'(M * upscale3d(gy) / 8), the masked
+    up-scale formed in the convolution's gather instead of being written (and kept for the double backward) as a tensor.
+    Backward: for gy, block_sum(M * conv(ggx)) / 8 -- the layer's own forward on the incoming gradient; for w, the weight
+    gradient of (ggx, M * upscale3d(gy) / 8), gathered the same way (sg_conv3d_wgrad_bias_up_masked)."""
+
+    @staticmethod
+    def forward(ctx, gy, w, signs, slope, coef, mask_bits, mask_slope):
+        _note_all(gy)
+        gx = _gather_dgrad_launch(gy, w, signs, slope, coef, mask_bits, mask_slope)
+        ctx.save_for_backward(gy, w, signs, mask_bits)
+        ctx.cfg = (float(slope), float(coef), float(mask_slope))
+        ctx.out_back = None
+        if mask_bits is not None:
+            ctx.out_back = gx._sg_back = BackInfo(mask_bits, mask_slope)
+        return gx
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w, signs, mask_bits = ctx.saved_tensors
+        slope, coef, mask_slope = ctx.cfg
+        if mask_bits is not None and not (ctx.out_back is not None and ctx.out_back.all_premask()):
+            ggx, _ = _BiasActBwd.apply(ggx, mask_bits, mask_slope, False)      # pull the (linear) output mask back
+        g_gy = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_gy = _Down.apply(_Conv.apply(ggx, w, coef, False, False), 0.125, None, (2, 2, 2), signs, slope)
+        if _wants(ctx, 1, w.data_ptr()):
+            lib = _lib.load()
+            ggx_, gy_ = ndhwc(ggx), ndhwc(gy)
+            n, _, d, h, wd = _dims(ggx_)
+            dt = _dt(ggx_)
+            shp = _shape(n, d, h, wd, 32, 64, (3, 3, 3), False)
+            ws_bytes = lib.sg_conv3d_wgrad_workspace(C.byref(shp), dt)
+            ws = torch.empty(ws_bytes, device=ggx.device, dtype=torch.uint8)
+            dw = torch.empty((3, 3, 3, 32, 64), device=ggx.device, dtype=torch.float32)
+            rc = lib.sg_conv3d_wgrad_bias_up_masked(_ptr(ggx_), _ptr(gy_), _ptr(signs), slope, 0.125, _ptr(dw), None, coef,
+                                                    _ptr(ws), ws_bytes, C.byref(shp), dt, _stream())
+            if rc == _lib.SG_EUNSUPPORTED:      # the materialised pair, as the plain path computes it
+                g_full = _Up.apply(gy_, 0.125, signs, slope, (2, 2, 2))
+                dw, _ = raw_wgrad(ggx_, g_full, (3, 3, 3), coef, False, False)
+            else:
+                check(rc, 'sg_conv3d_wgrad_bias_up_masked')
+            g_w = dw.reshape(w.shape)
+        return g_gy, g_w, None, None, None, None, None
 
 
 def _pooled_backward_gather(gy, x, w, signs, coef, slope, in_info, want_gx, want_gw, want_db):

@@ -85,7 +85,9 @@ typedef struct {
    * -- the first stage of downscale3d(act(conv3d(x) + b)) (pgan/discriminator.py:39-44), finished by
    * sg_downscale_sum(1,2,1, gain 1/2).  sign_out still receives the FULL-resolution sign words (all the backward
    * needs).  Only the sliding-halo kernel implements it (bf16, 3x3x3, cin <= 32, w % 32 == 0, cout % 32 == 0, even
-   * d and h, no pixel-norm / mask): anything else returns SG_EUNSUPPORTED and the caller runs conv + downscale.
+   * d and h, no pixel-norm; mask_bits only without bias / activation / sign_out and with 32 input channels: the block means
+   * of M * conv(x), the double backward of such a layer): anything else returns SG_EUNSUPPORTED and the caller runs conv +
+   * downscale.
    * pool = 2: the mean over 1 (D) x 2 (H) x 2 (W) blocks instead, [n, d, h/2, w/2, cout], finished by
    * sg_downscale_sum(2,1,1, gain 1/2): the streamed ping-pong kernel's tile (bf16, 3x3x3, cin % 16 == 0, cout % 64 == 0,
    * even h and w, no pixel-norm / mask), for the layers with more than 32 input channels.  With act = 0 and no bias

@@ -1644,7 +1644,7 @@ static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
   if (s->upsample_in && (KS == 0 || GC != 2 || ((s->d | s->h | s->w) & 1))) return SG_OK;
   if (a.in_mask && !s->upsample_in) return SG_OK;
   if (s->d < 4 || (s->w % 32) != 0 || (s->cout % 32) != 0) return SG_OK;   // >= 2 steps per column; full 32-wide rows and tiles
-  if (a.pool && ((s->d & 1) || (s->h & 1) || a.pixel_norm || a.mask_bits || KS != 0)) return SG_OK;
+  if (a.pool && ((s->d & 1) || (s->h & 1) || a.pixel_norm || (a.mask_bits && (a.sign_out || a.bias || a.act)) || KS != 0)) return SG_OK;
   if (a.pixel_norm && (a.mask_bits || KS == 1 || a.ntile != 1)) return SG_OK;
   if (a.mask_bits && a.sign_out) return SG_OK;
   if (a.pnb_y && (KS != 0 || GC != 2 || a.ntile != 1 || !a.mask_bits || a.pixel_norm || a.pool || a.sign_out || a.bias || a.act ||
@@ -1713,6 +1713,13 @@ static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
       case SG_EP_PN | SG_EP_SIGN: rc = launch_fwd3s_inst<GC, 0, SG_EP_PN | SG_EP_SIGN>(a, (unsigned)gx, lds, st); break;
       case SG_EP_SIGN | SG_EP_POOL: rc = launch_fwd3s_inst<GC, 0, SG_EP_SIGN | SG_EP_POOL>(a, (unsigned)gx, lds, st); break;
       case SG_EP_POOL: rc = launch_fwd3s_inst<GC, 0, SG_EP_POOL>(a, (unsigned)gx, lds, st); break;
+      case SG_EP_MASK | SG_EP_POOL:
+      case SG_EP_MASK | SG_EP_POOL | SG_EP_SIGN:      // block means of M * conv(x): the double backward of a pooled LeakyReLU layer
+        if constexpr (GC == 2) {                        // (a caller's sign_out then receives the signs of M * conv(x): nobody asks)
+          if (epi & SG_EP_SIGN) return SG_OK;
+          rc = launch_fwd3s_inst<GC, 0, SG_EP_MASK | SG_EP_POOL>(a, (unsigned)gx, lds, st);
+          break;
+        } else return SG_OK;
       case SG_EP_MASK | SG_EP_PNB:
         if constexpr (GC == 2) { rc = launch_fwd3s_inst<GC, 0, SG_EP_MASK | SG_EP_PNB>(a, (unsigned)gx, lds, st); break; }
         else return SG_OK;

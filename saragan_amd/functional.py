@@ -807,7 +807,15 @@ class _PooledDgradGather(torch.autograd.Function):
             ggx, _ = _BiasActBwd.apply(ggx, mask_bits, mask_slope, False)      # pull the (linear) output mask back
         g_gy = g_w = None
         if ctx.needs_input_grad[0]:
-            g_gy = _Down.apply(_Conv.apply(ggx, w, coef, False, False), 0.125, None, (2, 2, 2), signs, slope)
+            # block_sum(M * conv(ggx)) / 8: the mask and the 2 x 1 x 2 block means in the convolution's epilogue
+            # (sg_conv_epilogue.pool with mask_bits), the H pairs by sg_downscale_sum -- the 64-channel tensor is never written
+            res = None
+            if not torch.is_grad_enabled() and not _NO_POOL_FUSION and _pool_mode(ggx, (3, 3, 3), 32, 64) == 1:
+                res = raw_conv(ggx, w, coef, False, False, mask_bits=signs, mask_slope=slope, pool=1)
+            if res is not None:
+                g_gy = _Down.apply(res[0], 0.5, None, _POOL_REST[1])
+            else:
+                g_gy = _Down.apply(_Conv.apply(ggx, w, coef, False, False), 0.125, None, (2, 2, 2), signs, slope)
         if _wants(ctx, 1, w.data_ptr()):
             lib = _lib.load()
             ggx_, gy_ = ndhwc(ggx), ndhwc(gy)

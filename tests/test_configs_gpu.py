@@ -361,3 +361,61 @@ def test_config4_m_phase7_fade_in_step():
     print(f'config 4 step: peak {peak:.1f} GiB, gen_loss {float(gl):.4f}, disc_loss {float(dl):.4f}')
     from saragan_amd.varstore import set_compute_dtype
     set_compute_dtype(torch.float32)
+
+
+def test_gradient_penalty_through_the_fused_gather_matches_the_materialised_path(monkeypatch):
+    """The gradient penalty of the benchmarked discriminator (pgan 's' phase 6, bf16, 32x128x128, batch 4 -- the smallest
+    batch whose 128^2 level fills the gather kernels' grid) with the pooled layer's backward through the fused masked gather
+    (functional._PooledDgradGather: first backward differentiable, double backward = masked, pooled forward of the incoming
+    gradient + gathered weight gradient) against the materialised path (SARAGAN_NO_GATHER_BWD): the same penalty, a
+    bit-identical first-backward gradient, every parameter gradient of the double backward within bf16 rounding of the
+    other path's (the fused double backward rounds block means where the other rounds the full-resolution tensor)."""
+    from saragan_amd import functional as F
+    from saragan_amd.networks.pgan.discriminator import discriminator
+    from saragan_amd.networks.pgan.variables import preset_specs
+    from saragan_amd.varstore import VariableStore, set_compute_dtype, use_store
+    took = []
+    real = F._PooledDgradGather.forward
+
+    def run(no_gather):
+        monkeypatch.setattr(F, '_NO_GATHER_BWD', no_gather)
+        set_compute_dtype(torch.bfloat16)
+        store = VariableStore('cuda', seed=3)
+        g_ = torch.Generator(device='cuda').manual_seed(5)
+        x = torch.randn((4, 1, 32, 128, 128), generator=g_, device='cuda').bfloat16().contiguous(memory_format=torch.channels_last_3d)
+        with use_store(store):
+            xi = x.clone().requires_grad_(True)
+            ks, fs = preset_specs('s', (1, 1, 4, 4), 8)
+            d = discriminator(xi, 0.0, 6, 512, 'leaky_relu', ks, fs, param=0.2).float()
+            params = list(store.vars.values())
+            with F.skip_param_grads(params):
+                (gr,) = torch.autograd.grad(d, xi, grad_outputs=torch.ones_like(d), create_graph=True)
+            took.append(any(type(fn).__name__ == '_PooledDgradGatherBackward' for fn in _graph_nodes(gr.grad_fn)))
+            slopes = torch.sqrt(F.sumsq_keep_w(gr).sum(dim=1))
+            gp = 10 * ((slopes - 1) ** 2).mean()
+            grads = torch.autograd.grad(gp, params, allow_unused=True)
+        return float(gp.detach()), gr.detach().clone(), {k: g for k, g in zip(store.vars.keys(), grads)}
+
+    def _graph_nodes(fn, seen=None):
+        seen = set() if seen is None else seen
+        if fn is None or fn in seen:
+            return seen
+        seen.add(fn)
+        for nxt, _ in fn.next_functions:
+            _graph_nodes(nxt, seen)
+        return seen
+
+    gp0, gr0, g0 = run(True)
+    gp1, gr1, g1 = run(False)
+    assert took == [False, True], took
+    assert real is F._PooledDgradGather.forward
+    assert gp0 == gp1 and torch.equal(gr0, gr1)
+    for k in g0:
+        assert (g0[k] is None) == (g1[k] is None), k
+        if g0[k] is not None:
+            e = float(torch.linalg.vector_norm(g0[k].float() - g1[k].float()) / (torch.linalg.vector_norm(g0[k].float()) + 1e-30))
+            assert e <= 1e-2, (k, e)
+    from saragan_amd.varstore import set_compute_dtype as _s
+    _s(torch.float32)
+    F.clear_pack_cache()
+    torch.cuda.empty_cache()

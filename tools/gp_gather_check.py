@@ -12,7 +12,7 @@ from saragan_amd.varstore import VariableStore, set_compute_dtype, use_store   #
 from saragan_amd.networks.pgan.variables import preset_specs   # noqa: E402
 
 
-def run(no_gather, n=2):
+def run(no_gather, n=4):
     F._NO_GATHER_BWD = no_gather
     set_compute_dtype(torch.bfloat16)
     store = VariableStore('cuda', seed=3)

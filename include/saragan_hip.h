@@ -116,7 +116,7 @@ typedef struct {
    * tensor of the FINE shape [n,d,h,w,cin] (ceil(cin/32) words per voxel).  This is the gradient of
    * downscale3d(leaky_relu(.)) (pgan/discriminator.py:39-44 backward: networks/ops.py:265-273 then :175-178, gain 1/8)
    * formed while the halo is staged, so the full-resolution gradient -- 8 x the bytes of x -- is never written.  Values are
-   * rounded to the storage type exactly as sg_upscale2x_masked rounds them.  Implemented by the two-pass 64 -> 32 path
+   * rounded to the storage type exactly as sg_upscale2x_masked rounds them; in_gain must be a power of two (1/8 for downscale3d).  Implemented by the two-pass 64 -> 32 path
    * (see workspace; bf16, 3x3x3, even d/h/w, w % 32 == 0): anything else returns SG_EUNSUPPORTED.  NULL: off. */
   const void* in_mask_bits;
   float in_mask_slope;
@@ -189,7 +189,7 @@ int sg_conv3d_wgrad_bias(const void* x, const void* dy, float* dw_dhwio, float* 
  * dy_half [n, d/2, h/2, w/2, cout] is the gradient of the POOLED output; the gradients are taken against
  * dy_gain * where(bit, mask_slope, 1) * upscale3d(dy_half) -- networks/ops.py:265-273 backward (dy_gain = 1/8) followed by
  * :175-178 with the layer's sign words mask_bits [n*d*h*w][cout/32] -- formed while each tile is staged, with the rounding
- * of sg_upscale2x_masked, so the full-resolution gradient is never written.  s is the FINE shape.  bf16, 3x3x3,
+ * of sg_upscale2x_masked (dy_gain: a power of two), so the full-resolution gradient is never written.  s is the FINE shape.  bf16, 3x3x3,
  * cout % 32 == 0, even d/h/w, w % 32 == 0 and the sliding-halo kernel's tile: otherwise SG_EUNSUPPORTED.  Same workspace
  * as sg_conv3d_wgrad_bias. */
 int sg_conv3d_wgrad_bias_up_masked(const void* x, const void* dy_half, const void* mask_bits, float mask_slope, float dy_gain,

@@ -196,16 +196,31 @@ __device__ __forceinline__ uint32_t sg_pack_bf16(float lo, float hi) {   // one 
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_));
 }
 
+static inline bool sg_is_pow2f(float g) {      // a positive normal power of two: the mantissa bits are zero
+  uint32_t u;
+  __builtin_memcpy(&u, &g, 4);
+  return g > 0.f && (u & 0x007FFFFFu) == 0 && (u >> 23) != 0 && (u >> 23) != 255;
+}
+
 // One staged 16-byte piece (8 bf16 channels) of a masked nearest up-scale: bf16(x * gain [* slope where the sign bit of
-// the fine voxel's channel is set]), bit e of m = channel e of the piece.  The arithmetic of sg_upscale2x_masked
-// (elementwise.hip), so that a gather fused into a consumer is bit-identical to the tensor that kernel would write.
+// the fine voxel's channel is set]), bit e of m = channel e of the piece.  `gain` is a power of two (host-checked), so
+// x * (gain * slope) is bit for bit (x * gain) * slope, the arithmetic of sg_upscale2x_masked (elementwise.hip): a gather
+// fused into a consumer is bit-identical to the tensor that kernel would write.  Per element: unpack, sign-extended bit
+// (v_bfe_i32), factor select (v_bfi_b32), multiply -- 4.5 VALU with the pack, where and + cmp + cndmask + two multiplies
+// were 6.5 (the mask arithmetic sets the off-phase of the gathered K-split passes).
 __device__ __forceinline__ u32x4 sg_mask_piece_bf16(u32x4 v, uint32_t m, float gain, float slope) {
+  const uint32_t fg = __float_as_uint(gain), fs = __float_as_uint(gain * slope);
   u32x4 o;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    float lo = __uint_as_float(v[e] << 16) * gain, hi = __uint_as_float(v[e] & 0xFFFF0000u) * gain;
-    lo = ((m >> (2 * e)) & 1u) ? lo * slope : lo;
-    hi = ((m >> (2 * e + 1)) & 1u) ? hi * slope : hi;
+    // (inline asm: written as C the compiler canonicalises the pair back to v_and + v_cmp + v_cndmask)
+    uint32_t t0, t1, f0, f1;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t0) : "v"(m), "n"(2 * e));
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(t1) : "v"(m), "n"(2 * e + 1));
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(f0) : "v"(t0), "v"(fs), "v"(fg));      // (t & fs) | (~t & fg)
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(f1) : "v"(t1), "v"(fs), "v"(fg));
+    const float lo = __uint_as_float(v[e] << 16) * __uint_as_float(f0);
+    const float hi = __uint_as_float(v[e] & 0xFFFF0000u) * __uint_as_float(f1);
     o[e] = sg_pack_bf16(lo, hi);
   }
   return o;

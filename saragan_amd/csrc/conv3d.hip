@@ -2863,8 +2863,9 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
   a.in_gain = ep ? ep->in_gain : 1.f;
   a.in_mask_nw = (s->cin + 31) >> 5;
   if (a.in_mask && (dt != SG_BF16 || !s->upsample_in || s->kd != 3 || s->kh != 3 || s->kw != 3 || s->cin != 64 || s->cout != 32 ||
-                    !sg_aligned16(a.in_mask)))
-    return a.in_mask && !sg_aligned16(a.in_mask) ? SG_EALIGN : SG_EUNSUPPORTED;     // only the two-pass 64 -> 32 path masks its gather
+                    !sg_aligned16(a.in_mask) || !sg_is_pow2f(a.in_gain)))
+    return a.in_mask && !sg_aligned16(a.in_mask) ? SG_EALIGN : SG_EUNSUPPORTED;     // only the two-pass 64 -> 32 path masks its gather;
+                                                                                   // the gain must be a power of two (sg_mask_piece_bf16)
   a.os = (ep && ep->out_scale == 2) ? 2 : 1;
   a.oa = ep ? ep->out_off[0] : 0; a.ob = ep ? ep->out_off[1] : 0; a.oc = ep ? ep->out_off[2] : 0;
   const bool subpixel = a.os == 2 || a.tap_d || a.tap_h || a.tap_w || s->kd == 2;

@@ -1557,7 +1557,7 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
   if (!conv_shape_ok_w(s) || !x || !dy || !dw || !workspace) return SG_EINVAL;
   if (!sg_aligned16(x) || !sg_aligned16(dy) || !sg_aligned16(workspace)) return SG_EALIGN;
   if (dy_mask && (dt != SG_BF16 || s->kd != 3 || s->kh != 3 || s->kw != 3 || s->upsample_in || (s->cout % 32) ||
-                  sg_cfg().wgrad_v1 || sg_cfg().wgrad_no_v3))
+                  sg_cfg().wgrad_v1 || sg_cfg().wgrad_no_v3 || !sg_is_pow2f(dy_gain)))
     return SG_EUNSUPPORTED;
   const size_t need = sg_conv3d_wgrad_workspace(s, dt);
   if (workspace_bytes < need) return SG_EWORKSPACE;

@@ -541,6 +541,23 @@ def main():
                                                        sorted(by_kernel.items(), key=lambda kv: -kv[1])[:8]},
                            losses_after=dict(disc=round(losses[0], 4), gen=round(losses[1], 4))),
                roofline=roof)
+    # the bandwidth-bound kernels of the step priced in bytes (calibration-step timings; configs[4]'s 4-16-channel layers): the
+    # heaviest (kind, shape) of the small-channel family, algorithmic bytes = one read of x and one read / write of y
+    es_ = 2 if args.dtype == 'bf16' else 4
+    small = [e for e in rows if e.kernel.startswith(b'conv_small') and e.launches > 0 and      # ... those below the machine balance
+             e.flops_per_launch / (e.shape.n * e.shape.d * e.shape.h * e.shape.w * (e.shape.cin + e.shape.cout) * es_) < peak * 1e12 / HBM_PEAK]
+    if small:
+        e = max(small, key=lambda r: r.total_ms)
+        s_ = e.shape
+        es = 2 if args.dtype == 'bf16' else 4
+        nbytes = int(s_.n * s_.d * s_.h * s_.w * (s_.cin + s_.cout) * es)
+        avg = e.total_ms / e.launches
+        gbs = nbytes / (avg * 1e-3) / 1e9
+        out['roofline_hbm'] = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK / 1e9, unit='GB/s', frac=round(gbs * 1e9 / HBM_PEAK, 4),
+                                   traffic=pmc_traffic(e, args.dtype), kernel=e.kernel.decode(), kind='fwd' if e.kind == 0 else 'wgrad',
+                                   shape=dict(n=s_.n, d=s_.d, h=s_.h, w=s_.w, cin=s_.cin, cout=s_.cout, k=[s_.kd, s_.kh, s_.kw]),
+                                   launches=int(e.launches), avg_ms=round(avg, 4), algorithmic_bytes=nbytes,
+                                   note='the small-channel VALU kernels (csrc/small.hip), timed during the calibration steps')
     if world == 1 and args.config == 3 and not args.no_extras:
         extras = {}
         extras['loader_in_loop'] = loader_leg(args, cfg, device, max(3, args.steps), barrier)

@@ -514,6 +514,12 @@ def main():
                                upsample_in=s.upsample_in),
                     launches=int(best.launches), avg_ms=round(avg_ms, 4), flops_per_launch=best.flops_per_launch,
                     algorithmic_bytes=alg_bytes)
+        # the same kernel on its other shapes (calibration-step timings): the object above quotes the heaviest one by summed time
+        others = sorted((e for e in rows if e.kernel == dom_name and e.launches > 0), key=lambda r: -r.total_ms)[:5]
+        roof['by_shape'] = [dict(n=e.shape.n, cin=e.shape.cin, cout=e.shape.cout, calls_per_step=round(e.launches / ncal, 1),
+                                 avg_ms=round(e.total_ms / e.launches, 4),
+                                 achieved=round(e.flops_per_launch / (e.total_ms / e.launches * 1e-3) / 1e12, 1),
+                                 frac=round(e.flops_per_launch / (e.total_ms / e.launches * 1e-3) / 1e12 / peak, 4)) for e in others]
     fg, fd = conv_flops_per_volume(cfg['ks'], cfg['fs'], args.phase, cfg['base_shape'], args.latent, args.dims)
     # executed conv work: G fwd+dgrad+wgrad; D: 3 forwards, 3 (wgan: the G loss reuses the D-loss data gradient)
     # or 4 data-gradient passes, 2 weight-gradient passes, 2 convs of the GP double backward + its weight gradient

@@ -580,12 +580,14 @@ static int launch_fwd2(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st) {
 // the table holds KD x (KH + MTW - 1) x KW addresses instead of KD x KH x KW x MTW (36 instead of 54 registers at 3x3x3
 // with two M tiles, which is what kept <2,2,3,3,3> from fitting 256 VGPRs next to its 64 accumulators; 54 instead of
 // 108 with four).
-template <int MTW, int KH, int KW, bool HS>
+// RS: H rows between the wave's consecutive M tiles -- 1 with 32-wide tile rows (an M tile is one row), 2 with 16-wide
+// rows (an M tile is two rows): KD x (KH + RS (MTW - 1)) x KW addresses.
+template <int MTW, int KH, int KW, bool HS, int RS = 1>
 __host__ __device__ constexpr int sg_xa_index(int tap, int mt) {
-  return HS ? ((tap / (KH * KW)) * (KH + MTW - 1) + (tap / KW) % KH + mt) * KW + tap % KW : tap * MTW + mt;
+  return HS ? ((tap / (KH * KW)) * (KH + RS * (MTW - 1)) + (tap / KW) % KH + RS * mt) * KW + tap % KW : tap * MTW + mt;
 }
-template <int MTW, int KD, int KH, int KW, bool HS>
-struct sg_xa_size { static constexpr int value = HS ? KD * (KH + MTW - 1) * KW : KD * KH * KW * MTW; };
+template <int MTW, int KD, int KH, int KW, bool HS, int RS = 1>
+struct sg_xa_size { static constexpr int value = HS ? KD * (KH + RS * (MTW - 1)) * KW : KD * KH * KW * MTW; };
 
 template <typename T, int MTW, int GC, int TAPS, int RING, int KH, int KW, bool HS, int NA>
 struct sg_unrolled_k {
@@ -638,7 +640,7 @@ struct sg_unrolled_k {
 
 // Same for the streamed-weight kernel (v4): one step = one tap of the current 32-byte channel chunk:
 // NTB weight fragments + MTW activation fragments, MTW*NTB MFMAs.
-template <typename T, int MTW, int NTB, int TAPS, int RING, int KH, int KW, bool HS, int NA>
+template <typename T, int MTW, int NTB, int TAPS, int RING, int KH, int KW, bool HS, int NA, int RS = 1>
 struct sg_unrolled_k4 {
   static constexpr int PF = RING - 1, RPS = NTB + MTW;
   template <int ST>
@@ -650,7 +652,7 @@ struct sg_unrolled_k4 {
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wfr[SL][nt]) : "v"(wl_off), "n"((ST * NTB + nt) << 10));
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
-      asm volatile("ds_read_b128 %0, %1" : "=v"(xfr[SL][mt]) : "v"(xaddr[sg_xa_index<MTW, KH, KW, HS>(ST, mt)]));
+      asm volatile("ds_read_b128 %0, %1" : "=v"(xfr[SL][mt]) : "v"(xaddr[sg_xa_index<MTW, KH, KW, HS, RS>(ST, mt)]));
   }
   template <int ST>
   static __device__ __forceinline__ void step(f32x16 (&acc)[MTW][NTB], u32x4 (&wfr)[RING][NTB], u32x4 (&xfr)[RING][MTW],
@@ -1740,7 +1742,7 @@ static int launch_fwd3s(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, 
 // other group fetches ITS next halo chunk and weight slab (all taps of that chunk, NTB output tiles) by
 // LDS-DMA and, when its previous item closed a tile, runs that tile's epilogue.  One barrier per item.
 // ------------------------------------------------------------------------------------------------------
-template <typename T, int MTW, int NTB, int KD, int KH, int KW>
+template <typename T, int MTW, int NTB, int KD, int KH, int KW, int RS = 1>
 __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TAPS = KD * KH * KW;
@@ -1782,7 +1784,7 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
   // HS (64 accumulators per lane: two M x two N tiles, or four M tiles): the address table is shared between the
   // wave's M tiles (sg_xa_index); the host launches it only where M tile mt is M tile 0 moved by mt H rows
   constexpr bool HS = (MTW * NTB >= 4);
-  constexpr int NA = sg_xa_size<MTW, KD, KH, KW, HS>::value;
+  constexpr int NA = sg_xa_size<MTW, KD, KH, KW, HS, RS>::value;
   int xaddr[NA];
   int tcoord[MTW];
 #pragma unroll
@@ -1801,17 +1803,17 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
 #pragma unroll
     for (int kd = 0; kd < KD; ++kd)
 #pragma unroll
-      for (int kh = 0; kh < KH + (HS ? MTW - 1 : 0); ++kh)
+      for (int kh = 0; kh < KH + (HS ? RS * (MTW - 1) : 0); ++kh)
 #pragma unroll
         for (int kw = 0; kw < KW; ++kw) {
           const int row = lrow + ((kd + a.tap_d) * g.HH + (kh + a.tap_h)) * g.HW + (kw + a.tap_w);
-          const int idx = HS ? (kd * (KH + MTW - 1) + kh) * KW + kw : ((kd * KH + kh) * KW + kw) * MTW + mt;
+          const int idx = HS ? (kd * (KH + RS * (MTW - 1)) + kh) * KW + kw : ((kd * KH + kh) * KW + kw) * MTW + mt;
           xaddr[idx] = grp * a.xbytes + row * rb + ((hh ^ ((row >> 3) & 1)) << 4);
         }
   }
   const int hv = g.TN * g.HD * g.HH * g.HW;
   const int items = hv * 2;
-  constexpr int MAXIT = MTW > 2 ? 10 : 8;   // LDS-DMA pieces per wave per halo chunk (host-checked)
+  constexpr int MAXIT = MTW > 2 ? 10 : (RS == 2 ? 6 : 8);   // LDS-DMA pieces per wave per halo chunk (host-checked)
   int it_rel[MAXIT];   // element offset (chunk 0) relative to the tile's first halo voxel, -1 dead
   int it_crd[MAXIT];
   const int Di = g.ups ? (g.D >> 1) : g.D, Hi = g.ups ? (g.H >> 1) : g.H, Wi = g.ups ? (g.W >> 1) : g.W;
@@ -1981,7 +1983,7 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
               for (int i = 0; i < 16; ++i) acc[mt][nt][i] = bias_lds[nt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hh];
         }
         // (four M tiles: a step already carries 4 MFMAs = 128 cycles, one step of fragment prefetch covers the LDS latency)
-        sg_unrolled_k4<T, MTW, NTB, TAPS, (MTW > 2 ? 2 : 3), KH, KW, HS, NA>::run(acc, xaddr, (int)(wl - smem) + (a.wres ? (q % ncg) : (q & 1)) * a.wbytes);
+        sg_unrolled_k4<T, MTW, NTB, TAPS, (MTW > 2 || RS == 2 ? 2 : 3) /* RS = 2: 45 table registers, ring of 2 */, KH, KW, HS, NA, RS>::run(acc, xaddr, (int)(wl - smem) + (a.wres ? (q % ncg) : (q & 1)) * a.wbytes);
       }
     } else {
       // my next item is q' = (p + 1) >> 1; my previous one q' - 1 (ran in phase p - 1)
@@ -2082,7 +2084,7 @@ __global__ __launch_bounds__(512) void conv_fwd4_kernel(ConvFwdArgs a) {
   }
 }
 
-template <typename T, int MTW, int NTB, int KD, int KH, int KW>
+template <typename T, int MTW, int NTB, int KD, int KH, int KW, int RS = 1>
 static int launch_fwd4(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used) {
   *used = false;
   constexpr int BM = MTW * 128;
@@ -2109,8 +2111,9 @@ static int launch_fwd4(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, b
   a.lean = ((!s->upsample_in || (g.TD % 2 == 0 && g.TH % 2 == 0 && g.TW % 2 == 0 && g.TN == 1)) &&
             !sg_cfg().fwd4_no_lean) ? 1 : 0;
   a.wbytes = a.taps * NTB * 1024;
-  if (sg_cdiv(hv * 2, 64) > (MTW > 2 ? 40 : 32)) return SG_OK;
-  if (MTW * NTB >= 4 && !(g.TW == 32 && g.TH % MTW == 0)) return SG_OK;   // shared address table (sg_xa_index)
+  if (sg_cdiv(hv * 2, 64) > (MTW > 2 ? 40 : (RS == 2 ? 24 : 32))) return SG_OK;
+  // shared address table (sg_xa_index): M tile mt must be M tile 0 moved by RS * mt H rows of the same (n, d) plane
+  if (MTW * NTB >= 4 && !(RS == 1 ? (g.TW == 32 && g.TH % MTW == 0) : (g.TW == 16 && g.TH % (2 * MTW) == 0))) return SG_OK;
   size_t lds = 2ull * a.xbytes + (size_t)a.nchunk * a.wbytes + NTB * 128;
   a.wres = (lds <= 160 * 1024 && !sg_cfg().fwd4_no_wres) ? 1 : 0;
   if (!a.wres) lds = 2ull * a.xbytes + 2ull * a.wbytes + NTB * 128;
@@ -2118,7 +2121,7 @@ static int launch_fwd4(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, b
   a.ntiles = (int)ntiles;
   a.vec_in = 1;
   a.vec_out = (s->cout % 4 == 0) ? 1 : 0;
-  auto kern = conv_fwd4_kernel<T, MTW, NTB, KD, KH, KW>;
+  auto kern = conv_fwd4_kernel<T, MTW, NTB, KD, KH, KW, RS>;
   SG_ALLOW_160K_LDS(kern);
   SG_KNAME("conv_fwd4<%s,%d,%d,%d,%d,%d>", sg_tname<T>(), MTW, NTB, KD, KH, KW);
   hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)ny), dim3(512), lds, st, a);
@@ -3006,6 +3009,11 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     // 32-channel slice per block (pixel-norm over 64 channels then falls through to the v2 kernels)
     const sg_tile_geom g4 = sg_make_geom(s, 256, /*prefer_w32=*/true);
     const bool n1 = a.ntile == 1 || (!(g4.TW == 32 && (g4.TH & 1) == 0) && !a.pixel_norm);
+    // 16-wide tile rows (the 16^2 level): two output-channel tiles per wave through the address table with a two-row shift
+    if (dt == SG_BF16 && k333 && a.ntile >= 2 && g4.TW == 16 && (g4.TH & 3) == 0 && !a.pixel_norm && !sg_cfg().fwd4_no_lean) {
+      rc = launch_fwd4<bf16_t, 2, 2, 3, 3, 3, 2>(a, s, hs, &used);
+      if (rc != SG_OK || used) { prof.done(rc); return rc; }
+    }
     // (A 4 x 4 x 32 tile with four M tiles per wave was measured for the one-slice deep-K layers, 64 -> 32 at 128^2:
     // 682 against 732 TFLOP/s.  It doubles the MFMAs per staged halo chunk but no longer fits next to resident weights,
     // so the streamed slab halves put back the bytes per phase it saved: those layers are bound by the LDS-DMA issue ->

@@ -312,6 +312,51 @@ int sg_optim_step(int kind, float* p, const float* g, float* s1, float* s2, floa
  * (tf.norm per gradient + tf.clip_by_global_norm, optimization.py:66-71).  offsets: DEVICE int64[nseg+1]. */
 int sg_segment_sumsq(const float* flat, const int64_t* offsets, float* out, int32_t nseg, sg_stream_t st);
 
+/* ---- validation metrics on device tensors (metrics/swd.py:13-123, metrics/skim_metrics.py:8-45) ---------------- */
+/* One axis of a separable FIR filter over x viewed as [outer, n, inner] (f32, or f64 when `f64` != 0; accumulated in
+ * f64 either way): y = alpha * value + add (add may be NULL; it is shaped like y).
+ *   mode 0: value[o] = sum_t taps[t] x[B(o + t - r)]                    extent n      (scipy.ndimage.gaussian_filter1d)
+ *   mode 1: value[o] = sum_t taps[t] x[B(2o + t - r)]                   extent (n+1)/2  (pyr_down, swd.py:63-66:
+ *           the 5x5x5 binomial filter is separable, then [::2])
+ *   mode 2: value[o] = sum_t taps[t] z[B(o + t - r)], z[2k] = x[k], z[odd] = 0, extent 2n  (pyr_up, swd.py:69-74)
+ * r = ntaps / 2, ntaps odd <= 15, taps on the HOST.  border B: 0 scipy 'mirror', 1 scipy 'reflect'.  x != y. */
+int sg_filter_axis(const void* x, void* y, const void* add, int64_t outer, int32_t n, int64_t inner, const double* taps,
+                   int32_t ntaps, int32_t mode, int32_t border, double alpha, int32_t f64, sg_stream_t st);
+/* get_descriptors_for_minibatch (swd.py:13-26): x f32 [n_img, c, d, h, w] (NCDHW, as the metrics receive it);
+ * out[nh, c, i, j, k] = x[nh / per_image, c, d0[nh] + i - rd, h0[nh] + k - rw, w0[nh] + j - rh], out shaped
+ * [n_img * per_image, c, 2rd+1, 2rh+1, 2rw+1] -- the reference adds its fourth-axis offsets to the W centre and its
+ * fifth-axis offsets to the H centre, and so does this.  d0 / h0 / w0: DEVICE int32[n_img * per_image], centres the
+ * caller drew inside [r, extent - r). */
+int sg_swd_gather(const float* x, float* out, const int32_t* d0, const int32_t* h0, const int32_t* w0, int32_t n_img,
+                  int32_t c, int32_t d, int32_t h, int32_t w, int32_t per_image, int32_t rd, int32_t rh, int32_t rw,
+                  sg_stream_t st);
+/* finalize_descriptors (swd.py:31-39), in place: desc [n, c, inner] -> (desc - mean_c) / std_c over (n, inner). */
+size_t sg_desc_normalize_workspace(int32_t c);
+int sg_desc_normalize(float* desc, int64_t n, int32_t c, int64_t inner, void* workspace, size_t workspace_bytes,
+                      sg_stream_t st);
+/* sliced_wasserstein (swd.py:44-58) in three steps.  sg_swd_project: pt[dir][row] = sum_f a[row][f] * dirs[f][dir],
+ * a [n, f], dirs [f, ndirs], pt [ndirs, npad] with npad = sg_swd_padded_rows(n) (a power of two >= 64; rows n.. are
+ * +inf).  sg_sort_rows: every row of [rows, npad] ascending, in place (np.sort(axis=0) of the reference's layout).
+ * sg_swd_distance: out[0] = mean_{row, i < n} |pa - pb|; out: 1 + rows doubles (out[1..] the row sums). */
+int32_t sg_swd_padded_rows(int32_t n);
+int sg_swd_project(const float* a, const float* dirs, float* pt, int32_t n, int32_t f, int32_t ndirs, int32_t npad,
+                   sg_stream_t st);
+int sg_sort_rows(float* data, int32_t rows, int32_t npad, sg_stream_t st);
+int sg_swd_distance(const float* pa, const float* pb, double* out, int32_t rows, int32_t n, int32_t npad, sg_stream_t st);
+/* skimage.metrics restated on f64 device buffers (skim_metrics.py:8-45); workspace: sg_metric_workspace() bytes.
+ * sg_sqdiff_mean: out[0] = mean((a - b)^2).  sg_minmax: out[0] = min, out[1] = max.
+ * sg_ssim_products: xx = x*x, yy = y*y, xy = x*y.  sg_ssim_mean: out[0] = mean over the channels-last map
+ * [s0, s1, s2, c], cropped by crop0 on the first and crop on the other two spatial extents, of
+ * (2 ux uy + c1)(2 vxy + c2) / ((ux^2 + uy^2 + c1)(vx + vy + c2)), v* = cov_norm * (u** - u* u*). */
+size_t sg_metric_workspace(void);
+int sg_sqdiff_mean(const double* a, const double* b, double* out, int64_t numel, void* workspace, size_t workspace_bytes,
+                   sg_stream_t st);
+int sg_minmax(const double* a, double* out, int64_t numel, void* workspace, size_t workspace_bytes, sg_stream_t st);
+int sg_ssim_products(const double* x, const double* y, double* xx, double* yy, double* xy, int64_t numel, sg_stream_t st);
+int sg_ssim_mean(const double* ux, const double* uy, const double* uxx, const double* uyy, const double* uxy, double* out,
+                 int32_t s0, int32_t s1, int32_t s2, int32_t c, int32_t crop0, int32_t crop, double cov_norm, double c1,
+                 double c2, void* workspace, size_t workspace_bytes, sg_stream_t st);
+
 /* ---- opt-in kernel timing (used by bench.py's roofline leg) ------------------------------------- */
 /* When enabled, every sg_conv3d_fwd / sg_conv3d_wgrad launch is bracketed by hipEvents on its stream.
  * sg_prof_collect synchronises those events and returns, per kind (0 = conv fwd, 1 = wgrad) and per

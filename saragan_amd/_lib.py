@@ -91,6 +91,19 @@ SIGNATURES = {
     'sg_adam_ema': (C.c_int, [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p]),
     'sg_optim_step': (C.c_int, [C.c_int, _p, _p, _p, _p, _p, _i64, _f, _f, _f, C.c_int, _f, _f, _p]),
     'sg_segment_sumsq': (C.c_int, [_p, _p, _p, _i32, _p]),
+    'sg_filter_axis': (C.c_int, [_p, _p, _p, _i64, _i32, _i64, C.POINTER(C.c_double), _i32, _i32, _i32, C.c_double, _i32, _p]),
+    'sg_swd_gather': (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    'sg_desc_normalize_workspace': (_sz, [_i32]),
+    'sg_desc_normalize': (C.c_int, [_p, _i64, _i32, _i64, _p, _sz, _p]),
+    'sg_swd_padded_rows': (_i32, [_i32]),
+    'sg_swd_project': (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    'sg_sort_rows': (C.c_int, [_p, _i32, _i32, _p]),
+    'sg_swd_distance': (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p]),
+    'sg_metric_workspace': (_sz, []),
+    'sg_sqdiff_mean': (C.c_int, [_p, _p, _p, _i64, _p, _sz, _p]),
+    'sg_minmax': (C.c_int, [_p, _p, _i64, _p, _sz, _p]),
+    'sg_ssim_products': (C.c_int, [_p, _p, _p, _p, _p, _i64, _p]),
+    'sg_ssim_mean': (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, C.c_double, C.c_double, C.c_double, _p, _sz, _p]),
     'sg_prof_enable': (C.c_int, [C.c_int]),
     'sg_prof_collect': (C.c_int, [C.POINTER(ProfEntry), _i32, C.POINTER(_i32)]),
     'sg_prof_set_filter': (C.c_int, [C.c_int, _SHP]),

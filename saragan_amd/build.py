@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libsaragan_hip.so')
-SOURCES = ['conv3d.hip', 'wgrad.hip', 'elementwise.hip', 'optim.hip', 'prof.hip', 'small.hip', 'subpix.hip', 'gemm.hip']
+SOURCES = ['conv3d.hip', 'wgrad.hip', 'elementwise.hip', 'optim.hip', 'prof.hip', 'small.hip', 'subpix.hip', 'gemm.hip', 'metrics.hip']
 HEADERS = ['common.h', 'prof.h', os.path.join('..', '..', 'include', 'saragan_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 # The MFMA kernels' off-phases share their SIMD with the other wave group's MFMAs, and packed-f32 VALU ops

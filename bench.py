@@ -166,7 +166,7 @@ def build(args, device, dtype):
     alpha = ScalarVariable(args.alpha, 'alpha')
     g_lr, d_lr = ScalarVariable(1e-3, 'g_lr'), ScalarVariable(1e-3, 'd_lr')
     og, od = opt.AdamOptimizer(g_lr, 0.0, 0.9), opt.AdamOptimizer(d_lr, 0.0, 0.9)
-    if parallel.size() > 1:
+    if parallel.size() > 1 or (parallel.forced() and torch.distributed.is_initialized()):
         og, od = parallel.DistributedOptimizer(og), parallel.DistributedOptimizer(od)
         og.distributed.timing = od.distributed.timing = True
     sp = [s * 2 ** (args.phase - 1) for s in base_shape[1:]]
@@ -335,8 +335,28 @@ class Stopwatch:
         return False
 
 
+class quiet_collector:
+    """The timed regions start with an EMPTY device queue (barrier), so a host stall in their first steps is device idle
+    time: a full pass of Python's cyclic collector over the ~10^6 objects of a torch process takes ~0.1 s, and one landed
+    in a 10-step region now and then (a 57.8 ms/step run read 69.5 with every kernel at its usual duration).  Collect
+    first, then keep the collector off for the K steps -- what `timeit` does; a step leaves no device memory in cycles
+    (tools/cycle_probe.py), and the product loop freezes its long-lived objects instead (train.py)."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self.was = gc.isenabled()
+        gc.disable()
+
+    def __exit__(self, *exc):
+        import gc
+        if self.was:
+            gc.enable()
+        return False
+
+
 def timed_steps(step, nsteps, barrier):
-    with Stopwatch(barrier) as sw:
+    with quiet_collector(), Stopwatch(barrier) as sw:
         for i in range(nsteps):
             step(i)
     return sw.seconds
@@ -434,18 +454,39 @@ def main():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     device = torch.device('cuda', local % max(1, torch.cuda.device_count()))   # (rehearsals may stack ranks on one GPU)
     torch.cuda.set_device(device)
-    comm = parallel.collective_info() if world > 1 else None     # backend, RCCL version, communicator size, bucket algorithm
+    dp = torch.distributed.is_initialized()      # world > 1, or the one-rank rehearsal of the collectives (SARAGAN_DP_FORCE=1)
+    comm = parallel.collective_info() if dp else None     # backend, RCCL version, communicator size, bucket algorithm
     cfg = build(args, device, args.dtype)
     sess, ph = cfg['sess'], cfg['ph']
     batches = [synthetic_batch(cfg['shape'], rank * 1000 + i, device) for i in range(4)]
 
+    # The host enqueues a step in ~10 ms and the device runs it in ~58: unthrottled, a long run has the host hundreds of
+    # steps ahead and the caching allocator cannot hand blocks back that are still queued (700 steps ended in an
+    # out-of-memory error at 278 GiB).  The host waits for the step issued RUN_AHEAD steps earlier: the queue never drains,
+    # so nothing changes for the device.
+    RUN_AHEAD = 6
+    inflight = []
+    mem_diag = bool(os.environ.get('SARAGAN_BENCH_MEM'))
+
     def step(i):
         sess.run(cfg['train'], feed_dict={ph: batches[i % len(batches)]})
         sess.run(cfg['ema_op'])
+        ev = torch.cuda.Event()
+        ev.record()
+        inflight.append(ev)
+        if len(inflight) > RUN_AHEAD:
+            inflight.pop(0).synchronize()
+        if mem_diag and i % 20 == 0:
+            import gc
+            print(f'MEM step {i} allocated {torch.cuda.memory_allocated() / 2**30:.2f} GiB reserved '
+                  f'{torch.cuda.memory_reserved() / 2**30:.2f} GiB gc {gc.get_count()}', file=sys.stderr, flush=True)
+            if i % 100 == 0 and i:
+                n_ = gc.collect()
+                print(f'MEM   after gc.collect() ({n_} objects): {torch.cuda.memory_allocated() / 2**30:.2f} GiB', file=sys.stderr, flush=True)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -516,12 +557,12 @@ def main():
     if dom is not None:
         lib.sg_prof_set_filter(dom.kind, C.byref(dom.shape))
     barrier()
-    if world > 1:
+    if dp:
         for o_ in cfg['optimizers']:
             o_.distributed.exposed_ms()       # forget the warm-up steps
     lib.sg_prof_enable(0 if os.environ.get('SARAGAN_BENCH_NO_PROF') else 1)     # (diagnostic: no event bracketing at all)
     step_marks = [] if os.environ.get('SARAGAN_BENCH_STEP_TIMES') else None      # diagnostic: an event after every step (no sync)
-    with Stopwatch(lambda: None) as sw:      # the barrier before is the one above; the one after follows
+    with quiet_collector(), Stopwatch(lambda: None) as sw:      # the barrier before is the one above; the one after follows
         for i in range(args.steps):
             step(args.warmup + ncal + i)
             if step_marks is not None:
@@ -533,7 +574,7 @@ def main():
         dev_ms = [round(step_marks[i][0].elapsed_time(step_marks[i + 1][0]), 2) for i in range(len(step_marks) - 1)]
         host_ms = [round((step_marks[i + 1][1] - step_marks[i][1]) * 1e3, 2) for i in range(len(step_marks) - 1)]
         print('STEP_TIMES device', dev_ms, 'host', host_ms, file=sys.stderr, flush=True)
-    if world > 1:      # all-reduce time left exposed behind backward, per step (G + D), this rank
+    if dp:      # all-reduce time left exposed behind backward, per step (G + D), this rank
         comm['exposed_allreduce_ms_per_step'] = round(sum(sum(o_.distributed.exposed_ms()) for o_ in cfg['optimizers']) / args.steps, 3)
         comm['bucket_mib'] = cfg['optimizers'][0].distributed.bucket_elems * 4 >> 20
     timed = collect()
@@ -542,7 +583,7 @@ def main():
     losses = [float(v) for v in sess.run(cfg['losses'] + cfg['train'], feed_dict={ph: batches[0]})[:2]]
     if not all(l == l and abs(l) < 1e30 for l in losses):
         raise SystemExit(f'non-finite losses after the timed steps: {losses}')
-    if world > 1:
+    if dp:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())

@@ -505,7 +505,9 @@ class _ConvBiasAct(torch.autograd.Function):
                                    eps=eps, want_scale=True, want_signs=act and not _NO_SIGN_WORDS)
         if out_info is not None:
             out_info.bits = signs
-            out_info.pn = (y, scale) if pixel_norm else None
+            # (an alias without autograd history: `y` itself will point at this node, which holds out_info -- a reference
+            # cycle that kept the stage's output alive until the cyclic collector ran, 1.7 GiB per step at batch 32)
+            out_info.pn = (y.detach(), scale) if pixel_norm else None
         ctx.save_for_backward(x, w, y if (pixel_norm or (act and signs is None)) else None, scale, signs)
         ctx.cfg = (coef, ups, act, slope, pixel_norm)
         ctx.has_b = b is not None

@@ -25,14 +25,27 @@ def init_distributed(backend=None, timeout_s=600):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or forced()) and not dist.is_initialized():
         import datetime
+        if world == 1 and 'RANK' not in os.environ:      # the one-rank rehearsal started as a plain process
+            import socket
+            with socket.socket() as s_:
+                s_.bind(('127.0.0.1', 0))
+                port = s_.getsockname()[1]
+            os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         if backend is None:
             backend = os.environ.get('SARAGAN_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if torch.cuda.is_available():
             torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend=backend, timeout=datetime.timedelta(seconds=timeout_s))
     return rank, world, local
+
+
+def forced():
+    """SARAGAN_DP_FORCE=1: a single rank still creates its process group and issues every collective (a sum over one rank).
+    A one-GPU box can then run the RCCL calls of the N-rank path -- communicator start-up, the bucket collectives on RCCL's
+    stream ordered against the compute stream, the broadcast -- and must get the single-process result."""
+    return os.environ.get('SARAGAN_DP_FORCE', '0') == '1'
 
 
 def size():
@@ -137,7 +150,7 @@ class GradientAllReducer:
 
     def _launch(self, b):
         b['launched'] = True
-        if self.world_size > 1:
+        if self.world_size > 1 or (forced() and dist.is_initialized()):
             view = self._flat[b['off']:b['off'] + b['len']]
             if self.algo == 'rs_ag':
                 self._launch_rs_ag(view)
@@ -250,7 +263,7 @@ class AdasumReducer(GradientAllReducer):
         return self._seg, self._nseg
 
     def finish(self):
-        if self.world_size == 1 or not self._ranges:
+        if (self.world_size == 1 and not (forced() and dist.is_initialized())) or not self._ranges:
             return
         lo = min(o for o, _ in self._ranges)
         hi = max(o + n for o, n in self._ranges)
@@ -294,7 +307,7 @@ def collective_info(group=None):
 def broadcast_global_variables(store, root_rank=0, group=None):
     """hvd.broadcast_global_variables(root): every variable takes rank `root_rank`'s value.  Flat buffers go out
     as one message per network."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not forced()):
         return
     done = set()
     for prefix, flat in store.flat.items():

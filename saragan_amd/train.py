@@ -2,6 +2,7 @@
 per-phase graph build, restore from the previous phase, mixing / stabilising loop with alpha, learning-rate and
 EMA ops, periodic and end-of-phase checkpoints.  TensorBoard summaries, metrics (FID/SWD/...) and optuna are out
 of scope (SURVEY.md section 2a #11-13).  Reference quirks Q2-Q5 are reproduced (see comments)."""
+import gc
 import importlib
 import os
 import random
@@ -154,6 +155,11 @@ def run_training(args, device=None, max_steps_per_phase=None, log_every=1):
             else:
                 sess.run([train_g, train_d], feed_dict={real_image_input: batch})
             sess.run(ema_op)
+            if local_step == batch_size:
+                # The phase's graph, variables and closures live until the phase ends: taken out of the cyclic collector's
+                # sight, a full collection no longer walks them (~0.1 s of host stall each in a process of this size).
+                gc.collect()
+                gc.freeze()
             global_step += batch_size * global_size
             local_step += batch_size
             imgs += batch_size * global_size
@@ -180,6 +186,7 @@ def run_training(args, device=None, max_steps_per_phase=None, log_every=1):
                 global_step = (phase - args.starting_phase + 1) * (args.stabilizing_nimg + args.mixing_nimg)
                 break
         loader.close()
+        gc.unfreeze()
         torch.cuda.synchronize()
         stats[phase] = dict(img_s=imgs / max(1e-9, time.time() - t_phase), d_loss=d_loss, g_loss=g_loss,
                             batch_size=batch_size, steps=local_step // batch_size)

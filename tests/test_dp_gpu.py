@@ -23,11 +23,12 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, golden, q, backend='gloo'):
+def _worker(rank, world, port, golden, q, backend='gloo', extra_env=None):
     # gloo: both ranks share cuda:0 (one GPU suffices); nccl (= RCCL): one device per rank
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank) if backend == 'nccl' else '0', SARAGAN_DIST_BACKEND=backend,
                       HSA_ENABLE_IPC_MODE_LEGACY='0', SARAGAN_DP_TIMING='1')
+    os.environ.update(extra_env or {})
     import saragan_amd.optimization as opt
     from saragan_amd import parallel
     from saragan_amd.ExtendedEMA import ExtendedEMA
@@ -46,7 +47,8 @@ def _worker(rank, world, port, golden, q, backend='gloo'):
     L.set_random_source(L.InjectedRandom({k: v[sl].float() for k, v in fx['rnd'].items()}))
     alpha = ScalarVariable(fx['alpha'])
     og = parallel.DistributedOptimizer(opt.AdamOptimizer(ScalarVariable(1e-3), 0.0, 0.9))
-    od = parallel.DistributedOptimizer(opt.AdamOptimizer(ScalarVariable(1e-3), 0.0, 0.9))
+    od = parallel.DistributedOptimizer(opt.AdamOptimizer(ScalarVariable(1e-3), 0.0, 0.9),
+                                       op=parallel.Adasum if os.environ.get('SARAGAN_TEST_ADASUM') == '1' else parallel.Average)
     ph = opt.Placeholder([n, 1, 1, 1, 1])
     with use_store(store):
         tup = opt.optimize_step(og, od, generator, discriminator, ph, LATENT, alpha, fx['phase'], BASE_SHAPE, KERNEL_SPEC,
@@ -66,7 +68,9 @@ def _worker(rank, world, port, golden, q, backend='gloo'):
     if backend == 'nccl':
         assert torch.distributed.get_backend() == 'nccl' and torch.cuda.current_device() == rank
     exposed = og.distributed.exposed_ms() + od.distributed.exposed_ms()
-    assert len(exposed) == 2 and all(e >= 0 for e in exposed)
+    assert len(exposed) == (1 if os.environ.get('SARAGAN_TEST_ADASUM') == '1' else 2) and all(e >= 0 for e in exposed)
+    if extra_env and extra_env.get('SARAGAN_DP_FORCE') == '1':
+        assert torch.distributed.is_initialized() and torch.distributed.get_backend() == backend
     q.put((rank, {k: v.detach().cpu().numpy() for k, v in store.vars.items()}))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -93,3 +97,23 @@ def test_two_rank_step_equals_full_batch_oracle(golden_dir, backend):
         for r in range(world):
             np.testing.assert_allclose(res[r][k], ref.numpy(), rtol=1e-4, atol=3e-5, err_msg=f'rank {r} {k}')
         np.testing.assert_array_equal(res[0][k], res[1][k])   # replicas stay bit-identical
+
+
+@pytest.mark.parametrize('algo', ['allreduce', 'rs_ag', 'adasum'])
+def test_single_rank_rccl_collectives_execute(golden_dir, algo):
+    """One GPU cannot hold two RCCL ranks, but it can run every RCCL call of the N-rank path with a communicator of ONE rank
+    (SARAGAN_DP_FORCE=1): start-up, the hook-launched bucket collectives on RCCL's stream against the compute stream the
+    HIP kernels are enqueued on, broadcast, all three reduction forms.  The step must equal the oracle's full-batch step."""
+    from tests.stepfix import load_step_fixture
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    env = dict(SARAGAN_DP_FORCE='1', SARAGAN_DP_ALGO='allreduce' if algo == 'adasum' else algo, SARAGAN_BUCKET_MIB='1',
+               SARAGAN_TEST_ADASUM='1' if algo == 'adasum' else '0')
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), golden_dir, q, 'nccl', env))
+    p.start()
+    res = dict([q.get(timeout=300)])
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    fx = load_step_fixture(os.path.join(golden_dir, NAME), torch.float64)
+    for k, ref in fx['p1'].items():
+        np.testing.assert_allclose(res[0][k], ref.numpy(), rtol=1e-4, atol=3e-5, err_msg=k)

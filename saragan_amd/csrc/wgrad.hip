@@ -165,8 +165,12 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 }
 
 __global__ void wgrad_finalize_kernel(const float* __restrict__ dwt, float* __restrict__ dw, float coef, int taps,
-                                      int cin, int cout, int ciT, int coT, int nslab, int64_t slab) {
+                                      int cin, int cout, int ciT, int coT, int nslab, int64_t slab,
+                                      const float* __restrict__ bias_staged = nullptr, float* __restrict__ dbias = nullptr) {
   const int64_t total = (int64_t)taps * cin * cout;
+  // the bias gradient the kernel accumulated beside the tile (one memset clears both): out to the caller's buffer
+  if (bias_staged != nullptr && blockIdx.x == 0)
+    for (int c = threadIdx.x; c < cout; c += blockDim.x) dbias[c] = bias_staged[c];
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int co = (int)(i % cout);
     int64_t q = i / cout;
@@ -1605,13 +1609,20 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
   const bool det = sg_cfg().deterministic != 0;
   const size_t ns_max = det ? (size_t)wgrad_slab_count(s) : 1;
   hipError_t e = hipSuccess;
-  if (!det) {      // (reproducible mode: every block of the grid stores its whole slab, nothing to clear)
-    e = hipMemsetAsync(workspace, 0, tile_bytes, hs);
-    if (e == hipSuccess && dbias) e = hipMemsetAsync(dbias, 0, (size_t)s->cout * sizeof(float), hs);
+  // The kernels add the bias gradient to a staging row right behind the tile (inside the workspace: the fallback pass's
+  // region starts no later and is only used when no kernel summed the bias), so that ONE memset clears both; the
+  // finalize kernel copies it out.  (Two memsets per weight gradient were ~70 launches per step.)
+  const size_t tile_al = (tile_bytes + 255) & ~(size_t)255;
+  float* bias_staged = (!det && dbias) ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + tile_al) : nullptr;
+  if (bias_staged && tile_al + (size_t)s->cout * sizeof(float) > ns_max * wgrad_tile_bytes(s) + sg_bias_act_bwd_workspace(s->cout)) {
+    prof.done(SG_EWORKSPACE);
+    return SG_EWORKSPACE;
   }
+  if (!det)      // (reproducible mode: every block of the grid stores its whole slab, nothing to clear)
+    e = hipMemsetAsync(workspace, 0, bias_staged ? tile_al + (size_t)s->cout * sizeof(float) : tile_bytes, hs);
   if (e != hipSuccess) { prof.done((int)e); return (int)e; }
   WgradArgs a;
-  a.dbias = dbias;
+  a.dbias = bias_staged ? bias_staged : dbias;
   a.slab = det ? (int64_t)(wgrad_tile_bytes(s) / 4) : 0;
   a.bslab = det ? (int64_t)(wgrad_bias_slab_bytes(s) / 4) : 0;
   a.nslab = 1;
@@ -1652,7 +1663,7 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, hs, a.dwt, dw, coef, a.taps, s->cin,
-                       s->cout, a.ciT, a.coT, det ? a.nslab : 1, a.slab);
+                       s->cout, a.ciT, a.coT, det ? a.nslab : 1, a.slab, (const float*)((bias_staged && db_done) ? bias_staged : nullptr), dbias);
     if (det && dbias && db_done)
       hipLaunchKernelGGL(wgrad_bias_slabs_kernel, dim3((unsigned)sg_cdiv(s->cout, 256)), dim3(256), 0, hs, bias_slabs, dbias, s->cout,
                          a.nslab, a.bslab);

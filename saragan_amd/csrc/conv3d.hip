@@ -2803,8 +2803,13 @@ static int launch_pw_fwd(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st,
   if (s->cin <= 4 && s->cout % E == 0 && 256 % (s->cout / E) == 0 && s->cout / E <= 256 &&
       ((s->cout / E) & (s->cout / E - 1)) == 0) {
     const int rows = 256 / (s->cout / E);
-    int64_t nb = (nvox + rows - 1) / rows;
-    if (nb > 8192) nb = 8192;
+    // Grid: EIGHT trips per block (never fewer blocks than the 2048 a full chip holds).  This write stream is sensitive to
+    // how far apart the blocks in flight write: at 32 x 128 x 128, n32, 8192 blocks of 32 trips ran at 4.4 TB/s, 2048 of 128
+    // (all resident, in lockstep) at 5.1-5.6, 32768 of 8 at 6.1-6.2, 131072 of 2 at 4.0 (tools/pw_probe.py) -- blocks that
+    // live for a few trips are dispatched in order and sweep memory nearly sequentially.
+    const int64_t full = (nvox + rows - 1) / rows;
+    int64_t nb = (full + 7) / 8;
+    if (nb < 2048) nb = full < 2048 ? full : 2048;
     SG_KNAME("pw_fwd_small_cin<%s>", sg_tname<T>());
     switch (s->cin) {
       case 1: hipLaunchKernelGGL((pw_fwd_small_cin_kernel<T, 1>), dim3((unsigned)nb), dim3(256), 0, st, a, nvox); break;

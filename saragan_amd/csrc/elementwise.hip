@@ -50,6 +50,19 @@ inline int grid_for(int64_t items, int per_block = 256, int cap = 2048) {
   return (int)b;
 }
 
+// Grid of a streaming kernel sized in TRIPS per block (grid-stride loop, no per-block partial results; never fewer blocks
+// than the 2048 a full chip holds).  Swept over this file's kernels at their in-step shapes (2 / 4 / 8 / 16 trips against
+// the capped grids): sg_axpby gains 10 % with two trips (5.2-5.4 -> 5.9-6.0 TB/s); the others stay within noise of their
+// capped grids, which they keep.  (The write-dominated pointwise forward is the kernel this matters for: conv3d.hip.)
+inline int grid_trips(int64_t items, int per_block, int trips) {
+  int64_t full = (items + per_block - 1) / per_block;
+  if (full < 1) full = 1;
+  int64_t b = (full + trips - 1) / trips;
+  if (b < 2048) b = full < 2048 ? full : 2048;
+  if (b > (1 << 24)) b = 1 << 24;
+  return (int)b;
+}
+
 // ---------------------------------------------------------------------------------------------------
 template <typename T, bool VEC>
 __global__ void bias_act_fwd_kernel(const T* __restrict__ x, const float* __restrict__ bias, T* __restrict__ y,
@@ -1199,7 +1212,7 @@ extern "C" int sg_axpby(const void* a, const void* b, void* out, float wa, float
   if (!sg_aligned16(a) || !sg_aligned16(out) || (b && !sg_aligned16(b))) return SG_EALIGN;
   hipStream_t hs = sg_st(st);
   const int E = dt == SG_BF16 ? 8 : 4;
-  const int blocks = grid_for(numel / E + 1);
+  const int blocks = grid_trips(numel / E + 1, 256, 2);
 #define L(T) hipLaunchKernelGGL((axpby_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)a, (const T*)b, (T*)out, wa, wb, numel)
   SG_DISPATCH(dt, L(bf16_t), L(float));
 #undef L

@@ -206,42 +206,46 @@ static int conv_shape_ok_w(const sg_conv_shape* s) {
 // image channels; networks/ops.py:239-247): dw[ci][co] = sum_v x[v][ci] * dy[v][co] is a column reduction,
 // HBM-bound.  "small" has cs <= 4 channels, "big" has cb channels (16-byte pieces, pieces | 256).
 // ------------------------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int CS = 0, int U = 4>      // CS: the small side's channel count at compile time (1: the image layers), 0: run time, <= 4
 __global__ __launch_bounds__(256) void pw_wgrad_partial_kernel(const T* __restrict__ small, const T* __restrict__ big,
-                                                               float* __restrict__ part, int64_t nvox, int cs, int cb,
+                                                               float* __restrict__ part, int64_t nvox, int cs_rt, int cb,
                                                                int ones_extra, T* __restrict__ dsmall = nullptr,
                                                                const float* __restrict__ wsm = nullptr) {
   // dsmall (optional, [nvox][cs]): the data gradient for the small side from the same read of `big` (= dy),
   // dsmall[v][j] = sum_c big[v][c] * wsm[j][c] (sg_conv3d_pw_bwd)
   constexpr int E = 16 / (int)sizeof(T);
+  constexpr int CM = CS ? CS : 4;                // rows of sums kept in registers (+ 1: the ones row)
+  const int cs = CS ? CS : cs_rt;
   __shared__ float red[256 * E];
   const int P = cb / E, rows = 256 / P;
   const int p = threadIdx.x % P, rr = threadIdx.x / P;
-  float wreg[4][E];
+  // One-channel images are the case the training step runs: with the four-channel arrays (72 registers of sums and
+  // weights) the kernel held 123 VGPRs -- four blocks per CU, 48 KiB in flight per CU where the memory system wants ~60:
+  // 3.8-4.2 TB/s.  Sized for ONE channel it fits eight.
+  float wreg[CM][E];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < CM; ++j)
 #pragma unroll
     for (int e = 0; e < E; ++e) wreg[j][e] = (dsmall != nullptr && j < cs) ? wsm[j * cb + p * E + e] : 0.f;
-  float s[5][E];   // row cs (when ones_extra): the big side's plain column sums (bias gradient)
+  float s[CM + 1][E];   // row CM (when ones_extra): the big side's plain column sums (bias gradient)
 #pragma unroll
-  for (int j = 0; j < 5; ++j)
+  for (int j = 0; j < CM + 1; ++j)
 #pragma unroll
     for (int e = 0; e < E; ++e) s[j][e] = 0.f;
   const int csx = cs + (ones_extra ? 1 : 0);
   // four voxel rows per trip: the loads are independent, and one 16-byte load per lane per trip left the memory
   // system mostly idle (2.4 TB/s)
-  constexpr int U = 4;
-  const int64_t step = rows;                     // the four rows of a trip are adjacent voxel groups (one contiguous stretch)
+  const int64_t step = rows;                     // the U rows of a trip are adjacent voxel groups (one contiguous stretch)
   for (int64_t v0 = (int64_t)blockIdx.x * U * rows + rr; v0 < nvox; v0 += (int64_t)gridDim.x * U * rows) {
     u32x4 raw[U];
-    float sv[U][4];
+    float sv[U][CM];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t v = v0 + u * step;
       const bool live = v < nvox;
       raw[u] = live ? *reinterpret_cast<const u32x4*>(big + v * cb + (int64_t)p * E) : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) sv[u][j] = (live && j < cs) ? sg_traits<T>::to_f(small[v * cs + j]) : 0.f;
+      for (int j = 0; j < CM; ++j) sv[u][j] = (live && j < cs) ? sg_traits<T>::to_f(small[v * cs + j]) : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_partial_kernel(const T* __restri
 #pragma unroll
       for (int e = 0; e < E; ++e) bv[e] = sg_traits<T>::to_f(bt[e]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < CM; ++j) {
         if (j < cs) {
 #pragma unroll
           for (int e = 0; e < E; ++e) s[j][e] += sv[u][j] * bv[e];
@@ -258,12 +262,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_partial_kernel(const T* __restri
       }
       if (ones_extra) {   // dead rows were loaded as zeros
 #pragma unroll
-        for (int e = 0; e < E; ++e) s[4][e] += bv[e];
+        for (int e = 0; e < E; ++e) s[CM][e] += bv[e];
       }
       if (dsmall != nullptr) {   // uniform; the P lanes of a voxel are adjacent and run the same trips
         const int64_t v = v0 + u * step;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < CM; ++j) {
           if (j < cs) {
             float dsum = 0.f;
 #pragma unroll
@@ -281,18 +285,22 @@ __global__ __launch_bounds__(256) void pw_wgrad_partial_kernel(const T* __restri
     }
   }
   for (int j = 0; j < csx; ++j) {
-    const int js = j < cs ? j : 4;     // the ones row lives in slot 4
+    const int js = j < cs ? j : CM;    // the ones row lives in slot CM
     __syncthreads();
 #pragma unroll
-    for (int e = 0; e < E; ++e) red[threadIdx.x * E + e] = js == 0 ? s[0][e] : js == 1 ? s[1][e] : js == 2 ? s[2][e] : js == 3 ? s[3][e] : s[4][e];
-    __syncthreads();
-    if (threadIdx.x < P) {
+    for (int e = 0; e < E; ++e) {
+      float val = s[CM][e];
 #pragma unroll
-      for (int e = 0; e < E; ++e) {
-        float t = 0.f;
-        for (int k = 0; k < rows; ++k) t += red[(k * P + threadIdx.x) * E + e];
-        part[((int64_t)blockIdx.x * csx + j) * cb + threadIdx.x * E + e] = t;
-      }
+      for (int jj = 0; jj < CM; ++jj) val = js == jj ? s[jj][e] : val;
+      red[threadIdx.x * E + e] = val;
+    }
+    __syncthreads();
+    // column e of piece q summed over the block's `rows` voxel rows: thread (q, e-group) instead of P threads doing it all
+    for (int idx = threadIdx.x; idx < P * E; idx += 256) {
+      const int q = idx / E, e = idx - q * E;
+      float t = 0.f;
+      for (int k = 0; k < rows; ++k) t += red[(k * P + q) * E + e];
+      part[((int64_t)blockIdx.x * csx + j) * cb + q * E + e] = t;
     }
   }
 }
@@ -320,6 +328,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_final_kernel(const float* __rest
 }
 
 static size_t wgrad_tile_bytes(const sg_conv_shape* s);
+static constexpr int PW_WGRAD_MAX_BLOCKS = 1024;   // per-block partial sums of the pointwise weight gradient (pw_wgrad_partial)
 // upper bound of the slabs a launcher writes (generic kernel: gridDim.x <= cdiv(512, pairs); ping-pong kernels: two wave
 // groups per block, gridDim.x <= 256 / pairs and >= 8)
 static int wgrad_slab_count(const sg_conv_shape* s) {
@@ -1545,7 +1554,8 @@ static int launch_wgrad_planes(WgradArgs& a, const sg_conv_shape* s, hipStream_t
 
 static size_t wgrad_tile_bytes(const sg_conv_shape* s) {
   const size_t need = (size_t)(s->kd * s->kh * s->kw) * sg_cdiv(s->cin, 32) * sg_cdiv(s->cout, 32) * 4096;
-  const size_t pw = (size_t)1024 * 5 * (size_t)(s->cin > s->cout ? s->cin : s->cout) * sizeof(float);
+  const bool pointwise = s->kd * s->kh * s->kw == 1 && (s->cin <= 4 || s->cout <= 4);
+  const size_t pw = pointwise ? (size_t)PW_WGRAD_MAX_BLOCKS * 5 * (size_t)(s->cin > s->cout ? s->cin : s->cout) * sizeof(float) : 0;
   return ((need > pw ? need : pw) + 255) & ~(size_t)255;
 }
 
@@ -1578,12 +1588,17 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
       const int64_t nvox = (int64_t)s->n * s->d * s->h * s->w;
       const int rows = 256 / (cb / E);
       int64_t nb = (nvox + rows - 1) / rows;
-      if (nb > 1024) nb = 1024;
+      // (one round of four blocks per CU: measured at 32 x 128 x 128, 768 / 1024 / 1536 / 2048 blocks read 4.7 / 5.2 / 4.9 /
+      // 3.9 TB/s -- every block ends in an LDS reduction and a row of partial sums, tools/pww_probe.py)
+      if (nb > PW_WGRAD_MAX_BLOCKS) nb = PW_WGRAD_MAX_BLOCKS;
       float* part = reinterpret_cast<float*>(workspace);
       const int ones = (dbias != nullptr && small_is_cin) ? 1 : 0;   // the big side is dy: its column sums are the bias gradient
       SG_KNAME("pw_wgrad_partial");
       if (pw_dx && !small_is_cin) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }
-      if (dt == SG_BF16)
+      if (dt == SG_BF16 && cs == 1)
+        hipLaunchKernelGGL((pw_wgrad_partial_kernel<bf16_t, 1>), dim3((unsigned)nb), dim3(256), 0, hs, (const bf16_t*)sm,
+                           (const bf16_t*)bg, part, nvox, cs, cb, ones, (bf16_t*)pw_dx, pw_wmat);
+      else if (dt == SG_BF16)
         hipLaunchKernelGGL(pw_wgrad_partial_kernel<bf16_t>, dim3((unsigned)nb), dim3(256), 0, hs, (const bf16_t*)sm,
                            (const bf16_t*)bg, part, nvox, cs, cb, ones, (bf16_t*)pw_dx, pw_wmat);
       else

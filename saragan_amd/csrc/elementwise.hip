@@ -925,7 +925,7 @@ extern "C" int sg_bias_act_fwd(const void* x, const float* bias, void* y, int64_
   return SG_OK;
 }
 
-static const int kBwdBlocks = 1024;
+static const int kBwdBlocks = 1024;      // (swept 512 / 1024 / 2048 / 4096 at the in-step shapes: 1024 is the best compromise, tools/ew_roofline.py)
 extern "C" size_t sg_bias_act_bwd_workspace(int32_t c) { return (size_t)kBwdBlocks * (size_t)(c > 0 ? c : 0) * sizeof(float); }
 
 static int bias_act_bwd_launch(const void* dy, const void* y, const uint32_t* words, void* dx, float* dbias,

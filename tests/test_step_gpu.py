@@ -329,3 +329,40 @@ def test_other_optimizers_match_oracle(golden_dir, kind, strategy):
                                        err_msg=f'{kind} step {step} {k}')
             np.testing.assert_allclose(ema.average(k).double().cpu().numpy(), shadow[k].numpy(), rtol=2e-4, atol=atol,
                                        err_msg=f'{kind} ema step {step} {k}')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_a_step_leaves_no_device_memory_in_reference_cycles(golden_dir, dtype):
+    """A training step must free its activations by reference counting alone: a cycle (the fused pixel-norm stage once held
+    its own output through its ActInfo) keeps device tensors alive until Python's cyclic collector happens to run -- 1.7 GiB
+    per step at the benchmarked size, an out-of-memory error after a few hundred steps."""
+    import gc
+    fx = load_step_fixture(os.path.join(golden_dir, FIXTURES[3]), torch.float64)      # phase 3: fused pixel-norm stages
+    store, tup, ph, ema, sess = _build(fx, dtype)
+    feed = {ph: fx['real'].float()}
+    ema_op = ema.apply()
+
+    def step():
+        sess.run([tup[0], tup[1]], feed_dict=feed)
+        sess.run(ema_op)
+    step()
+    step()
+    torch.cuda.synchronize()
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        base = torch.cuda.memory_allocated()
+        step()
+        torch.cuda.synchronize()
+        after = torch.cuda.memory_allocated()
+        gc.set_debug(gc.DEBUG_SAVEALL)
+        gc.collect()
+        gc.set_debug(0)
+        held = [o for o in gc.garbage if torch.is_tensor(o) and o.is_cuda]
+        gc.garbage.clear()
+    finally:
+        if was:
+            gc.enable()
+    assert not held, [tuple(t.shape) for t in held]
+    assert after == base, (base, after)

@@ -151,3 +151,23 @@ def test_gpu_metric_kernels_through_the_c_abi():
     np.testing.assert_allclose(got, want, rtol=1e-4)
     with pytest.raises(RuntimeError):
         G.pyr_down(torch.zeros(1, 1, 4, 4, 4))                                   # CPU tensor: no fallback
+
+
+@pytest.mark.gpu
+def test_gpu_swd_at_the_benchmarked_volume_size():
+    """get_swd_for_volumes with the reference's default arguments (3 x 9 x 9 neighbourhoods, 512 per volume, 8 x 512
+    directions) on 32 x 128 x 128 volumes: four pyramid levels (128 .. 16), 1536 descriptors per level."""
+    from saragan_amd.metrics import swd as G
+    rng = np.random.default_rng(21)
+    x = rng.normal(size=(3, 1, 32, 128, 128)).astype(np.float32)
+    y = (0.8 * x + 0.6 * rng.normal(size=x.shape)).astype(np.float32) + 0.05
+    np.random.seed(17)
+    want = M.get_swd_for_volumes(x.copy(), y.copy())
+    np.random.seed(17)
+    got = G.get_swd_for_volumes(x, y)
+    assert len(got) == len(want) == 5
+    np.testing.assert_allclose(got, want, rtol=2e-4)
+    from saragan_amd.metrics import skim_metrics as S
+    xi, yi = (x * 300).astype(np.int16), (y * 300).astype(np.int16)
+    np.testing.assert_allclose(S.get_ssim(xi[:2], yi[:2]), M.get_ssim(xi[:2], yi[:2]), rtol=1e-9, atol=1e-12)
+    assert abs(S.get_psnr(xi, yi) - M.peak_signal_noise_ratio(xi, yi, 3072)) < 1e-9

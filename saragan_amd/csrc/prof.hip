@@ -14,7 +14,7 @@ bool g_filter = false;
 int g_fkind = 0;
 sg_conv_shape g_fshape;
 std::vector<Rec> g_recs;
-const char* kVersion = "saragan_hip 0.3 (gfx950)";
+const char* kVersion = "saragan_hip 0.4 (gfx950)";
 }  // namespace
 
 bool sg_prof_on() { return g_on; }

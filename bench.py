@@ -542,8 +542,13 @@ def main():
     ncal = 2
     barrier()
     lib.sg_prof_enable(1)
+    hipgraph = os.environ.get('SARAGAN_HIPGRAPH', '0') == '1'     # opt-in: the step's forward + backward replayed as one hipGraph
+    if hipgraph:
+        os.environ['SARAGAN_HIPGRAPH'] = '0'      # the per-launch event bracketing only exists on the eager path
     for i in range(ncal):
         step(args.warmup + i)
+    if hipgraph:
+        os.environ['SARAGAN_HIPGRAPH'] = '1'
     barrier()
     table = collect()
     lib.sg_prof_enable(0)
@@ -646,7 +651,7 @@ def main():
                                         not int(os.environ.get('SARAGAN_NO_LERP_PRUNE', '0'))) else 'computed',
                            timed_region_s=dict(wall=round(sw.wall, 4), hip_events=round(sw.gpu, 4)),
                            local_batch=args.batch, global_batch=args.batch * world, latent_dim=args.latent,
-                           parallelism=f'dp{world}', collective=comm, settle=preheat, step_gflop_per_volume=round(step_gf, 1),
+                           parallelism=f'dp{world}', collective=comm, settle=preheat, hipgraph=hipgraph, step_gflop_per_volume=round(step_gf, 1),
                            step_mfma_tflops=round(value * step_gf / 1e3 / world, 2),
                            conv_kernel_ms_per_step=round(total_conv_ms / args.steps, 3),
                            conv_ms_per_step_by_kernel={k.decode(): round(v / ncal, 3) for k, v in

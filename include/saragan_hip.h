@@ -276,6 +276,10 @@ int sg_axpby(const void* a, const void* b, void* out, float wa, float wb, int64_
  * (instance noise, networks/loss.py:122-123). */
 int sg_add_noise(const void* x, void* out, float stddev, uint64_t seed, uint64_t offset, int64_t numel,
                  sg_dtype dt, sg_stream_t st);
+/* The same with the Philox offset read from DEVICE memory (one uint64) and, after the launch, advanced by `bump` on the
+ * device: a captured hipGraph of the training step (SARAGAN_HIPGRAPH=1) draws fresh instance noise at every replay. */
+int sg_add_noise_dev(const void* x, void* out, float stddev, uint64_t seed, uint64_t* offset_dev, uint64_t bump,
+                     int64_t numel, sg_dtype dt, sg_stream_t st);
 /* out[n*w_extent + w] = sum_{d,h,c} g[n,d,h,w,c]^2   (the reduce_sum of networks/loss.py:140, quirk Q1:
  * axes (1,2,3) of NCDHW = c,d,h).  out f32 [n*w], overwritten. */
 int sg_sumsq_ndhwc_keep_w(const void* g, float* out, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,

@@ -727,7 +727,8 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
 
 template <typename T>
 __global__ void add_noise_kernel(const T* __restrict__ x, T* __restrict__ out, float stddev, uint64_t seed,
-                                 uint64_t offset, int64_t numel) {
+                                 uint64_t offset, int64_t numel, const uint64_t* __restrict__ offset_dev = nullptr) {
+  if (offset_dev != nullptr) offset = *offset_dev;     // (sg_add_noise_dev: the counter lives on the device, graph replays move on)
   const int64_t ngroups = (numel + 3) / 4;
   for (int64_t gi = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; gi < ngroups; gi += (int64_t)gridDim.x * blockDim.x) {
     const uint64_t ctr = (uint64_t)gi + offset;
@@ -1229,6 +1230,24 @@ extern "C" int sg_add_noise(const void* x, void* out, float stddev, uint64_t see
   SG_DISPATCH(dt, L(bf16_t), L(float));
 #undef L
   SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+__global__ void counter_add_kernel(uint64_t* ctr, uint64_t inc) { *ctr += inc; }
+
+extern "C" int sg_add_noise_dev(const void* x, void* out, float stddev, uint64_t seed, uint64_t* offset_dev, uint64_t bump,
+                                int64_t numel, sg_dtype dt, sg_stream_t st) {
+  if (!x || !out || !offset_dev || numel < 1) return SG_EINVAL;
+  hipStream_t hs = sg_st(st);
+  const int blocks = grid_for((numel + 3) / 4);
+#define L(T) hipLaunchKernelGGL((add_noise_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)x, (T*)out, stddev, seed, (uint64_t)0, numel, (const uint64_t*)offset_dev)
+  SG_DISPATCH(dt, L(bf16_t), L(float));
+#undef L
+  SG_LAUNCH_CHECK();
+  if (bump) {      // stream order: every block of the launch above has read the counter before this runs
+    hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(1), 0, hs, offset_dev, bump);
+    SG_LAUNCH_CHECK();
+  }
   return SG_OK;
 }
 

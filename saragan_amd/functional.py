@@ -1258,13 +1258,19 @@ class _Axpby(torch.autograd.Function):
 class _AddNoise(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, stddev, seed, offset):
+        """offset: a Python int, or a one-element int64 DEVICE tensor holding the Philox offset (read by the kernel and then
+        advanced by 1 << 40 on the device: the form a captured step uses, sg_add_noise_dev)."""
         _note_all(x, stddev, seed, offset)
         lib = _lib.load()
         _req_cuda(x)
         x = ndhwc(x)
         out = torch.empty_like(x)
-        check(lib.sg_add_noise(_ptr(x), _ptr(out), float(stddev), int(seed), int(offset), x.numel(), _dt(x),
-                               _stream()), 'sg_add_noise')
+        if torch.is_tensor(offset):
+            check(lib.sg_add_noise_dev(_ptr(x), _ptr(out), float(stddev), int(seed), _ptr(offset), 1 << 40, x.numel(), _dt(x),
+                                       _stream()), 'sg_add_noise_dev')
+        else:
+            check(lib.sg_add_noise(_ptr(x), _ptr(out), float(stddev), int(seed), int(offset), x.numel(), _dt(x),
+                                   _stream()), 'sg_add_noise')
         return out
 
     @staticmethod

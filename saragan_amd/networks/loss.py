@@ -47,6 +47,45 @@ class InjectedRandom(RandomSource):
         return F.lerp(x, noise.contiguous(memory_format=torch.channels_last_3d), 1.0, float(stddev))
 
 
+class StaticRandom:
+    """The randomness of a CAPTURED training step (optimization.StepGraph, SARAGAN_HIPGRAPH=1): latents and the gradient
+    penalty's mixing weights are drawn from `base`'s generator OUTSIDE the captured region into fixed buffers (`draw()`, same
+    order and shapes as the eager step: bit-identical values), the instance noise reads its Philox offset from a device
+    counter that the captured launches advance themselves.  `after_replay()` keeps `base.calls` in step, so that an eager
+    step that follows continues the same sequence."""
+
+    def __init__(self, base, n, latent_dim, device):
+        self.base, self.n, self.latent_dim = base, int(n), int(latent_dim)
+        self.z = torch.empty(self.n, self.latent_dim, device=device)
+        self.g = torch.empty(self.n, 1, 1, 1, 1, device=device)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=device)
+        self.noise_calls = 0         # add_noise calls of one step (counted while capturing)
+        self.counting = False
+
+    def draw(self):
+        self.z.copy_(self.base.latent(self.n, self.latent_dim, self.z.device))
+        self.g.copy_(self.base.gamma(self.n, self.g.device))
+
+    def sync_counter(self):
+        self.counter.fill_((self.base.calls + 1) << 40)
+
+    def latent(self, n, latent_dim, device):
+        assert (int(n), int(latent_dim)) == (self.n, self.latent_dim)
+        return self.z
+
+    def gamma(self, n, device):
+        assert int(n) == self.n
+        return self.g
+
+    def add_noise(self, x, stddev, tag):
+        if self.counting:
+            self.noise_calls += 1
+        return F.add_noise(x, stddev, self.base.seed, offset=self.counter)
+
+    def after_replay(self):
+        self.base.calls += self.noise_calls
+
+
 _RANDOM = {'src': None}
 _LINK = {'on': False}
 _NO_BATCHED_D = bool(int(os.environ.get('SARAGAN_NO_BATCHED_D', '0')))   # diagnostic: separate D(real) / D(fake) passes

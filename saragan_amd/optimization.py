@@ -8,6 +8,7 @@ gradient penalty), backward, gradient all-reduce (if the optimizer is wrapped by
 parallel.DistributedOptimizer), optional global-norm clipping, and the fused TF-Adam(+EMA) kernel."""
 import importlib
 import math
+import os
 
 import numpy as np
 import torch
@@ -16,7 +17,7 @@ from . import functional as F
 from .networks.loss import forward_discriminator, forward_generator, forward_simultaneous, linear_generator_link
 from .networks.ops import Op, ScalarVariable
 from .networks.pgan.variables import pgan_variable_shapes
-from .varstore import current_store, use_store
+from .varstore import compute_dtype, current_store, use_store
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -230,20 +231,10 @@ class StepGraph:
             net_args = (c['latent_dim'], alpha, c['phase'], c['base_shape'], c['kernel_spec'], c['filter_spec'],
                         c['activation'], c['leakiness'], c['loss_fn'])
             if c['optim_strategy'] == 'simultaneous':
-                nets = {self.trains[t]['net'] for t in train_ids}
-                if nets >= {'generator', 'discriminator'}:
-                    with linear_generator_link():   # wgan: G's gradient through D comes out of D's own backward
-                        gen_loss, disc_loss, gp_loss, gen_sample = forward_simultaneous(
-                            c['generator'], c['discriminator'], real, *net_args, c['gp_weight'], c['noise_stddev'])
+                if self._capturable(train_ids, real):
+                    out, pend = self._replay_or_capture(real, train_ids, net_args, alpha)
                 else:
-                    gen_loss, disc_loss, gp_loss, gen_sample = forward_simultaneous(
-                        c['generator'], c['discriminator'], real, *net_args, c['gp_weight'], c['noise_stddev'])
-                out.update(gen_loss=gen_loss, disc_loss=disc_loss, gp_loss=gp_loss, gen_sample=gen_sample)
-                if hasattr(gen_loss, 'sg_link'):    # the discriminator's backward must run first: it feeds G's
-                    train_ids = sorted(train_ids, key=lambda t: self.trains[t]['net'] != 'discriminator')
-                pend = []
-                for j, tid in enumerate(train_ids):   # both gradients at the pre-step weights (optimization.py:128-163)
-                    pend.append((tid, self._backward(tid, out, retain=j + 1 < len(train_ids))))
+                    pend = self._compute_simultaneous(real, train_ids, net_args, out)
                 for tid, info in pend:
                     self._finish(tid, info, out, apply=tid in want_train)
             else:                               # alternate: D step, then G forward on the updated D
@@ -273,6 +264,87 @@ class StepGraph:
                 v = out[f.key]
                 res.append(v.detach() if torch.is_tensor(v) else v)
         return res
+
+    def _compute_simultaneous(self, real, train_ids, net_args, out):
+        """Forward pass and both backward passes of a 'simultaneous' step (no optimizer): fills `out`, returns the per-net
+        records `_finish` needs."""
+        c = self.cfg
+        nets = {self.trains[t]['net'] for t in train_ids}
+        if nets >= {'generator', 'discriminator'}:
+            with linear_generator_link():   # wgan: G's gradient through D comes out of D's own backward
+                gen_loss, disc_loss, gp_loss, gen_sample = forward_simultaneous(
+                    c['generator'], c['discriminator'], real, *net_args, c['gp_weight'], c['noise_stddev'])
+        else:
+            gen_loss, disc_loss, gp_loss, gen_sample = forward_simultaneous(
+                c['generator'], c['discriminator'], real, *net_args, c['gp_weight'], c['noise_stddev'])
+        out.update(gen_loss=gen_loss, disc_loss=disc_loss, gp_loss=gp_loss, gen_sample=gen_sample)
+        if hasattr(gen_loss, 'sg_link'):    # the discriminator's backward must run first: it feeds G's
+            train_ids = sorted(train_ids, key=lambda t: self.trains[t]['net'] != 'discriminator')
+        pend = []
+        for j, tid in enumerate(train_ids):   # both gradients at the pre-step weights (optimization.py:128-163)
+            pend.append((tid, self._backward(tid, out, retain=j + 1 < len(train_ids))))
+        return pend
+
+    # -- hipGraph capture of the step (opt-in: SARAGAN_HIPGRAPH=1) ------------------------------------------------
+    # The small phases and the 2-D configuration are HOST-bound: ~600-1500 kernel launches per step through Python,
+    # autograd and ctypes (config 5: 13-23 ms of wall time for 13 ms of kernels).  Forward and both backward passes
+    # are captured ONCE into a hipGraph (torch.cuda.graph: the C-ABI launches go to torch's current stream, which is
+    # the capturing one; workspaces come from the graph's private pool) and replayed as a single launch; the two
+    # optimizer kernels stay eager, so Adam's host-side bias correction and the learning-rate schedule never enter the
+    # graph.  What varies per step is kept out of the captured region or on the device: the batch and the latents /
+    # mixing weights live in fixed buffers refilled before each replay (loss.StaticRandom), the instance noise reads
+    # its Philox offset from a device counter.  The graph is keyed by everything that is baked in (fetch set, alpha,
+    # batch shape, dtype) and captured after two eager steps of the same key (every lazy one-time call has happened).
+    def _capturable(self, train_ids, real):
+        if os.environ.get('SARAGAN_HIPGRAPH', '0') != '1' or not real.is_cuda:
+            return False
+        nets = {self.trains[t]['net'] for t in train_ids}
+        if not nets >= {'generator', 'discriminator'}:
+            return False                         # the full training step only
+        if any(self.trains[t]['optimizer'].distributed is not None for t in train_ids):
+            return False                         # the all-reduce hooks stay eager
+        from .networks import loss as L
+        return type(L._rng(real.device)) is L.RandomSource
+
+    def _replay_or_capture(self, real, train_ids, net_args, alpha):
+        from .networks import loss as L
+        key = (tuple(train_ids), frozenset(self._wanted), float(alpha), tuple(real.shape), str(compute_dtype()))
+        caps = self.__dict__.setdefault('_captures', {})
+        ent = caps.setdefault(key, dict(eager=0))
+        base = L._rng(real.device)
+        if 'graph' not in ent and ent['eager'] < 2:          # warm-up: the ordinary path
+            ent['eager'] += 1
+            out = {}
+            return out, self._compute_simultaneous(real, train_ids, net_args, out)
+        if 'graph' not in ent:
+            ent['real'] = real.clone()
+            ent['rnd'] = L.StaticRandom(base, real.shape[0], self.cfg['latent_dim'], real.device)
+            ent['rnd'].draw()
+            ent['rnd'].sync_counter()
+            ent['out'] = {}
+            g = torch.cuda.CUDAGraph()
+            L.set_random_source(ent['rnd'])
+            ent['rnd'].counting = True
+            # The parameters' AccumulateGrad nodes remember the stream they were created on and are kept alive by the last
+            # step's autograd graph: reused inside the capture they would run on the (non-capturing) default stream --
+            # hipStreamEndCapture then crashes.  Without a live graph they are created afresh, on the capturing stream.
+            self.last = None
+            try:
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    ent['pend'] = self._compute_simultaneous(ent['real'], train_ids, net_args, ent['out'])
+            finally:
+                ent['rnd'].counting = False
+                L.set_random_source(base)
+                F.clear_pack_cache()
+            ent['graph'] = g
+        else:
+            ent['real'].copy_(real, non_blocking=True)
+            ent['rnd'].draw()
+            ent['rnd'].sync_counter()
+        ent['graph'].replay()
+        ent['rnd'].after_replay()
+        return ent['out'], ent['pend']
 
     def _backward(self, tid, out, retain=False):
         tr = self.trains[tid]

@@ -310,6 +310,9 @@ class StepGraph:
         from .networks import loss as L
         key = (tuple(train_ids), frozenset(self._wanted), float(alpha), tuple(real.shape), str(compute_dtype()))
         caps = self.__dict__.setdefault('_captures', {})
+        if key not in caps and len(caps) >= 64:      # a fade-in phase moves alpha every step: forget keys that never repeated
+            for k in [k for k, e in caps.items() if 'graph' not in e]:
+                del caps[k]
         ent = caps.setdefault(key, dict(eager=0))
         base = L._rng(real.device)
         if 'graph' not in ent and ent['eager'] < 2:          # warm-up: the ordinary path
@@ -337,6 +340,10 @@ class StepGraph:
                 ent['rnd'].counting = False
                 L.set_random_source(base)
                 F.clear_pack_cache()
+            # replays need the captured launches and the output buffers, not the Python autograd graph: without it the
+            # AccumulateGrad nodes made on the capturing stream go away too (a later eager step would find them on the
+            # wrong stream and synchronise)
+            ent['out'] = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in ent['out'].items()}
             ent['graph'] = g
         else:
             ent['real'].copy_(real, non_blocking=True)

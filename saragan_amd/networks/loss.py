@@ -30,6 +30,17 @@ class RandomSource:
         return F.add_noise(x, stddev, self.seed, offset=self.calls << 40)
 
 
+_DEVICE_RANDOM = RandomSource      # (the class itself: tests substitute `RandomSource` with host-drawn variants)
+
+
+def graph_safe(src):
+    """Whether a captured step (loss.StaticRandom) can stand in for `src`: the device-side source with none of its draws
+    overridden."""
+    return (type(src) is _DEVICE_RANDOM or (isinstance(src, _DEVICE_RANDOM) and all(
+        getattr(type(src), m) is getattr(_DEVICE_RANDOM, m) for m in ('latent', 'gamma', 'add_noise')))) and \
+        hasattr(src, 'calls') and hasattr(src, 'gen')
+
+
 class InjectedRandom(RandomSource):
     """Replays stored tensors: keys z, noise_real, noise_fake, gamma (oracle.pgan_oracle.draw_randomness)."""
 

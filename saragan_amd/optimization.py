@@ -304,7 +304,7 @@ class StepGraph:
         if any(self.trains[t]['optimizer'].distributed is not None for t in train_ids):
             return False                         # the all-reduce hooks stay eager
         from .networks import loss as L
-        return type(L._rng(real.device)) is L.RandomSource
+        return L.graph_safe(L._rng(real.device))
 
     def _replay_or_capture(self, real, train_ids, net_args, alpha):
         from .networks import loss as L

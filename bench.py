@@ -399,7 +399,7 @@ def restore_state(cfg, snap):
     F.clear_pack_cache()
 
 
-def loader_leg(args, cfg, device, nsteps, barrier):
+def loader_leg(args, cfg, device, nsteps, barrier, snap=None):
     """The same step with the data path inside the timed loop (SURVEY section 8d "loader included"): synthetic
     `{xy}x{xy}/NNNN.npy` int16 volumes on local disk, NumpyPathDataset drawing batches, PinnedPrefetcher loading,
     normalising and copying them host-to-device on a side stream while the step runs."""
@@ -425,6 +425,9 @@ def loader_leg(args, cfg, device, nsteps, barrier):
         # (profiles/r02_clock_trace.txt)
         for i in range(max(30, args.warmup + 5)):
             step(i)
+        if snap is not None:      # those steps were for the board: the timed ones train on from the post-warm-up state, as the
+            restore_state(cfg, snap)      # main loop's do (30 more steps of WGAN-GP at lr 1e-3 on noise left the finite range
+            #                               in about one run in five, and the leg then reports no number)
         dt = timed_steps(step, nsteps, barrier)
         la = leg_losses(cfg, pf.next())
         pf.close()
@@ -680,7 +683,7 @@ def main():
         extras = {}
         try:
             restore_state(cfg, snap)      # (every leg starts where the main loop did: after the warm-up)
-            extras['loader_in_loop'] = loader_leg(args, cfg, device, max(3, args.steps), barrier)
+            extras['loader_in_loop'] = loader_leg(args, cfg, device, max(3, args.steps), barrier, snap)
             if float(args.alpha) in (0.0, 1.0):
                 # the same step with the faded-out lerp branch computed as the reference's graph does (it contributes exact
                 # zeros: DESIGN.md 4.5); `value` is measured with the branch pruned

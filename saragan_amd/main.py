@@ -62,6 +62,8 @@ def build_parser():
     p.add_argument('--gp_weight', type=float, default=1)
     p.add_argument('--optim_strategy', default='simultaneous', choices=['simultaneous', 'alternate'])
     p.add_argument('--use_adasum', default=False, action='store_true')
+    p.add_argument('--hipgraph', default=False, action='store_true',
+                   help='(not in the reference) replay forward + backward of the training step as one hipGraph: SARAGAN_HIPGRAPH=1')
     p.add_argument('--ema_beta', type=float, default=0.99)
     p.add_argument('--noise_stddev', type=float, required=True)
     p.add_argument('--optimizer', type=none_or_str, choices=[None, 'Adam', 'SGD', 'Momentum', 'Adadelta'], default='Adam')
@@ -120,6 +122,9 @@ def main(argv=None):
     if unknown:
         print(f'ignoring flags outside the hot path: {unknown}')
     args = finalize_args(args)
+    if getattr(args, 'hipgraph', False):
+        import os
+        os.environ['SARAGAN_HIPGRAPH'] = '1'
     from .train import run_training
     out = run_training(args, max_steps_per_phase=args.max_steps_per_phase)
     for ph, st in out['stats'].items():

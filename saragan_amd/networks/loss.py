@@ -74,11 +74,13 @@ class StaticRandom:
         self.counting = False
 
     def draw(self):
-        self.z.copy_(self.base.latent(self.n, self.latent_dim, self.z.device))
-        self.g.copy_(self.base.gamma(self.n, self.g.device))
+        # (straight into the fixed buffers: the same draws from the same generator as RandomSource.latent / .gamma)
+        torch.randn(self.n, self.latent_dim, generator=self.base.gen, out=self.z)
+        torch.rand(self.n, 1, 1, 1, 1, generator=self.base.gen, out=self.g)
 
     def sync_counter(self):
-        self.counter.fill_((self.base.calls + 1) << 40)
+        if getattr(self, '_synced_calls', None) != self.base.calls:      # (only after eager steps moved the host count on)
+            self.counter.fill_((self.base.calls + 1) << 40)
 
     def latent(self, n, latent_dim, device):
         assert (int(n), int(latent_dim)) == (self.n, self.latent_dim)
@@ -95,6 +97,7 @@ class StaticRandom:
 
     def after_replay(self):
         self.base.calls += self.noise_calls
+        self._synced_calls = self.base.calls      # the device counter moved on by the same amount
 
 
 _RANDOM = {'src': None}

@@ -8,8 +8,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libsaragan_hip.so')
-SOURCES = ['conv3d.hip', 'wgrad.hip', 'elementwise.hip', 'optim.hip', 'prof.hip', 'small.hip', 'subpix.hip', 'gemm.hip', 'metrics.hip']
-HEADERS = ['common.h', 'prof.h', os.path.join('..', '..', 'include', 'saragan_hip.h')]
+SOURCES = ['conv3d.hip', 'conv3p.hip', 'wgrad.hip', 'elementwise.hip', 'optim.hip', 'prof.hip', 'small.hip', 'subpix.hip', 'gemm.hip', 'metrics.hip']
+HEADERS = ['common.h', 'prof.h', 'conv_args.h', os.path.join('..', '..', 'include', 'saragan_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 # The MFMA kernels' off-phases share their SIMD with the other wave group's MFMAs, and packed-f32 VALU ops
 # (v_pk_mul_f32 / v_pk_add_f32, which the SLP vectoriser forms from the epilogues' per-element arithmetic) were measured at
@@ -18,7 +18,7 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-u
 # -save-temps=obj: the device assembly of exactly the code that ships (build/<name>-hip-amdgcn-amd-amdhsa-gfx950.s) is kept
 # for tests/test_build_resources.py, which checks the hand-counted `s_waitcnt lgkmcnt(N)` regions of the unrolled K loops.
 FILE_FLAGS = {'conv3d.hip': ['-fno-slp-vectorize', '-save-temps=obj'], 'wgrad.hip': ['-fno-slp-vectorize', '-save-temps=obj'],
-              'subpix.hip': ['-fno-slp-vectorize'], 'gemm.hip': ['-fno-slp-vectorize']}
+              'subpix.hip': ['-fno-slp-vectorize'], 'conv3p.hip': ['-fno-slp-vectorize', '-save-temps=obj'], 'gemm.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc():

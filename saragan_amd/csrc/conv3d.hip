@@ -13,6 +13,7 @@
 // so a wave fetches a fragment with one lane-linear 1-KiB access (LDS-DMA friendly, conflict-free ds_read_b128).
 #include "common.h"
 #include "prof.h"
+#include "conv_args.h"
 
 // ------------------------------------------------------------------------------------------------------
 // weight packing
@@ -98,42 +99,6 @@ extern "C" int sg_conv3d_pack_weights(const float* w, float coef, int transpose_
 // ------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------
-struct ConvFwdArgs {
-  const void* x;
-  const void* wp;
-  void* y;
-  const float* bias;
-  float* pn_scale;
-  const uint32_t* mask_bits;   // optional sign words [voxel][ntile]: output *= (bit ? mask_slope : 1)  (fused LeakyReLU backward)
-  uint32_t* sign_out;          // optional sign words of THIS output (after bias/act), same layout, for a later mask_bits
-  float mask_slope;
-  sg_tile_geom g;
-  int cin, cout, taps, kh, kw;
-  int nchunk, ntile;    // K chunks of 32 B, output-channel tiles of 32
-  int G, TG;            // chunks staged per K phase, taps staged per weight phase
-  int rs;               // LDS row stride of the halo image (bytes)
-  int xbytes;           // LDS bytes of the halo image
-  sg_fastdiv fnp;       // fastdiv by pieces per halo row (G*2)
-  int sshift, rshift;   // v2: log2(slots per row), log2(rows per 256-byte bank row)
-  int wbytes, ntiles;   // v3r: resident weight image bytes, number of spatial tiles
-  int wres;             // v4: all weight slabs resident in LDS
-  int lean;             // v4: input below 2 GiB and no fused up-sampling: buffer addressing for the halo
-  int tap_d, tap_h, tap_w;   // added to the tap index when addressing the halo (sub-pixel classes)
-  int xcs, xco;              // sliding-halo kernel: channels per voxel of the x TENSOR and first channel of the slice convolved (K split)
-  const float* addend;       // sliding-halo kernel, second K-split pass: the first pass's f32 partial sums [voxel][cout]
-  const void* pnb_y;         // sliding-halo kernel, pixel-norm backward epilogue: the stage's output y [voxel][cout] ...
-  const float* pnb_scale;    // ... and its per-voxel rsqrt factor (sg_conv_epilogue.pn_bwd_y / pn_bwd_scale)
-  const uint32_t* in_mask;   // sliding-halo kernel with the fused nearest-x2 gather: sign words of the FINE input [voxel][in_mask_nw] ...
-  float in_mask_slope, in_gain;   // ... the staged halo is in_gain * where(bit, in_mask_slope, 1) * x (sg_conv_epilogue.in_mask_bits)
-  int in_mask_nw;
-  int pool;                  // 1: y is the D x W mean-pooled output [n, D/2, H, W/2, cout] (sliding-halo kernel only)
-  int os, oa, ob, oc;        // output scatter: os == 2 writes voxel (2d+oa, 2h+ob, 2w+oc) of a [n,2D,2H,2W,cout] tensor
-  unsigned long long* dbg;  // diagnostic time stamps (NULL in production)
-  int dbg_flags;            // diagnostic ablations (0 in production): 1 = no re-staging, 2 = no epilogue
-  int vec_in, vec_out;
-  int act, pixel_norm;
-  float slope, eps;
-};
 
 template <typename T> struct sg_vec4 { typedef u32x4 type; };
 template <> struct sg_vec4<bf16_t> { typedef u32x2 type; };
@@ -1122,7 +1087,7 @@ struct sg_unrolled_ks2 {
 // Epilogue features of the sliding-halo kernel, compile-time: the off-phase of the generic (run-time flags) version
 // spent most of its ~4.3k cycles on scalar bookkeeping -- 200 spilled SGPRs (v_readlane), kernel arguments re-read
 // from memory behind s_waitcnt lgkmcnt(0), branches around features the launch did not use.
-enum : int { SG_EP_SIGN = 1, SG_EP_MASK = 2, SG_EP_PN = 4, SG_EP_POOL = 8, SG_EP_PNB = 16 };
+// (SG_EP_*: conv_args.h)
 #ifndef SG_V3S_RING
 #define SG_V3S_RING 6   // fragment ring of the MFMA phase: reads run RING - 2 steps (of 1-2 MFMAs) ahead of their use
 #endif
@@ -2952,6 +2917,12 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
         !(a.in_mask && (!s->upsample_in || a.sign_out || a.pixel_norm || xpl)) &&
         ep && ep->workspace &&
         ep->workspace_bytes >= (size_t)s->n * s->d * s->h * s->w * (size_t)s->cout * 4 && sg_aligned16(ep->workspace)) {
+      // one pass with sliding accumulators (conv3p.hip) where its tile applies; else the K split below
+      if (!sg_cfg().fwd_no_3p && !xpl) {
+        bool u3 = false;
+        rc = sg_launch_fwd3p(a, s, hs, &u3);
+        if (rc != SG_OK || u3) { prof.done(rc); return rc; }
+      }
       // K split: 64 input channels as two sliding-halo passes over 32 channels each (resident weights, a 64-byte
       // half of every 128-byte channel row fetched ONCE per pass) with the f32 partial sums in the caller's workspace.
       // The streamed kernel fetches every row as four 32-byte slivers in four passes too far apart for L2: each

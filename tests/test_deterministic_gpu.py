@@ -72,7 +72,7 @@ def test_two_runs_are_bit_identical_in_reproducible_mode():
             assert torch.equal(w1[k], w2[k]), k
         a1, c1, kernels = _run_cfg3(4)
         a2, c2, _ = _run_cfg3(4)
-        for need in ('conv_wgrad3l', 'upconv_subpixel_wgrad', 'conv_wgrad<', 'K split'):
+        for need in ('conv_wgrad3l', 'upconv_subpixel_wgrad', 'conv_wgrad<', 'conv_fwd3p'):
             assert any(need in k for k in kernels), (need, sorted(kernels))
         assert c1 == c2, (c1, c2)
         bad = [k for k in a1 if not torch.equal(a1[k], a2[k])]

@@ -19,7 +19,7 @@ def _run(name, sg_env):
     try:
         assert mod.main(), f'{name}: see the captured output'
     finally:
-        for k in ('SG_FWD_NO_V3S', 'SG_FWD_NO_V5', 'SG_WGRAD_NO_LEAN'):
+        for k in ('SG_FWD_NO_V3S', 'SG_FWD_NO_3P', 'SG_FWD_NO_V5', 'SG_WGRAD_NO_LEAN'):
             os.environ.pop(k, None)
         sg_env()        # fresh configuration snapshot for the tests that follow
 

@@ -734,11 +734,18 @@ def test_conv_epilogue_fused_downscale(monkeypatch):
     _mostly_close(resg[2], gb_ref, 1e-3, 1e-3, 'db (gather vs one launch)')
 
 
-def test_pooled_backward_gather_equals_the_two_tensor_path_at_the_benchmarked_size():
-    """At the size the bench runs (batch 32, 32x128x128, the discriminator's 32 -> 64 layer): the fused masked gather against
-    the materialised two-tensor path -- bit-identical data gradient (with the input's LeakyReLU mask in the epilogue),
-    weight and bias gradient to f32 summation order."""
+def test_pooled_backward_gather_equals_the_two_tensor_path_at_the_benchmarked_size(sg_env):
+    """At the size the bench runs (batch 32, 32x128x128, the discriminator's 32 -> 64 layer): the fused masked gather
+    (with the input's LeakyReLU mask in the epilogue) against the materialised gradient.
+      * one-pass kernel (conv_fwd3p, round 4): the gather is BIT-IDENTICAL to the same kernel run on the materialised
+        M * upscale3d(gy) / 8 (sg_upscale_nn writes exactly what the gather forms), and within f32 summation order
+        (<= 1 bf16 ulp on <= 1e-3 of the elements) of the two-tensor path, which still runs the two-pass K split;
+      * with the one-pass kernel switched off (SG_FWD_NO_3P=1) both paths run the K split and are bit-identical, as in
+        round 3;
+      * weight and bias gradient to f32 summation order."""
+    from saragan_amd import _lib
     from saragan_amd import functional as F
+    lib = _lib.load()
     n, d, h, w_ = 32, 32, 128, 128
     g_ = torch.Generator(device='cuda').manual_seed(92)
 
@@ -752,12 +759,31 @@ def test_pooled_backward_gather_equals_the_two_tensor_path_at_the_benchmarked_si
     info.consume(True)
     with torch.no_grad():
         rp = F._pooled_backward_planes(gy, x, wt, signs, 0.05, 0.2, info, True, True, True)
+        lib.sg_prof_enable(1)
         rg = F._pooled_backward_gather(gy, x, wt, signs, 0.05, 0.2, info, True, True, True)
+        torch.cuda.synchronize()
+        ents = (_lib.ProfEntry * 16)()
+        cnt = C.c_int32(0)
+        lib.sg_prof_collect(ents, 16, C.byref(cnt))
+        lib.sg_prof_enable(0)
+        names = [ents[i].kernel.decode() for i in range(cnt.value)]
+        assert any('conv_fwd3p' in k for k in names), names
+        g_full = F._Up.apply(gy, 0.125, signs, 0.2, (2, 2, 2))
+        gx_same = F._Conv.apply(g_full, wt, 0.05, True, False, None, info.bits, info.slope)
+        del g_full
     assert rp is not None and rg is not None
-    assert torch.equal(rp[0], rg[0]), 'data gradient differs between the fused gather and the two-tensor path'
+    assert torch.equal(gx_same, rg[0]), 'the fused gather differs from the same kernel on the materialised gradient'
+    del gx_same
+    ne = int((rp[0].view(torch.int16) != rg[0].view(torch.int16)).sum())
+    assert ne <= 1e-3 * rg[0].numel(), ne
+    assert float((rp[0].float() - rg[0].float()).abs().max() / rp[0].float().abs().max()) <= 2.0 ** -7
     assert float((rp[1] - rg[1]).abs().max() / rp[1].abs().max()) <= 1e-4
     assert float((rp[2] - rg[2]).abs().max() / rp[2].abs().max()) <= 1e-4
-    del rp, rg
+    sg_env(SG_FWD_NO_3P=1)
+    with torch.no_grad():
+        rg2 = F._pooled_backward_gather(gy, x, wt, signs, 0.05, 0.2, info, True, False, False)
+    assert torch.equal(rp[0], rg2[0]), 'K split: data gradient differs between the fused gather and the two-tensor path'
+    del rp, rg, rg2
     torch.cuda.empty_cache()
 
 
@@ -901,12 +927,18 @@ def test_conv_64_to_32_split_over_input_channels(sg_env):
         lib.sg_prof_enable(0)
         return out, [ents[i].kernel.decode() for i in range(cnt.value)]
 
+    (y3, s3), names3 = kernels_of(lambda: F.raw_conv(xg, wg, coef, False, bias=bg, act=True, want_signs=True)[::2])
+    assert any('conv_fwd3p' in k for k in names3), names3        # round 4: one pass with sliding accumulators (conv3p.hip)
+    sg_env(SG_FWD_NO_3P=1)
     (y2, s2), names = kernels_of(lambda: F.raw_conv(xg, wg, coef, False, bias=bg, act=True, want_signs=True)[::2])
     assert any('K split' in k for k in names), names
-    sg_env(SG_FWD_NO_KSPLIT=1)
+    sg_env(SG_FWD_NO_3P=0, SG_FWD_NO_KSPLIT=1)
     (y1, s1), names1 = kernels_of(lambda: F.raw_conv(xg, wg, coef, False, bias=bg, act=True, want_signs=True)[::2])
-    assert not any('K split' in k for k in names1) and any('conv_fwd4' in k for k in names1), names1
+    assert not any('K split' in k or 'conv_fwd3p' in k for k in names1) and any('conv_fwd4' in k for k in names1), names1
     sg_env(SG_FWD_NO_KSPLIT=0)
+    close(y3, yr, dtype, 'one-pass 64 -> 32')
+    d3 = (y3.float() - y2.float()).abs()
+    assert float((d3 > 0).float().mean()) < 2e-3 and float(d3.max()) <= 2.0 ** -6 * float(yr.abs().max()), (float(d3.max()),)
     close(y2, yr, dtype, 'split 64 -> 32')
     close(y1, yr, dtype, 'streamed 64 -> 32')
     # f32 partial sums in both: the two paths round the same f32 sums to bf16 (summation order differs by a few ulp of f32)

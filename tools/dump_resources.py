@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 
 if __name__ == '__main__':
     from saragan_amd import build as b
-    out = os.path.join(ROOT, 'profiles', sys.argv[1] if len(sys.argv) > 1 else 'r03_kernel_resources.json')
+    out = os.path.join(ROOT, 'profiles', sys.argv[1] if len(sys.argv) > 1 else 'r04_kernel_resources.json')
     u = b.resource_usage()
     with open(out, 'w') as f:
         json.dump(u, f, indent=1, sort_keys=True)

@@ -545,13 +545,19 @@ def main():
     ncal = 2
     barrier()
     lib.sg_prof_enable(1)
-    hipgraph = os.environ.get('SARAGAN_HIPGRAPH', '0') == '1'     # opt-in: the step's forward + backward replayed as one hipGraph
-    if hipgraph:
-        os.environ['SARAGAN_HIPGRAPH'] = '0'      # the per-launch event bracketing only exists on the eager path
+    # The calibration steps run EAGERLY whatever the capture mode (a replayed hipGraph has no launches to bracket); the
+    # environment is put back afterwards.  Unset, SARAGAN_HIPGRAPH means "capture the step if it is host-bound" (measured by
+    # optimization.StepGraph on its own eager steps): the small phases replay one graph, the benchmarked one stays eager.
+    env_graph = os.environ.get('SARAGAN_HIPGRAPH')
+    os.environ['SARAGAN_HIPGRAPH'] = '0'
     for i in range(ncal):
         step(args.warmup + i)
-    if hipgraph:
-        os.environ['SARAGAN_HIPGRAPH'] = '1'
+    if env_graph is None:
+        del os.environ['SARAGAN_HIPGRAPH']
+    else:
+        os.environ['SARAGAN_HIPGRAPH'] = env_graph
+    step_graph = cfg['train'][0].graph
+    hipgraph = any('graph' in e for e in step_graph.__dict__.get('_captures', {}).values())
     barrier()
     table = collect()
     lib.sg_prof_enable(0)
@@ -568,7 +574,8 @@ def main():
     if dp:
         for o_ in cfg['optimizers']:
             o_.distributed.exposed_ms()       # forget the warm-up steps
-    lib.sg_prof_enable(0 if os.environ.get('SARAGAN_BENCH_NO_PROF') else 1)     # (diagnostic: no event bracketing at all)
+    # (a captured step is replayed as one launch: nothing to bracket, the roofline object then quotes the calibration steps)
+    lib.sg_prof_enable(0 if (os.environ.get('SARAGAN_BENCH_NO_PROF') or hipgraph) else 1)
     step_marks = [] if os.environ.get('SARAGAN_BENCH_STEP_TIMES') else None      # diagnostic: an event after every step (no sync)
     with quiet_collector(), Stopwatch(lambda: None) as sw:      # the barrier before is the one above; the one after follows
         for i in range(args.steps):
@@ -610,6 +617,11 @@ def main():
     peak = 2500.0 if args.dtype == 'bf16' else 157.3
     roof = None
     timed = [e for e in timed if e.kernel == dom_name] or timed       # (one shape may run as several kernel variants)
+    timing_note = 'HIP events around every launch of this (kernel, shape) inside the timed region'
+    if hipgraph:      # the timed region replayed a hipGraph: the dominant kernel's duration comes from the eager calibration steps
+        timed = sorted((e for e in table if e.kernel == dom_name and e.launches > 0), key=lambda r: -r.total_ms)
+        timing_note = ('HIP events around every launch during the two eager calibration steps just before the timed region (the '
+                       'timed region replays the step as ONE hipGraph: there is no launch to bracket)')
     if timed and timed[0].launches > 0:      # the dominant kernel's heaviest shape, timed inside the timed region
         best = timed[0]
         avg_ms = best.total_ms / best.launches
@@ -627,7 +639,7 @@ def main():
                     shape=dict(n=s.n, d=s.d, h=s.h, w=s.w, cin=s.cin, cout=s.cout, k=[s.kd, s.kh, s.kw],
                                upsample_in=s.upsample_in),
                     launches=int(best.launches), avg_ms=round(avg_ms, 4), flops_per_launch=best.flops_per_launch,
-                    algorithmic_bytes=alg_bytes)
+                    algorithmic_bytes=alg_bytes, timing=timing_note)
         # the same kernel on its other shapes (calibration-step timings): the object above quotes the heaviest one by summed time
         others = sorted((e for e in rows if e.kernel == dom_name and e.launches > 0), key=lambda r: -r.total_ms)[:5]
         roof['by_shape'] = [dict(n=e.shape.n, cin=e.shape.cin, cout=e.shape.cout, calls_per_step=round(e.launches / ncal, 1),

@@ -272,6 +272,10 @@ int sg_trilinear_up2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, i
 /* out = wa*a + wb*b     (fade-in lerp pgan/generator.py:100-101, pgan/discriminator.py:105; b may be NULL) */
 int sg_axpby(const void* a, const void* b, void* out, float wa, float wb, int64_t numel, sg_dtype dt,
              sg_stream_t st);
+/* The same with the coefficients read from DEVICE memory, out = w[0]*a + w[1]*b (b NULL: w[0]*a, w[1] is not read): the
+ * fade-in of a step captured as a hipGraph, whose alpha moves every step (networks/ops.py:4-23, optuna_objective.py:446-467:
+ * the reference feeds alpha as a graph variable too).  Same f32 arithmetic as sg_axpby. */
+int sg_axpby_dev(const void* a, const void* b, void* out, const float* w, int64_t numel, sg_dtype dt, sg_stream_t st);
 /* out = x + stddev * N(0,1), counter-based Philox4x32-10 keyed by (seed, element index)
  * (instance noise, networks/loss.py:122-123). */
 int sg_add_noise(const void* x, void* out, float stddev, uint64_t seed, uint64_t offset, int64_t numel,
@@ -312,6 +316,13 @@ int sg_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64_
 enum { SG_OPT_SGD = 0, SG_OPT_MOMENTUM = 1, SG_OPT_ADADELTA = 2 };
 int sg_optim_step(int kind, float* p, const float* g, float* s1, float* s2, float* ema, int64_t numel, float lr,
                   float h, float eps, int nesterov, float gscale, float ema_decay, sg_stream_t st);
+/* sg_adam_ema / sg_optim_step with the step size read from DEVICE memory (one float: lr_t resp. lr): the optimiser launches
+ * of a captured step, whose learning-rate schedule (optimization.py:227-296) and Adam bias correction stay host arithmetic
+ * -- the host writes the value before each replay. */
+int sg_adam_ema_dev(float* p, const float* g, float* m, float* v, float* ema, int64_t numel, const float* lr_t,
+                    float b1, float b2, float eps, float gscale, float ema_decay, sg_stream_t st);
+int sg_optim_step_dev(int kind, float* p, const float* g, float* s1, float* s2, float* ema, int64_t numel, const float* lr,
+                      float h, float eps, int nesterov, float gscale, float ema_decay, sg_stream_t st);
 /* out[i] = sum of squares of segment i (offsets[i]..offsets[i+1]) of a flat f32 buffer
  * (tf.norm per gradient + tf.clip_by_global_norm, optimization.py:66-71).  offsets: DEVICE int64[nseg+1]. */
 int sg_segment_sumsq(const float* flat, const int64_t* offsets, float* out, int32_t nseg, sg_stream_t st);
@@ -375,6 +386,9 @@ typedef struct {
   char kernel[64];     /* kernel family + template arguments the dispatcher chose for this shape, e.g. "conv_fwd4<bf16,2,1,3,3,3>" */
 } sg_prof_entry;
 int sg_prof_enable(int on);
+/* 1 while the timing is enabled.  A caller that captures launches into a hipGraph (optimization.StepGraph) must not capture
+ * the profiler's event records: it checks this and runs that step eagerly. */
+int sg_prof_enabled(void);
 /* Restrict the timing to ONE (kind, shape) (NULL: every launch again): two event records per launch are not free, and a
  * throughput measurement that wants the dominant kernel's duration from inside its own timed region brackets only
  * that kernel's launches. */

@@ -83,6 +83,7 @@ SIGNATURES = {
     'sg_downscale_sum_masked': (C.c_int, [_p, _p, _f, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
     'sg_trilinear_up2x': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, C.c_int, _p]),
     'sg_axpby': (C.c_int, [_p, _p, _p, _f, _f, _i64, C.c_int, _p]),
+    'sg_axpby_dev': (C.c_int, [_p, _p, _p, _p, _i64, C.c_int, _p]),
     'sg_add_noise': (C.c_int, [_p, _p, _f, _u64, _u64, _i64, C.c_int, _p]),
     'sg_add_noise_dev': (C.c_int, [_p, _p, _f, _u64, _p, _u64, _i64, C.c_int, _p]),
     'sg_sumsq_ndhwc_keep_w': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, C.c_int, _p]),
@@ -91,6 +92,8 @@ SIGNATURES = {
     'sg_cast': (C.c_int, [_p, C.c_int, _p, C.c_int, _i64, _p]),
     'sg_adam_ema': (C.c_int, [_p, _p, _p, _p, _p, _i64, _f, _f, _f, _f, _f, _f, _p]),
     'sg_optim_step': (C.c_int, [C.c_int, _p, _p, _p, _p, _p, _i64, _f, _f, _f, C.c_int, _f, _f, _p]),
+    'sg_adam_ema_dev': (C.c_int, [_p, _p, _p, _p, _p, _i64, _p, _f, _f, _f, _f, _f, _p]),
+    'sg_optim_step_dev': (C.c_int, [C.c_int, _p, _p, _p, _p, _p, _i64, _p, _f, _f, C.c_int, _f, _f, _p]),
     'sg_segment_sumsq': (C.c_int, [_p, _p, _p, _i32, _p]),
     'sg_filter_axis': (C.c_int, [_p, _p, _p, _i64, _i32, _i64, C.POINTER(C.c_double), _i32, _i32, _i32, C.c_double, _i32, _p]),
     'sg_swd_gather': (C.c_int, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
@@ -106,6 +109,7 @@ SIGNATURES = {
     'sg_ssim_products': (C.c_int, [_p, _p, _p, _p, _p, _i64, _p]),
     'sg_ssim_mean': (C.c_int, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, C.c_double, C.c_double, C.c_double, _p, _sz, _p]),
     'sg_prof_enable': (C.c_int, [C.c_int]),
+    'sg_prof_enabled': (C.c_int, []),
     'sg_prof_collect': (C.c_int, [C.POINTER(ProfEntry), _i32, C.POINTER(_i32)]),
     'sg_prof_set_filter': (C.c_int, [C.c_int, _SHP]),
     'sg_config_reload': (C.c_int, []),

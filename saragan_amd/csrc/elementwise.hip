@@ -688,8 +688,12 @@ __global__ void trilinear_up2x_adj_kernel(const T* __restrict__ g, T* __restrict
 
 template <typename T>
 __global__ void axpby_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, float wa,
-                             float wb, int64_t numel) {
+                             float wb, int64_t numel, const float* __restrict__ w_dev = nullptr) {
   constexpr int E = Piece<T>::E;
+  if (w_dev) {      // the coefficients of a captured step live on the device (sg_axpby_dev): same f32 values, same arithmetic
+    wa = w_dev[0];
+    wb = b ? w_dev[1] : 0.f;
+  }
   const int64_t nv = numel / E;
   const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = tid0; i < nv; i += stride) {
@@ -1215,6 +1219,19 @@ extern "C" int sg_axpby(const void* a, const void* b, void* out, float wa, float
   const int E = dt == SG_BF16 ? 8 : 4;
   const int blocks = grid_trips(numel / E + 1, 256, 2);
 #define L(T) hipLaunchKernelGGL((axpby_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)a, (const T*)b, (T*)out, wa, wb, numel)
+  SG_DISPATCH(dt, L(bf16_t), L(float));
+#undef L
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_axpby_dev(const void* a, const void* b, void* out, const float* w, int64_t numel, sg_dtype dt, sg_stream_t st) {
+  if (!a || !out || !w || numel < 1) return SG_EINVAL;
+  if (!sg_aligned16(a) || !sg_aligned16(out) || (b && !sg_aligned16(b))) return SG_EALIGN;
+  hipStream_t hs = sg_st(st);
+  const int E = dt == SG_BF16 ? 8 : 4;
+  const int blocks = grid_trips(numel / E + 1, 256, 2);
+#define L(T) hipLaunchKernelGGL((axpby_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)a, (const T*)b, (T*)out, 0.f, 0.f, numel, w)
   SG_DISPATCH(dt, L(bf16_t), L(float));
 #undef L
   SG_LAUNCH_CHECK();

@@ -8,7 +8,8 @@ namespace {
 
 __global__ void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                 float* __restrict__ v, float* __restrict__ ema, int64_t numel, float lr_t, float b1,
-                                float b2, float eps, float gscale, float ema_decay) {
+                                float b2, float eps, float gscale, float ema_decay, const float* __restrict__ lr_dev) {
+  if (lr_dev) lr_t = *lr_dev;      // captured step: the bias-corrected step size is written by the host before each replay
   const int64_t nv = numel / 4;
   const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
   const float omd = 1.f - ema_decay;
@@ -73,7 +74,8 @@ __device__ __forceinline__ void optim_rule(float& p, float g, float& s1, float& 
 template <int KIND>
 __global__ void optim_step_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ s1,
                                   float* __restrict__ s2, float* __restrict__ ema, int64_t numel, float lr, float h,
-                                  float eps, int nesterov, float gscale, float ema_decay) {
+                                  float eps, int nesterov, float gscale, float ema_decay, const float* __restrict__ lr_dev) {
+  if (lr_dev) lr = *lr_dev;
   const int64_t nv = numel / 4;
   const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
   const float omd = 1.f - ema_decay;
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(256) void segment_sumsq_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" int sg_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t numel, float lr_t,
+static int adam_ema_launch(float* p, const float* g, float* m, float* v, float* ema, int64_t numel, float lr_t, const float* lr_dev,
                            float b1, float b2, float eps, float gscale, float ema_decay, sg_stream_t st) {
   if (!p || numel < 1 || (g && (!m || !v)) || (!g && !ema)) return SG_EINVAL;
   if (!sg_aligned16(p) || (g && (!sg_aligned16(g) || !sg_aligned16(m) || !sg_aligned16(v))) ||
@@ -141,13 +143,24 @@ extern "C" int sg_adam_ema(float* p, const float* g, float* m, float* v, float* 
   if (blocks < 1) blocks = 1;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(adam_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, sg_st(st), p, g, m, v, ema, numel, lr_t,
-                     b1, b2, eps, gscale, ema_decay);
+                     b1, b2, eps, gscale, ema_decay, lr_dev);
   SG_LAUNCH_CHECK();
   return SG_OK;
 }
 
-extern "C" int sg_optim_step(int kind, float* p, const float* g, float* s1, float* s2, float* ema, int64_t numel,
-                             float lr, float h, float eps, int nesterov, float gscale, float ema_decay,
+extern "C" int sg_adam_ema(float* p, const float* g, float* m, float* v, float* ema, int64_t numel, float lr_t,
+                           float b1, float b2, float eps, float gscale, float ema_decay, sg_stream_t st) {
+  return adam_ema_launch(p, g, m, v, ema, numel, lr_t, nullptr, b1, b2, eps, gscale, ema_decay, st);
+}
+
+extern "C" int sg_adam_ema_dev(float* p, const float* g, float* m, float* v, float* ema, int64_t numel, const float* lr_t,
+                               float b1, float b2, float eps, float gscale, float ema_decay, sg_stream_t st) {
+  if (!lr_t) return SG_EINVAL;
+  return adam_ema_launch(p, g, m, v, ema, numel, 0.f, lr_t, b1, b2, eps, gscale, ema_decay, st);
+}
+
+static int optim_step_launch(int kind, float* p, const float* g, float* s1, float* s2, float* ema, int64_t numel,
+                             float lr, const float* lr_dev, float h, float eps, int nesterov, float gscale, float ema_decay,
                              sg_stream_t st) {
   if (!p || !g || numel < 1) return SG_EINVAL;
   if (kind != SG_OPT_SGD && kind != SG_OPT_MOMENTUM && kind != SG_OPT_ADADELTA) return SG_EINVAL;
@@ -161,15 +174,28 @@ extern "C" int sg_optim_step(int kind, float* p, const float* g, float* s1, floa
   const dim3 grid((unsigned)blocks), blk(256);
   if (kind == SG_OPT_SGD)
     hipLaunchKernelGGL(optim_step_kernel<SG_OPT_SGD>, grid, blk, 0, sg_st(st), p, g, s1, s2, ema, numel, lr, h, eps,
-                       nesterov, gscale, ema_decay);
+                       nesterov, gscale, ema_decay, lr_dev);
   else if (kind == SG_OPT_MOMENTUM)
     hipLaunchKernelGGL(optim_step_kernel<SG_OPT_MOMENTUM>, grid, blk, 0, sg_st(st), p, g, s1, s2, ema, numel, lr, h,
-                       eps, nesterov, gscale, ema_decay);
+                       eps, nesterov, gscale, ema_decay, lr_dev);
   else
     hipLaunchKernelGGL(optim_step_kernel<SG_OPT_ADADELTA>, grid, blk, 0, sg_st(st), p, g, s1, s2, ema, numel, lr, h,
-                       eps, nesterov, gscale, ema_decay);
+                       eps, nesterov, gscale, ema_decay, lr_dev);
   SG_LAUNCH_CHECK();
   return SG_OK;
+}
+
+extern "C" int sg_optim_step(int kind, float* p, const float* g, float* s1, float* s2, float* ema, int64_t numel,
+                             float lr, float h, float eps, int nesterov, float gscale, float ema_decay,
+                             sg_stream_t st) {
+  return optim_step_launch(kind, p, g, s1, s2, ema, numel, lr, nullptr, h, eps, nesterov, gscale, ema_decay, st);
+}
+
+extern "C" int sg_optim_step_dev(int kind, float* p, const float* g, float* s1, float* s2, float* ema, int64_t numel,
+                                 const float* lr, float h, float eps, int nesterov, float gscale, float ema_decay,
+                                 sg_stream_t st) {
+  if (!lr) return SG_EINVAL;
+  return optim_step_launch(kind, p, g, s1, s2, ema, numel, 0.f, lr, h, eps, nesterov, gscale, ema_decay, st);
 }
 
 extern "C" int sg_segment_sumsq(const float* flat, const int64_t* offsets, float* out, int32_t nseg,

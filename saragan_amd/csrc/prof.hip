@@ -125,6 +125,11 @@ extern "C" int sg_prof_enable(int on) {
   return SG_OK;
 }
 
+extern "C" int sg_prof_enabled(void) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  return g_on ? 1 : 0;
+}
+
 extern "C" int sg_prof_set_filter(int kind, const sg_conv_shape* s) {
   std::lock_guard<std::mutex> lk(g_mu);
   g_filter = s != nullptr;

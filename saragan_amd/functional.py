@@ -1227,6 +1227,41 @@ class _TriUp(torch.autograd.Function):
         return _TriUp.apply(gy, not ctx.adjoint), None
 
 
+class DevCoef(float):
+    """A step scalar that ALSO lives in device memory (element `idx` of `buf`, f32): the value a kernel of a captured step
+    reads (sg_axpby_dev, sg_adam_ema_dev).  Behaves as its host value everywhere else."""
+
+    def __new__(cls, value, buf, idx):
+        o = float.__new__(cls, value)
+        o.buf, o.idx = buf, int(idx)
+        return o
+
+    def ptr(self):
+        return C.c_void_p(self.buf.data_ptr() + 4 * self.idx)
+
+
+class DevScalars:
+    """The per-step scalars of a captured step (optimization.StepGraph): fade-in weights [alpha, 1 - alpha] and the step size
+    of each optimiser.  The host writes them into a pinned mirror (`set`) and `flush()` sends all of them with one
+    asynchronous copy before the graph is replayed; the captured kernels read the device copy.  The values are the f32
+    roundings of the doubles the eager path hands to ctypes: the same bits reach the same arithmetic."""
+
+    def __init__(self, device, n=8):
+        self.host = torch.zeros(n, dtype=torch.float32).pin_memory() if torch.device(device).type == 'cuda' \
+            else torch.zeros(n, dtype=torch.float32)
+        self.dev = torch.zeros(n, dtype=torch.float32, device=device)
+
+    def set(self, idx, value):
+        self.host[idx] = float(value)
+
+    def coef(self, idx, value):
+        self.set(idx, value)
+        return DevCoef(value, self.dev, idx)
+
+    def flush(self):
+        self.dev.copy_(self.host, non_blocking=True)
+
+
 class _Axpby(torch.autograd.Function):
     """out = wa*a + wb*b (fade-in lerp, pgan/generator.py:100-101, pgan/discriminator.py:105)."""
 
@@ -1241,8 +1276,13 @@ class _Axpby(torch.autograd.Function):
             if b.shape != a.shape or b.dtype != a.dtype:
                 raise ValueError('lerp operands differ in shape or dtype')
         out = torch.empty_like(a)
-        check(lib.sg_axpby(_ptr(a), _ptr(b), _ptr(out), float(wa), float(wb), a.numel(), _dt(a), _stream()),
-              'sg_axpby')
+        if isinstance(wa, DevCoef):      # captured step: [wa, wb] are adjacent device floats (wb unread without b)
+            if b is not None and not (isinstance(wb, DevCoef) and wb.buf is wa.buf and wb.idx == wa.idx + 1):
+                raise ValueError('device-side lerp weights must be adjacent elements of one DevScalars buffer')
+            check(lib.sg_axpby_dev(_ptr(a), _ptr(b), _ptr(out), wa.ptr(), a.numel(), _dt(a), _stream()), 'sg_axpby_dev')
+        else:
+            check(lib.sg_axpby(_ptr(a), _ptr(b), _ptr(out), float(wa), float(wb), a.numel(), _dt(a), _stream()),
+                  'sg_axpby')
         ctx.wa, ctx.wb, ctx.has_b = wa, wb, b is not None
         return out
 
@@ -1403,23 +1443,39 @@ def minibatch_stddev(x, group_size=4):
     return _MinibatchStddev.apply(x, group_size)
 
 
-def adam_ema_(p, g, m, v, ema, lr, beta1, beta2, step, eps=1e-8, gscale=1.0, ema_decay=0.99):
-    """In-place fused TF-Adam + EMA over flat f32 buffers."""
+def adam_step_size(lr, beta1, beta2, step):
+    """lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t) (tf.train.AdamOptimizer), in host doubles."""
+    return lr * math.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step)
+
+
+def adam_ema_(p, g, m, v, ema, lr, beta1, beta2, step, eps=1e-8, gscale=1.0, ema_decay=0.99, lr_dev=None):
+    """In-place fused TF-Adam + EMA over flat f32 buffers.  lr_dev: a DevCoef holding lr_t on the
+    device (captured step): `lr` and `step` are then not used."""
     lib = _lib.load()
     _req_cuda(p, g, m, v, ema)
-    lr_t = lr * math.sqrt(1.0 - beta2 ** step) / (1.0 - beta1 ** step) if g is not None else 0.0
     if g is not None:
         _PACK_CACHE.clear()   # the kernel rewrites parameters behind torch's version counters
         _SUBPIX_CACHE.clear()
+    if lr_dev is not None and g is not None:
+        check(lib.sg_adam_ema_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(ema), p.numel(), lr_dev.ptr(), float(beta1),
+                                  float(beta2), float(eps), float(gscale), float(ema_decay), _stream()), 'sg_adam_ema_dev')
+        return
+    lr_t = adam_step_size(lr, beta1, beta2, step) if g is not None else 0.0
     check(lib.sg_adam_ema(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(ema), p.numel(), float(lr_t), float(beta1),
                           float(beta2), float(eps), float(gscale), float(ema_decay), _stream()), 'sg_adam_ema')
 
 
-def optim_step_(kind, p, g, s1, s2, ema, lr, h=0.0, eps=0.0, nesterov=False, gscale=1.0, ema_decay=0.99):
-    """In-place fused SGD / Momentum / Adadelta (+ EMA) over flat f32 buffers (sg_optim_step)."""
+def optim_step_(kind, p, g, s1, s2, ema, lr, h=0.0, eps=0.0, nesterov=False, gscale=1.0, ema_decay=0.99, lr_dev=None):
+    """In-place fused SGD / Momentum / Adadelta (+ EMA) over flat f32 buffers (sg_optim_step; lr_dev: the learning rate as
+    a DevCoef on the device, captured step)."""
     lib = _lib.load()
     _req_cuda(p, g, s1, s2, ema)
     clear_pack_cache()      # the kernel rewrites parameters behind torch's version counters
+    if lr_dev is not None:
+        check(lib.sg_optim_step_dev(int(kind), _ptr(p), _ptr(g), _ptr(s1), _ptr(s2), _ptr(ema), p.numel(), lr_dev.ptr(), float(h),
+                                    float(eps), 1 if nesterov else 0, float(gscale), float(ema_decay), _stream()),
+              'sg_optim_step_dev')
+        return
     check(lib.sg_optim_step(int(kind), _ptr(p), _ptr(g), _ptr(s1), _ptr(s2), _ptr(ema), p.numel(), float(lr), float(h),
                             float(eps), 1 if nesterov else 0, float(gscale), float(ema_decay), _stream()),
           'sg_optim_step')

@@ -398,9 +398,12 @@ def lerp(a, b, alpha):
     pruned here -- its value is never materialised (the lazy from_rgb / to_rgb of the previous phase does not run), and
     its variables keep the zeros their slice of the flat gradient buffer is cleared to (optimization.StepGraph._backward),
     which is what tf.gradients delivers for them."""
+    dev = alpha if isinstance(alpha, F.DevCoef) else None      # captured mixing step: [alpha, 1 - alpha] on the device
     alpha = float(alpha)
     if not _NO_LERP_PRUNE and (alpha == 0.0 or alpha == 1.0):
         return _val(b) if alpha == 0.0 else _val(a)
+    if dev is not None:
+        return F.lerp(_val(a), _val(b), dev, F.DevCoef(1.0 - alpha, dev.buf, dev.idx + 1))
     return F.lerp(_val(a), _val(b), alpha, 1.0 - alpha)
 
 

@@ -33,6 +33,16 @@ class _Optimizer:
     def lr_value(self):
         return float(self.lr.eval()) if isinstance(self.lr, ScalarVariable) else float(self.lr)
 
+    def step_size(self):
+        """The scalar the update kernel multiplies with at the CURRENT step count (Adam: the bias-corrected lr_t)."""
+        return self.lr_value()
+
+    def next_step_size(self):
+        """Captured step (StepGraph): advances the step count on the host and returns the scalar the replayed kernel reads
+        from device memory (functional.DevScalars); `apply(..., lr_dev=...)` then leaves the count alone."""
+        self.t += 1
+        return self.step_size()
+
     def _slots(self, prefix, flat, names):
         st = self.state.get(prefix)
         if st is None or st['total'] != flat['total']:
@@ -49,14 +59,18 @@ class AdamOptimizer(_Optimizer):
         super().__init__(learning_rate)
         self.beta1, self.beta2, self.epsilon = float(beta1), float(beta2), float(epsilon)
 
-    def apply(self, prefix, flat, ranges, gscale, ema_flat, ema_decay):
+    def step_size(self):
+        return F.adam_step_size(self.lr_value(), self.beta1, self.beta2, self.t)
+
+    def apply(self, prefix, flat, ranges, gscale, ema_flat, ema_decay, lr_dev=None):
         st = self._slots(prefix, flat, ('m', 'v'))
-        self.t += 1
+        if lr_dev is None:
+            self.t += 1
         lr = self.lr_value()
         for (o, n) in ranges:
             F.adam_ema_(flat['param'][o:o + n], flat['grad'][o:o + n], st['m'][o:o + n], st['v'][o:o + n],
                         None if ema_flat is None else ema_flat[o:o + n], lr, self.beta1, self.beta2, self.t,
-                        self.epsilon, gscale, ema_decay)
+                        self.epsilon, gscale, ema_decay, lr_dev=lr_dev)
 
 
 class _FusedRule(_Optimizer):
@@ -66,16 +80,17 @@ class _FusedRule(_Optimizer):
     def _hyper(self):
         return dict(h=0.0, eps=0.0, nesterov=False)
 
-    def apply(self, prefix, flat, ranges, gscale, ema_flat, ema_decay):
+    def apply(self, prefix, flat, ranges, gscale, ema_flat, ema_decay, lr_dev=None):
         st = self._slots(prefix, flat, self.SLOTS)
-        self.t += 1
+        if lr_dev is None:
+            self.t += 1
         lr = self.lr_value()
         for (o, n) in ranges:
             s1 = st[self.SLOTS[0]][o:o + n] if len(self.SLOTS) > 0 else None
             s2 = st[self.SLOTS[1]][o:o + n] if len(self.SLOTS) > 1 else None
             F.optim_step_(self.KIND, flat['param'][o:o + n], flat['grad'][o:o + n], s1, s2,
                           None if ema_flat is None else ema_flat[o:o + n], lr, gscale=gscale, ema_decay=ema_decay,
-                          **self._hyper())
+                          lr_dev=lr_dev, **self._hyper())
 
 
 class GradientDescentOptimizer(_FusedRule):
@@ -232,11 +247,11 @@ class StepGraph:
                         c['activation'], c['leakiness'], c['loss_fn'])
             if c['optim_strategy'] == 'simultaneous':
                 if self._capturable(train_ids, real):
-                    out, pend = self._replay_or_capture(real, train_ids, net_args, alpha)
+                    out = self._replay_or_capture(real, train_ids, want_train, net_args, alpha)
                 else:
                     pend = self._compute_simultaneous(real, train_ids, net_args, out)
-                for tid, info in pend:
-                    self._finish(tid, info, out, apply=tid in want_train)
+                    for tid, info in pend:
+                        self._finish(tid, info, out, apply=tid in want_train)
             else:                               # alternate: D step, then G forward on the updated D
                 d_ids = [t for t in train_ids if self.trains[t]['net'] == 'discriminator']
                 g_ids = [t for t in train_ids if self.trains[t]['net'] == 'generator']
@@ -250,8 +265,12 @@ class StepGraph:
                 out.update(gen_sample=gen_sample, gen_loss=gen_loss)
                 for tid in g_ids:
                     self._finish(tid, self._backward(tid, out), out, apply=tid in want_train)
-        self.last = out
+        static = out.pop('__static__', False)     # a replayed graph's outputs live in buffers the next replay overwrites
+        self.last = None if static else out
         F.clear_pack_cache()
+
+        def own(v):       # what the caller gets is his to keep (the eager path returns fresh tensors each step)
+            return v.clone() if static and torch.is_tensor(v) else v
         res = []
         for f in fetches:
             if f.key in ('train',):
@@ -259,13 +278,13 @@ class StepGraph:
             elif f.key == 'gradients':
                 res.append(out[('gradients', f.net)])
             elif f.key == 'max_norm':
-                res.append(out.get(('max_norm', f.net)))
+                res.append(own(out.get(('max_norm', f.net))))
             else:
                 v = out[f.key]
-                res.append(v.detach() if torch.is_tensor(v) else v)
+                res.append(own(v.detach()) if torch.is_tensor(v) else v)
         return res
 
-    def _compute_simultaneous(self, real, train_ids, net_args, out):
+    def _compute_simultaneous(self, real, train_ids, net_args, out, arm_dist=True):
         """Forward pass and both backward passes of a 'simultaneous' step (no optimizer): fills `out`, returns the per-net
         records `_finish` needs."""
         c = self.cfg
@@ -282,64 +301,154 @@ class StepGraph:
             train_ids = sorted(train_ids, key=lambda t: self.trains[t]['net'] != 'discriminator')
         pend = []
         for j, tid in enumerate(train_ids):   # both gradients at the pre-step weights (optimization.py:128-163)
-            pend.append((tid, self._backward(tid, out, retain=j + 1 < len(train_ids))))
+            pend.append((tid, self._backward(tid, out, retain=j + 1 < len(train_ids), arm_dist=arm_dist)))
         return pend
 
-    # -- hipGraph capture of the step (opt-in: SARAGAN_HIPGRAPH=1) ------------------------------------------------
+    # -- hipGraph capture of the step -----------------------------------------------------------------------------
     # The small phases and the 2-D configuration are HOST-bound: ~600-1500 kernel launches per step through Python,
-    # autograd and ctypes (config 5: 13-23 ms of wall time for 13 ms of kernels).  Forward and both backward passes
-    # are captured ONCE into a hipGraph (torch.cuda.graph: the C-ABI launches go to torch's current stream, which is
-    # the capturing one; workspaces come from the graph's private pool) and replayed as a single launch; the two
-    # optimizer kernels stay eager, so Adam's host-side bias correction and the learning-rate schedule never enter the
-    # graph.  What varies per step is kept out of the captured region or on the device: the batch and the latents /
-    # mixing weights live in fixed buffers refilled before each replay (loss.StaticRandom), the instance noise reads
-    # its Philox offset from a device counter.  The graph is keyed by everything that is baked in (fetch set, alpha,
-    # batch shape, dtype) and captured after two eager steps of the same key (every lazy one-time call has happened).
+    # autograd and ctypes (config 1: 2.6 ms of wall time for 1.2 ms of kernels).  The whole step -- forward, both backward
+    # passes with the gradient penalty's double backward, the global-norm clip, the optimiser + EMA launches -- is captured
+    # ONCE into a hipGraph (torch.cuda.graph: the C-ABI launches go to torch's current stream, which is the capturing one;
+    # workspaces come from the graphs' shared private pool) and replayed as a single launch.  What varies per step is on
+    # the device or outside the captured region:
+    #   * the batch, the latents and the penalty's mixing weights live in fixed buffers refilled before each replay
+    #     (loss.StaticRandom), the instance noise reads its Philox offset from a device counter;
+    #   * the fade-in weights [alpha, 1 - alpha] (networks/ops.py:4-23: alpha moves EVERY step of a mixing phase) and each
+    #     optimiser's step size (lr schedule optimization.py:227-296; Adam's bias correction) are host arithmetic written to
+    #     a pinned mirror and sent with one small copy before the replay (functional.DevScalars; sg_axpby_dev,
+    #     sg_adam_ema_dev): a mixing phase replays ONE graph;
+    #   * with a gradient reducer attached (parallel.DistributedOptimizer) the captured region ends after the backward
+    #     passes; the bucket collectives and the optimiser launches follow eagerly (RCCL stays outside the graph).
+    # The graph is keyed by what is baked in (train ops, whether gradient norms are asked for, alpha's class {0, 1, in
+    # between}, batch shape, dtype) -- NOT by the loss / sample fetches: every capture produces all of them -- and captured
+    # after three eager steps of the same key (every lazy one-time call has happened).
+    # SARAGAN_HIPGRAPH=1 forces capture, =0 forbids it; unset, a key is captured when its eager steps turn out host-bound
+    # (host enqueue time >= 0.8 x the device span of the step, measured on eager steps 2 and 3 of the key).
+    _MAX_CAPTURES = 4
+
     def _capturable(self, train_ids, real):
-        if os.environ.get('SARAGAN_HIPGRAPH', '0') != '1' or not real.is_cuda:
+        mode = os.environ.get('SARAGAN_HIPGRAPH', '')
+        if mode == '0' or not real.is_cuda:
             return False
         nets = {self.trains[t]['net'] for t in train_ids}
         if not nets >= {'generator', 'discriminator'}:
             return False                         # the full training step only
-        if any(self.trains[t]['optimizer'].distributed is not None for t in train_ids):
-            return False                         # the all-reduce hooks stay eager
+        if any(type(self.trains[t]['optimizer'].distributed).__name__ == 'AdasumReducer' for t in train_ids):
+            return False                         # Adasum combines weight deltas around the optimiser step: eager
+        if F._lib.load().sg_prof_enabled():
+            return False                         # the profiler brackets launches with events: never inside a capture
         from .networks import loss as L
         return L.graph_safe(L._rng(real.device))
 
-    def _replay_or_capture(self, real, train_ids, net_args, alpha):
+    @staticmethod
+    def assert_no_live_accumulate_grad(params):
+        """Raises if any parameter's AccumulateGrad node is kept alive by an autograd graph somebody still holds.  Such a node
+        remembers the stream it was created on; reused inside a capture it runs on the non-capturing stream and
+        hipStreamEndCapture aborts the process (round 3: gpurun_out/hg.log).  A leaf's node is only weakly held by the tensor:
+        pass 1 marks every node it is handed and lets go of it; a node that pass 2 receives WITH the mark survived without
+        our reference, i.e. a live graph owns it."""
+        token = object()
+        edge = torch.autograd.graph.get_gradient_edge
+        for p in params:
+            if p.requires_grad and p.grad_fn is None:
+                edge(p).node.metadata['sg_capture_probe'] = token
+        held = [i for i, p in enumerate(params)
+                if p.requires_grad and p.grad_fn is None and edge(p).node.metadata.get('sg_capture_probe') is token]
+        if held:
+            raise RuntimeError(f'{len(held)} parameter(s) still have an AccumulateGrad node owned by a live autograd graph '
+                               f'(first: #{held[0]}): drop the previous step\'s outputs before a step is captured')
+
+    def _replay_or_capture(self, real, train_ids, want_train, net_args, alpha):
         from .networks import loss as L
-        key = (tuple(train_ids), frozenset(self._wanted), float(alpha), tuple(real.shape), str(compute_dtype()))
+        alpha_class = 'mix' if 0.0 < alpha < 1.0 else float(alpha)
+        norms = tuple(sorted(t for t in train_ids if ('max_norm', t) in self._wanted))
+        dist_ids = tuple(t for t in train_ids if self.trains[t]['optimizer'].distributed is not None)
+        key = (tuple(train_ids), tuple(sorted(want_train)), norms, alpha_class, tuple(real.shape), str(compute_dtype()))
         caps = self.__dict__.setdefault('_captures', {})
-        if key not in caps and len(caps) >= 64:      # a fade-in phase moves alpha every step: forget keys that never repeated
-            for k in [k for k, e in caps.items() if 'graph' not in e]:
-                del caps[k]
-        ent = caps.setdefault(key, dict(eager=0))
+        ent = caps.get(key)
+        if ent is None:
+            ent = caps[key] = dict(eager=0, ratios=[])
+        ent['used'] = self.__dict__['_cap_clock'] = self.__dict__.get('_cap_clock', 0) + 1
         base = L._rng(real.device)
-        if 'graph' not in ent and ent['eager'] < 2:          # warm-up: the ordinary path
-            ent['eager'] += 1
+        forced = os.environ.get('SARAGAN_HIPGRAPH', '') == '1'
+
+        def eager():
             out = {}
-            return out, self._compute_simultaneous(real, train_ids, net_args, out)
+            pend = self._compute_simultaneous(real, train_ids, net_args, out)
+            for tid, info in pend:
+                self._finish(tid, info, out, apply=tid in want_train)
+            return out
+
         if 'graph' not in ent:
+            if ent.get('decided') == 'eager':
+                return eager()
+            if ent['eager'] < (2 if forced else 3):          # warm-up: the ordinary path, timed from its second step on
+                ent['eager'] += 1
+                if ent['eager'] == 1 or forced:
+                    return eager()
+                import time
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                t0 = time.perf_counter()
+                out = eager()
+                host_ms = (time.perf_counter() - t0) * 1e3
+                e1.record()
+                ent.setdefault('probes', []).append((host_ms, e0, e1))
+                return out
+            if not forced:
+                for host_ms, e0, e1 in ent.pop('probes', []):
+                    e1.synchronize()
+                    ent['ratios'].append(host_ms / max(1e-6, e0.elapsed_time(e1)))
+                if not ent['ratios'] or min(ent['ratios']) < 0.8:      # the device is the bottleneck: nothing to gain
+                    ent['decided'] = 'eager'
+                    return eager()
+            # ---- capture
+            while sum('graph' in e for e in caps.values()) >= self._MAX_CAPTURES:      # bounded: oldest captured key goes
+                old = min((k for k, e in caps.items() if 'graph' in e), key=lambda k: caps[k]['used'])
+                del caps[old]
             ent['real'] = real.clone()
             ent['rnd'] = L.StaticRandom(base, real.shape[0], self.cfg['latent_dim'], real.device)
             ent['rnd'].draw()
             ent['rnd'].sync_counter()
+            sc = ent['scalars'] = F.DevScalars(real.device, 8)
+            args = list(net_args)
+            if alpha_class == 'mix':
+                args[1] = sc.coef(0, alpha)
+                sc.set(1, 1.0 - alpha)
+            ent['opt'] = []                                   # (train id, optimiser, scalar slot) of the captured applies
+            lr_dev = {}
+            if not dist_ids:
+                for i, tid in enumerate(t for t in train_ids if t in want_train):
+                    o = self.trains[tid]['optimizer']
+                    lr_dev[tid] = sc.coef(2 + i, o.next_step_size())
+                    ent['opt'].append((tid, o, 2 + i))
+            sc.flush()
             ent['out'] = {}
             g = torch.cuda.CUDAGraph()
             L.set_random_source(ent['rnd'])
             ent['rnd'].counting = True
-            # The parameters' AccumulateGrad nodes remember the stream they were created on and are kept alive by the last
-            # step's autograd graph: reused inside the capture they would run on the (non-capturing) default stream --
-            # hipStreamEndCapture then crashes.  Without a live graph they are created afresh, on the capturing stream.
+            # No live autograd graph may own the parameters' AccumulateGrad nodes when the capture begins (see
+            # assert_no_live_accumulate_grad): the last step's outputs are dropped first, then the invariant is CHECKED.
             self.last = None
+            F.clear_pack_cache()      # every weight image the step uses is packed INSIDE the graph, from the current weights
+            self.assert_no_live_accumulate_grad([p for _, p in self.store.trainable('generator/')] +
+                                                [p for _, p in self.store.trainable('discriminator/')])
+            marks = []
             try:
                 torch.cuda.synchronize()
-                with torch.cuda.graph(g):
-                    ent['pend'] = self._compute_simultaneous(ent['real'], train_ids, net_args, ent['out'])
+                pool = self.__dict__.get('_cap_pool')
+                if pool is None:
+                    pool = self.__dict__['_cap_pool'] = torch.cuda.graph_pool_handle()
+                with torch.cuda.graph(g, pool=pool):
+                    ent['pend'] = self._compute_simultaneous(ent['real'], train_ids, tuple(args), ent['out'], arm_dist=False)
+                    if not dist_ids:
+                        for tid, info in ent['pend']:
+                            self._finish(tid, info, ent['out'], apply=tid in want_train, lr_dev=lr_dev.get(tid), marks=marks)
             finally:
                 ent['rnd'].counting = False
                 L.set_random_source(base)
                 F.clear_pack_cache()
+            ent['marks'] = marks
             # replays need the captured launches and the output buffers, not the Python autograd graph: without it the
             # AccumulateGrad nodes made on the capturing stream go away too (a later eager step would find them on the
             # wrong stream and synchronise)
@@ -349,11 +458,29 @@ class StepGraph:
             ent['real'].copy_(real, non_blocking=True)
             ent['rnd'].draw()
             ent['rnd'].sync_counter()
+            sc = ent['scalars']
+            if alpha_class == 'mix':
+                sc.set(0, alpha)
+                sc.set(1, 1.0 - alpha)
+            for tid, o, slot in ent['opt']:
+                sc.set(slot, o.next_step_size())
+            if alpha_class == 'mix' or ent['opt']:
+                sc.flush()
         ent['graph'].replay()
         ent['rnd'].after_replay()
-        return ent['out'], ent['pend']
+        out = dict(ent['out'])
+        out['__static__'] = True
+        if dist_ids:       # the collectives and the optimiser launches follow the replayed forward + backward eagerly
+            for tid, info in ent['pend']:
+                if info['dist'] is not None:
+                    info['dist'].begin(info['flat']['grad'], info['ranges'], [self.store.vars[n] for n in info['names']], None)
+                self._finish(tid, info, out, apply=tid in want_train)
+        elif self.ema is not None:
+            for prefix, ranges in ent['marks']:
+                self.ema.mark_updated(prefix, ranges)
+        return out
 
-    def _backward(self, tid, out, retain=False):
+    def _backward(self, tid, out, retain=False, arm_dist=True):
         tr = self.trains[tid]
         prefix = tr['net'] + '/'
         flat = self.store.flat[prefix]
@@ -369,7 +496,7 @@ class StepGraph:
         dist = tr['optimizer'].distributed
         other = 'discriminator/' if tr['net'] == 'generator' else 'generator/'
         link = getattr(out['gen_loss'], 'sg_link', None) if 'gen_loss' in out else None
-        if dist is not None:
+        if dist is not None and arm_dist:      # (a captured backward launches no collective: they follow the replay)
             roots = [link[0]] if (link is not None and tr['net'] == 'generator') else [loss]
             dist.begin(flat['grad'], ranges, params, roots if getattr(dist, 'world_size', 1) > 1 else None)
         with F.skip_param_grads(p for _, p in self.store.trainable(other)):   # e.g. D's weights under the G loss
@@ -385,7 +512,7 @@ class StepGraph:
                 torch.autograd.backward(start, grad_tensors=leaf.grad * factor, inputs=params, retain_graph=retain)
         return dict(prefix=prefix, flat=flat, names=names, ranges=ranges, dist=dist)
 
-    def _finish(self, tid, info, out, apply):
+    def _finish(self, tid, info, out, apply, lr_dev=None, marks=None):
         tr = self.trains[tid]
         flat, ranges, names = info['flat'], info['ranges'], info['names']
         gscale = 1.0
@@ -414,9 +541,14 @@ class StepGraph:
         if apply:
             ema_flat = self.ema.shadow_flat(info['prefix']) if self.ema is not None else None
             ema_decay = self.ema.decay if self.ema is not None else 0.0
-            tr['optimizer'].apply(info['prefix'], flat, ranges, gscale, ema_flat, ema_decay)
+            if lr_dev is not None:
+                tr['optimizer'].apply(info['prefix'], flat, ranges, gscale, ema_flat, ema_decay, lr_dev=lr_dev)
+            else:
+                tr['optimizer'].apply(info['prefix'], flat, ranges, gscale, ema_flat, ema_decay)
             if self.ema is not None:
                 self.ema.mark_updated(info['prefix'], ranges)
+                if marks is not None:       # a replay repeats this bookkeeping (ExtendedEMA.apply skips the covered ranges)
+                    marks.append((info['prefix'], ranges))
 
 
 def optimize_step(optimizer_gen, optimizer_disc, generator, discriminator, real_image_input, latent_dim, alpha, phase,

@@ -1,7 +1,10 @@
-"""SARAGAN_HIPGRAPH=1: forward + both backward passes of the training step captured once into a hipGraph and replayed
-(optimization.StepGraph); the optimizer kernels stay eager.  In reproducible mode the captured run must give BIT-IDENTICAL
-weights and losses to the eager run from the same state: same kernels in the same order, the latents / mixing weights drawn
-from the same generator in the same order, the instance noise from the same Philox offsets (device counter)."""
+"""The training step captured once into a hipGraph and replayed (optimization.StepGraph): forward, both backward passes, the
+global-norm clip and the optimiser + EMA launches.  In reproducible mode the captured run must give BIT-IDENTICAL weights and
+losses to the eager run from the same state: same kernels in the same order, the latents / mixing weights drawn from the same
+generator in the same order, the instance noise from the same Philox offsets (device counter), the fade-in weights and the
+optimisers' step sizes read from device scalars the host refreshes before each replay (round 4: a MIXING phase, whose alpha
+moves every step, and a learning-rate schedule replay one graph).  SARAGAN_HIPGRAPH=1 forces capture, =0 forbids it, unset
+the step is captured when it turns out host-bound -- which these toy steps are."""
 import os
 
 import pytest
@@ -13,7 +16,7 @@ pytestmark = pytest.mark.gpu
 NAME = 'oracle_step_p3_wgan_a000.npz'
 
 
-def _run(golden_dir, steps, dtype, captured):
+def _run(golden_dir, steps, dtype, captured, mixing=False, clipping=False, keep=False):
     import saragan_amd.optimization as opt
     from saragan_amd.ExtendedEMA import ExtendedEMA
     from saragan_amd.networks import loss as L
@@ -22,32 +25,55 @@ def _run(golden_dir, steps, dtype, captured):
     from saragan_amd.networks.pgan.generator import generator
     from saragan_amd.varstore import VariableStore, set_compute_dtype, use_store
     fx = load_step_fixture(os.path.join(golden_dir, NAME), torch.float64)
-    os.environ['SARAGAN_HIPGRAPH'] = '1' if captured else '0'
+    if captured == 'auto':
+        os.environ.pop('SARAGAN_HIPGRAPH', None)
+    else:
+        os.environ['SARAGAN_HIPGRAPH'] = '1' if captured else '0'
     set_compute_dtype(dtype)
     try:
         store = VariableStore('cuda', seed=0)
         L.set_random_source(L.RandomSource(1234, 'cuda'))
-        og = opt.AdamOptimizer(ScalarVariable(1e-3, 'g_lr'), 0.0, 0.9)
-        od = opt.AdamOptimizer(ScalarVariable(1e-3, 'd_lr'), 0.0, 0.9)
+        g_lr, d_lr = ScalarVariable(1e-3, 'g_lr'), ScalarVariable(1e-3, 'd_lr')
+        og = opt.AdamOptimizer(g_lr, 0.0, 0.9)
+        od = opt.AdamOptimizer(d_lr, 0.0, 0.9)
         ph = opt.Placeholder([4, 1, 1, 1, 1])
+        alpha = ScalarVariable(0.95 if mixing else 0.0, 'alpha')
+        freeze = None
+        if mixing:      # quirk Q4: the previous phase's variables stay frozen while alpha > 0
+            from oracle import pgan_oracle as O
+            freeze = list(O.variable_shapes(fx['phase'] - 1, BASE_SHAPE, LATENT, KERNEL_SPEC, FILTER_SPEC).keys())
         with use_store(store):
-            tup = opt.optimize_step(og, od, generator, discriminator, ph, LATENT, ScalarVariable(0.0, 'alpha'), fx['phase'],
+            tup = opt.optimize_step(og, od, generator, discriminator, ph, LATENT, alpha, fx['phase'],
                                     BASE_SHAPE, KERNEL_SPEC, FILTER_SPEC, 'leaky_relu', 0.2, 'wgan', fx['cfg']['gp_weight'],
-                                    'simultaneous', False, False, 0.01, None)
+                                    'simultaneous', clipping, clipping, 0.01, freeze)
         store.load_state_dict(dict(fx['p0']), strict=True)
         ema = ExtendedEMA(list(store.vars.keys()), 0.99, graph=tup[0].graph)
         ema_op = ema.apply()
         sess = opt.Session('cuda')
         g = torch.Generator().manual_seed(5)
-        losses = []
+        losses, kept = [], []
+        tg, td = (tup[12], tup[16]) if mixing else (tup[0], tup[1])
+        fetch = [tg, td, tup[2], tup[3]] + ([tup[10], tup[11]] if clipping and not mixing else [])
         for i in range(steps):
+            g_lr.assign(1e-3 * (1.0 + 0.1 * i))       # a schedule: the step size moves every step
+            d_lr.assign(1e-3 * (1.0 - 0.05 * i))
             real = (fx['real'].float() + 0.1 * torch.randn(fx['real'].shape, generator=g)).cuda()
-            _, _, gl, dl = sess.run([tup[0], tup[1], tup[2], tup[3]], feed_dict={ph: real})
+            res = sess.run(fetch, feed_dict={ph: real})
+            gl, dl = res[2], res[3]
             sess.run(ema_op)
-            losses.append((float(gl), float(dl)))
+            if keep:
+                kept.append((gl, dl))                 # read only after the loop: a fetched tensor is the caller's to keep
+            else:
+                losses.append((float(gl), float(dl)) + tuple(float(v) for v in res[4:]))
+            if mixing:
+                alpha.assign(max(float(alpha.eval()) - 0.11, 0.0))
+        if keep:
+            losses = [(float(a), float(b)) for a, b in kept]
         graph = tup[0].graph
         ncap = sum(1 for e in graph.__dict__.get('_captures', {}).values() if 'graph' in e)
-        return {k: v.detach().clone() for k, v in store.vars.items()}, losses, ncap
+        state = {k: v.detach().clone() for k, v in store.vars.items()}
+        state.update({'ema/' + p: ema.shadow_flat(p).clone() for p in ('generator/', 'discriminator/')})
+        return state, losses, ncap
     finally:
         os.environ['SARAGAN_HIPGRAPH'] = '0'
         set_compute_dtype(torch.float32)
@@ -68,3 +94,66 @@ def test_captured_step_equals_eager_step_bit_for_bit(golden_dir, dtype):
     bad = [k for k in w0 if not torch.equal(w0[k], w1[k])]
     assert not bad, bad
     assert all(abs(v) < 1e6 for pair in l0 for v in pair)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_captured_mixing_phase_replays_one_graph(golden_dir, dtype):
+    """alpha moves every step (networks/ops.py:4-23) and the freeze train ops run (quirk Q4): ONE captured graph serves the
+    whole phase -- alpha and 1 - alpha are device scalars -- and equals the eager run bit for bit (weights, EMA shadows, losses)."""
+    import saragan_amd
+    saragan_amd.set_deterministic(True)
+    try:
+        w0, l0, n0 = _run(golden_dir, 7, dtype, captured=False, mixing=True)
+        w1, l1, n1 = _run(golden_dir, 7, dtype, captured=True, mixing=True)
+    finally:
+        saragan_amd.set_deterministic(False)
+    assert n0 == 0 and n1 == 1, (n0, n1)
+    assert l0 == l1, (l0, l1)
+    assert len({a for a, _ in l0}) == len(l0)   # the losses do move with alpha: the replays did not reuse a stale weight
+    bad = [k for k in w0 if not torch.equal(w0[k], w1[k])]
+    assert not bad, bad
+
+
+def test_captured_step_with_clipping_norm_fetches_and_kept_outputs(golden_dir):
+    """Global-norm clipping and the max-norm fetches inside the graph; fetched tensors stay valid after later replays
+    (the replay path used to hand out aliases of the graph's static output buffers)."""
+    import saragan_amd
+    saragan_amd.set_deterministic(True)
+    try:
+        w0, l0, _ = _run(golden_dir, 6, torch.float32, captured=False, clipping=True)
+        w1, l1, n1 = _run(golden_dir, 6, torch.float32, captured=True, clipping=True)
+        _, l2, _ = _run(golden_dir, 6, torch.float32, captured=True, keep=True)
+        _, l3, _ = _run(golden_dir, 6, torch.float32, captured=False)
+    finally:
+        saragan_amd.set_deterministic(False)
+    assert n1 == 1
+    assert l0 == l1, (l0, l1)
+    assert not [k for k in w0 if not torch.equal(w0[k], w1[k])]
+    assert l2 == [v[:2] for v in l3], (l2, l3)
+
+
+def test_host_bound_step_is_captured_without_a_switch(golden_dir):
+    """No SARAGAN_HIPGRAPH in the environment: the toy step (a few hundred 10-microsecond kernels behind Python) measures
+    host-bound on its eager steps 2 and 3 and is captured; same results as the eager run."""
+    import saragan_amd
+    saragan_amd.set_deterministic(True)
+    try:
+        w0, l0, _ = _run(golden_dir, 8, torch.float32, captured=False)
+        w1, l1, n1 = _run(golden_dir, 8, torch.float32, captured='auto')
+    finally:
+        saragan_amd.set_deterministic(False)
+    assert n1 == 1, n1
+    assert l0 == l1
+    assert not [k for k in w0 if not torch.equal(w0[k], w1[k])]
+
+
+def test_capture_refuses_a_live_autograd_graph():
+    """the invariant behind round 3's hipStreamEndCapture crash is checked, not assumed (CPU-visible state)."""
+    import saragan_amd.optimization as opt
+    ps = [torch.nn.Parameter(torch.randn(4, device='cuda')) for _ in range(3)]
+    opt.StepGraph.assert_no_live_accumulate_grad(ps)
+    y = (ps[2] * 2).sum()
+    with pytest.raises(RuntimeError, match='AccumulateGrad'):
+        opt.StepGraph.assert_no_live_accumulate_grad(ps)
+    del y
+    opt.StepGraph.assert_no_live_accumulate_grad(ps)

@@ -39,7 +39,12 @@ CONFIGS = {   # BASELINE.json configs[i-1]: SURVEY.md section 8d
     3: dict(size='s', phase=6, latent=512, batch=32, dtype='bf16', alpha=0.0, dims=3),
     4: dict(size='m', phase=7, latent=512, batch=2, dtype='bf16', alpha=0.5, dims=3),
     5: dict(size='xs', phase=9, latent=512, batch=4, dtype='f32', alpha=0.0, dims=2),
+    # the reference's OWN operating point, the only throughput it publishes (SURFGAN_3D/out.txt:18,78,84-1639: 'xs' phase 5,
+    # 64x64x16, WGAN-GP 10, latent 512, LOCAL batch 2 on each of 8 Horovod ranks: 47.15 img/s global = 5.9 per GPU).
+    # `--config out_txt`; --batch 4 / 8 show what the small local batches of data parallelism at 128^2 / 256^2 cost.
+    6: dict(size='xs', phase=5, latent=512, batch=2, dtype='bf16', alpha=0.0, dims=3),
 }
+CONFIG_NAMES = {'out_txt': 6}
 
 
 def parse():
@@ -47,7 +52,8 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--config', type=int, default=3, choices=sorted(CONFIGS))
+    ap.add_argument('--config', type=lambda v: CONFIG_NAMES[v] if v in CONFIG_NAMES else int(v), default=3, choices=sorted(CONFIGS),
+                    help='1..5: BASELINE.json configs[i-1]; out_txt (6): the reference log\'s own operating point')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the configuration\'s)')
     ap.add_argument('--size', default=None)
     ap.add_argument('--phase', type=int, default=None)
@@ -294,6 +300,23 @@ def pmc_traffic(entry, dtype):
                 e.get('variant', '').startswith(('fwd bias', 'wgrad', 'bias', 'with'))]
         if hits and not s.upsample_in:
             return round(sum(hits) / len(hits))
+    return None
+
+
+def sustained_mfma_peak(dtype):
+    """TFLOP/s this board SUSTAINS on bare v_mfma_f32_32x32x16_bf16 with random operands (register-only loop, all 256 CUs,
+    6 s: tools/probe/mfma_ceiling.hip, committed as profiles/r04_mfma_ceiling.txt with the clock, power and power cap
+    beside it): the chip lowers its clock under MFMA load, so the 2.5 PFLOP/s spec peak is not reachable by ANY kernel on
+    random data.  None for f32 (the f32 MFMA runs at the vector rate and is not clock-limited the same way) or when the
+    file is not there."""
+    if dtype != 'bf16':
+        return None
+    path = os.path.join(ROOT, 'profiles', 'r04_mfma_ceiling.txt')
+    if not os.path.exists(path):
+        return None
+    for ln in open(path):
+        if ln.startswith('SUSTAINED_PEAK_32x32x16_TFLOPS'):
+            return float(ln.split()[1])
     return None
 
 
@@ -635,6 +658,9 @@ def main():
             roof = dict(bound='hbm', achieved=round(gbs, 1), peak=HBM_PEAK / 1e9, unit='GB/s', frac=round(gbs * 1e9 / HBM_PEAK, 4))
         else:
             roof = dict(bound='mfma', achieved=round(ach, 2), peak=peak, unit='TFLOP/s', frac=round(ach / peak, 4))
+            sp = sustained_mfma_peak(args.dtype)
+            if sp:      # what the board sustains on bare MFMAs with random operands (profiles/r04_mfma_ceiling.txt)
+                roof.update(sustained_peak=sp, frac_of_sustained=round(ach / sp, 4))
         roof.update(traffic=pmc_traffic(best, args.dtype), kernel=best.kernel.decode(),
                     shape=dict(n=s.n, d=s.d, h=s.h, w=s.w, cin=s.cin, cout=s.cout, k=[s.kd, s.kh, s.kw],
                                upsample_in=s.upsample_in),
@@ -658,7 +684,9 @@ def main():
                value=round(value, 3), unit=unit,
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
                higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.dtype, data='synthetic',
-               config=dict(workload=f"BASELINE configs[{args.config - 1}]: pgan '{args.size}' phase {args.phase} G+D step, "
+               config=dict(workload=(f"BASELINE configs[{args.config - 1}]" if args.config <= 5 else
+                                     "the reference's own operating point (SURFGAN_3D/out.txt:18,78: 47.15 img/s over 8 ranks)") +
+                                    f": pgan '{args.size}' phase {args.phase} G+D step, "
                                     f"{'volumes' if args.dims == 3 else 'images'} {'x'.join(str(v) for v in sh[2:])}, "
                                     f"{args.loss}-gp, simultaneous, alpha {args.alpha}",
                            fade_branch=('pruned: alpha is exactly 0 or 1, results identical (DESIGN.md 4.5; '

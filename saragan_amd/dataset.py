@@ -141,7 +141,11 @@ class NumpyPathDataset:
         part = object.__new__(NumpyPathDataset)
         part.__dict__.update(self.__dict__)
         part.npy_files, part.scratch_files = self.npy_files[lo:hi], self.scratch_files[lo:hi]
-        part._rng = random.Random(self._rng.random())       # children shuffle independently of the parent
+        # children shuffle independently of the parent -- and WITHOUT advancing its generator: the order of the training
+        # batches (drawn from the full set: quirk Q3) must not depend on whether a validation split was made
+        probe = random.Random()
+        probe.setstate(self._rng.getstate())
+        part._rng = random.Random(f'{probe.random()!r}:{lo}:{hi}')
         part._deck = _Deck(len(part.scratch_files), part._rng)
         return part
 

@@ -83,6 +83,18 @@ def build_parser():
     p.add_argument('--d_momentum', type=none_or_float, default=0.9)
     p.add_argument('--data_mean', default=None, type=float)
     p.add_argument('--data_stddev', default=None, type=float)
+    # validation split and in-loop metrics (main.py:255-256,319-333); --compute_FID is accepted and refused (needs a download)
+    p.add_argument('--validation_fraction', default=0.1, type=float)
+    p.add_argument('--test_fraction', default=0.1, type=float)
+    p.add_argument('--calc_metrics', default=False, action='store_true')
+    p.add_argument('--compute_metrics_train', default=False, action='store_true')
+    p.add_argument('--disable_compute_metrics_validation', dest='compute_metrics_validation', default=True, action='store_false')
+    p.add_argument('--disable_compute_metrics_test', dest='compute_metrics_test', default=True, action='store_false')
+    p.add_argument('--num_metric_samples', type=int, default=None)
+    p.add_argument('--metrics_every_nsteps', default=128, type=int)
+    p.add_argument('--metrics_batch_size', default=16, type=int)
+    for m in ('FID', 'swds', 'ssims', 'psnrs', 'mses', 'nrmses'):
+        p.add_argument(f'--compute_{m}', default=False, action='store_true')
     p.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'], help='activation / MFMA input type (new flag)')
     p.add_argument('--max_steps_per_phase', type=int, default=None, help='smoke runs: cap the steps per phase (new flag)')
     return p

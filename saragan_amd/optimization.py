@@ -241,6 +241,19 @@ class StepGraph:
         self._wanted = {(f.key, f.net) for f in fetches}
         real = feed
         out = {}
+        if all(f.key == 'gen_sample' for f in fetches):
+            # sess.run(gen_sample) (metrics/save_metrics.py:104: fake images for the validation metrics): TF prunes the graph
+            # to the generator; so does this -- fresh latents, the current weights and alpha, no discriminator pass
+            from .networks import loss as L
+            n = c['placeholder'].shape[0]
+            dev = self.store.device if real is None else real.device
+            with use_store(self.store), torch.no_grad():
+                alpha = float(c['alpha'].eval()) if isinstance(c['alpha'], ScalarVariable) else float(c['alpha'])
+                z = L._rng(dev).latent(n, c['latent_dim'], dev)
+                sample = c['generator'](z, alpha, c['phase'], c['base_shape'], activation=c['activation'],
+                                        kernel_spec=c['kernel_spec'], filter_spec=c['filter_spec'], param=c['leakiness'])
+            F.clear_pack_cache()
+            return [sample.detach() for _ in fetches]
         with use_store(self.store), torch.enable_grad():
             alpha = float(c['alpha'].eval()) if isinstance(c['alpha'], ScalarVariable) else float(c['alpha'])
             net_args = (c['latent_dim'], alpha, c['phase'], c['base_shape'], c['kernel_spec'], c['filter_spec'],
@@ -538,7 +551,15 @@ class StepGraph:
             else:
                 out[('max_norm', tid)] = torch.sqrt(sq).max()
         out[('gradients', tid)] = [self.store.vars[n].grad for n in names]
-        if apply:
+        if apply and info['dist'] is not None and getattr(info['dist'], 'delta_form', False):
+            # hvd.Adasum on a TF1 optimizer (parallel.AdasumReducer): local step, then the ranks' weight deltas are combined.
+            # The EMA update must see the combined weights: it is left to ExtendedEMA.apply (these ranges stay unmarked).
+            lo, hi = info['dist'].hull()
+            start = flat['param'][lo:hi].clone()
+            tr['optimizer'].apply(info['prefix'], flat, ranges, gscale, None, 0.0)
+            info['dist'].combine_deltas(flat['param'], start)
+            F.clear_pack_cache()
+        elif apply:
             ema_flat = self.ema.shadow_flat(info['prefix']) if self.ema is not None else None
             ema_decay = self.ema.decay if self.ema is not None else 0.0
             if lr_dev is not None:
@@ -654,6 +675,11 @@ class Session:
                 raise TypeError(f'cannot run {f!r}')
         for graph, idxs in graphs.values():
             ph = graph.cfg['placeholder']
+            if all(fl[i].key == 'gen_sample' for i in idxs) and (feed_dict is None or ph not in feed_dict):
+                vals = graph.run([fl[i] for i in idxs], None)      # the generator alone needs no real batch
+                for i, v in zip(idxs, vals):
+                    results[i] = v
+                continue
             if feed_dict is None or ph not in feed_dict:
                 raise ValueError('real_image_input must be fed')
             batch = feed_dict[ph]

@@ -231,11 +231,16 @@ def adasum_pair(a, b, seg, nseg):
 
 
 class AdasumReducer(GradientAllReducer):
-    """hvd.DistributedOptimizer(optimizer, op=hvd.Adasum) (optuna_objective.py:182-183): the ranks' gradients are
-    combined by the Adasum rule along a binary tree (ranks (0,1), (2,3), ... first, then pairs of pairs) instead of
-    being averaged.  Here every rank gathers all gradients (one all_gather of the flat buffer: 8 x 116 MB for the largest
-    discriminator of the presets) and evaluates the tree locally, so all ranks hold bit-identical results; the world
-    size must be a power of two, as Horovod requires.  Not overlapped with backward (the rule needs whole tensors)."""
+    """hvd.DistributedOptimizer(optimizer, op=hvd.Adasum) (optuna_objective.py:182-183) in the form Horovod gives a TF1
+    optimizer (`_DistributedAdasumOptimizer`, horovod/tensorflow/__init__.py of 0.19 -- third-party, not in the reference tree,
+    restated from its published behaviour): compute_gradients, clipping and the gradient norms stay LOCAL; apply_gradients
+    keeps the variables' start values, applies the local optimiser step, combines the ranks' weight DELTAS (var - start) by
+    the Adasum rule and writes start + combined delta.  (Adam normalises the gradient's scale, so Adasum of the gradients
+    followed by Adam -- what rounds 2-3 did -- is a different update.)  The rule runs along a binary tree (ranks (0,1), (2,3),
+    ... first, then pairs of pairs); every rank gathers all deltas (one all_gather of the flat range: 8 x 116 MB for the
+    largest discriminator of the presets) and evaluates the tree locally, so all ranks hold bit-identical weights; the world
+    size must be a power of two, as Horovod requires.  optimization.StepGraph._finish drives it (`delta_form`)."""
+    delta_form = True
 
     def __init__(self, group=None, bucket_bytes=None):
         super().__init__(group, bucket_bytes)
@@ -251,6 +256,9 @@ class AdasumReducer(GradientAllReducer):
         self._flat, self._ranges, self._params = flat_grad, list(ranges), list(params)
         self._armed = False
 
+    def finish(self):
+        """Nothing to wait for: the gradients are not reduced in this form."""
+
     def _segments(self, lo, hi):
         key = (self._flat.data_ptr(), lo, hi, len(self._params))
         if key != self._seg_key:
@@ -262,12 +270,17 @@ class AdasumReducer(GradientAllReducer):
             self._seg, self._nseg, self._seg_key = seg.to(self._flat.device), len(self._params) + 1, key
         return self._seg, self._nseg
 
-    def finish(self):
+    def hull(self):
+        """[lo, hi) of the flat buffers that the armed ranges span."""
+        return min(o for o, _ in self._ranges), max(o + n for o, n in self._ranges)
+
+    def combine(self, vec):
+        """In place: vec[lo:hi] (one flat vector per rank, laid out like the gradient buffer begin() was given) becomes the
+        Adasum of the ranks' vectors, per tensor."""
         if (self.world_size == 1 and not (forced() and dist.is_initialized())) or not self._ranges:
             return
-        lo = min(o for o, _ in self._ranges)
-        hi = max(o + n for o, n in self._ranges)
-        mine = self._flat[lo:hi]
+        lo, hi = self.hull()
+        mine = vec[lo:hi]
         allg = torch.empty(self.world_size * (hi - lo), device=mine.device, dtype=mine.dtype)
         dist.all_gather_into_tensor(allg, mine.contiguous(), group=self.group)
         allg = allg.view(self.world_size, hi - lo)
@@ -276,6 +289,15 @@ class AdasumReducer(GradientAllReducer):
         while len(level) > 1:
             level = [adasum_pair(level[i], level[i + 1], seg, nseg) for i in range(0, len(level), 2)]
         mine.copy_(level[0])
+
+    def combine_deltas(self, param_flat, start):
+        """After the LOCAL optimiser step: param[lo:hi] = start + Adasum over ranks of (param[lo:hi] - start); `start` is the
+        clone of param_flat[lo:hi] taken before the step."""
+        lo, hi = self.hull()
+        delta = torch.zeros_like(param_flat)
+        delta[lo:hi] = param_flat[lo:hi] - start
+        self.combine(delta)
+        param_flat[lo:hi] = start + delta[lo:hi]
 
 
 def DistributedOptimizer(optimizer, group=None, bucket_bytes=None, op=Average):

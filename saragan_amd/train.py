@@ -1,7 +1,9 @@
 """The training loop of SURFGAN_3D/optuna_objective.py:98-600 for a normal run (trial=None), on the HIP path:
-per-phase graph build, restore from the previous phase, mixing / stabilising loop with alpha, learning-rate and
-EMA ops, periodic and end-of-phase checkpoints.  TensorBoard summaries, metrics (FID/SWD/...) and optuna are out
-of scope.  Reference quirks Q2-Q5 are reproduced (see comments)."""
+per-phase graph build, train / validation / test split, restore from the previous phase, mixing / stabilising loop with
+alpha, learning-rate and EMA ops, the validation metrics every --metrics_every_nsteps images and at the end of a phase
+(SWD / SSIM / PSNR / MSE / NRMSE on the GPU: metrics/save_metrics.py), periodic and end-of-phase checkpoints.
+TensorBoard summaries, FID and optuna are out of scope.  Reference quirks Q2-Q5 are
+reproduced (see comments)."""
 import gc
 import importlib
 import os
@@ -15,11 +17,12 @@ from . import optimization as opt
 from . import parallel
 from .ExtendedEMA import ExtendedEMA
 from .dataset import NumpyPathDataset, PinnedPrefetcher, normalize_numpy
+from .metrics.save_metrics import get_compute_metrics_dict, save_metrics
 from .networks import loss as L
 from .networks import ops as nops
 from .networks.ops import ScalarVariable
-from .utils import (get_base_shape, get_current_input_shape, get_num_phases, get_xy_dim, print_summary_to_stdout,
-                    restore_variables, save_checkpoint, scale_lr)
+from .utils import (get_base_shape, get_current_input_shape, get_num_metric_samples, get_num_phases, get_xy_dim,
+                    print_summary_to_stdout, restore_variables, save_checkpoint, scale_lr)
 from .varstore import VariableStore, set_compute_dtype, use_store
 
 
@@ -68,6 +71,19 @@ def run_training(args, device=None, max_steps_per_phase=None, log_every=1):
         npy_data = get_numpy_dataset(phase, args.starting_phase, args.start_shape, args.dataset_path,
                                      args.scratch_path, verbose, rank if horovod else 0, global_size, seed=args.seed,
                                      local_rank=local)
+        # :121-124: the split keeps the file order (consecutive scans of one patient stay on one side); quirk Q3: the
+        # training batches below are still drawn from the FULL set npy_data, as the reference's are (:423-425)
+        vf, tf_ = getattr(args, 'validation_fraction', 0.0) or 0.0, getattr(args, 'test_fraction', 0.0) or 0.0
+        npy_data_train = npy_data_validation = npy_data_test = None
+        if vf + tf_ > 0 and phase >= args.starting_phase and len(npy_data) >= 3:
+            try:
+                npy_data_train, npy_data_testval = npy_data.split_by_fraction(1 - (vf + tf_))
+                npy_data_validation, npy_data_test = npy_data_testval.split_by_fraction(vf / (vf + tf_))
+                if verbose:
+                    print(f"Split dataset of {len(npy_data)} samples: train {len(npy_data_train)}, validation "
+                          f"{len(npy_data_validation)}, test {len(npy_data_test)}")
+            except AssertionError:      # a subset came out empty (tiny data sets): no split, no metrics
+                npy_data_train = npy_data_validation = npy_data_test = None
         batch_size = max(1, args.base_batch_size // (2 ** (phase - 1)))            # :127
         if args.max_global_batch_size is not None:                                # :130-136 (quirk Q6: float)
             max_local_batch_size = args.max_global_batch_size / global_size
@@ -75,6 +91,19 @@ def run_training(args, device=None, max_steps_per_phase=None, log_every=1):
                 batch_size = int(max_local_batch_size)
             assert batch_size * global_size <= args.max_global_batch_size
         real_image_input = opt.Placeholder(get_current_input_shape(phase, batch_size, args.start_shape))
+        num_metric_samples = get_num_metric_samples(getattr(args, 'num_metric_samples', None), batch_size, global_size)  # :144
+        calc_metrics = bool(getattr(args, 'calc_metrics', False)) and npy_data_validation is not None
+        metric_flags = get_compute_metrics_dict(args)
+        metric_tap = getattr(args, '_metric_tap', None)      # tests: receives (tag, metrics dict, batches)
+
+        def run_metrics(subset, nsamples, suffix='', tag='loop'):
+            kept = [] if metric_tap is not None else None
+            m = save_metrics(None, sess, subset, gen_sample, getattr(args, 'metrics_batch_size', 16), global_size, global_step,
+                             get_xy_dim(phase, args.start_shape), horovod, False, metric_flags, nsamples, args.data_mean,
+                             args.data_stddev, verbose, suffix=suffix, keep=kept)
+            if metric_tap is not None:
+                metric_tap.append((phase, tag + suffix, m, kept))
+            return m
 
         g_lr0, d_lr0 = scale_lr(args.g_lr, args.d_lr, args.g_scaling, args.d_scaling, horovod, global_size)
         d_lr = ScalarVariable(d_lr0, 'd_lr')
@@ -144,6 +173,7 @@ def run_training(args, device=None, max_steps_per_phase=None, log_every=1):
                 if verbose:
                     save_checkpoint(store, os.path.join(logdir, f'model_{phase}_ckpt_{global_step}'))
             batch = loader.next()
+            metrics_summary_bool = local_step % getattr(args, 'metrics_every_nsteps', 128) < batch_size      # :443
             if mixing_bool:      # quirk Q4: previous-phase variables stay frozen while alpha > 0
                 train_g, train_d = train_gen_freeze or train_gen, train_disc_freeze or train_disc
             else:
@@ -171,6 +201,11 @@ def run_training(args, device=None, max_steps_per_phase=None, log_every=1):
             if mixing_bool:
                 sess.run(update_alpha)
             in_phase_step = sess.run(update_intra_phase_step)
+            if metrics_summary_bool and calc_metrics:      # :500-507: on the training weights, then on the EMA weights
+                run_metrics(npy_data_validation, num_metric_samples)
+                sess.run(ema.assign_ema_weights())
+                run_metrics(npy_data_validation, num_metric_samples, suffix='_EMA')
+                sess.run(ema.restore_original_weights())
             if want_log:
                 print_summary_to_stdout(global_step, int(in_phase_step), img_s, local_img_s, d_loss, g_loss,
                                         float(d_lr_val), float(g_lr_val), alpha)
@@ -197,6 +232,24 @@ def run_training(args, device=None, max_steps_per_phase=None, log_every=1):
         if verbose:
             print(f"Writing final checkpoint file: model_{phase}")
             save_checkpoint(store, os.path.join(logdir, f'model_{phase}'))
+        # :593-627: metrics on the whole test / validation (/ training) subsets under the EMA weights.  (The reference runs
+        # these loops even with no metric enabled; with none enabled nothing would be computed, so they are skipped here.)
+        if npy_data_validation is not None and any(metric_flags.values()):
+            if verbose:
+                print(f"Computing final metrics for phase {phase} ...")
+            sess.run(ema.assign_ema_weights())
+            for on, subset, label, tag in ((getattr(args, 'compute_metrics_test', True), npy_data_test, 'Test', 'test'),
+                                           (getattr(args, 'compute_metrics_validation', True), npy_data_validation, 'Validation', 'validation'),
+                                           (getattr(args, 'compute_metrics_train', False), npy_data_train, 'Training', 'train')):
+                if on and subset is not None:
+                    t0 = time.time()
+                    m = run_metrics(subset, len(subset), tag=tag)
+                    if verbose:
+                        print(f"Computing metrics on {label.lower()} set took {time.time() - t0} seconds")
+                        print(f"{label} dataset metrics:")
+                        print(m)
+                    stats[phase][f'metrics_{tag}'] = m
+            sess.run(ema.restore_original_weights())
         if world > 1:
             torch.distributed.barrier()
     return dict(stats=stats, store=store, logdir=logdir)

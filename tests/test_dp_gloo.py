@@ -138,7 +138,7 @@ def _worker_algos(rank, world, port, q):
     params = [store.vars[k] for k in names]
     ranges = [(offs[k][0], (offs[k][1] + 3) // 4 * 4) for k in names]
 
-    def run(red):
+    def run(red, combine=False):
         flat['grad'].zero_()
         for p_, k in zip(params, names):
             o, n = offs[k]
@@ -148,6 +148,8 @@ def _worker_algos(rank, world, port, q):
         red.begin(flat['grad'], ranges, params)
         torch.autograd.backward(loss, inputs=params)
         red.finish()
+        if combine:       # the Adasum rule itself, on the vectors the backward left in the flat buffer
+            red.combine(flat['grad'])
         return flat['grad'].clone().numpy()
 
     out = dict(info=info)
@@ -162,7 +164,19 @@ def _worker_algos(rank, world, port, q):
     os.environ['SARAGAN_DP_ALGO'] = 'allreduce'
     ada = parallel.DistributedOptimizer(type('O', (), {})(), op=parallel.Adasum).distributed
     assert isinstance(ada, parallel.AdasumReducer) and ada.grad_scale == 1.0
-    out['adasum'] = run(ada)
+    local = run(ada)                 # delta form: finish() leaves the gradients LOCAL (Horovod's _DistributedAdasumOptimizer)
+    out['adasum_local'] = local
+    out['adasum'] = run(ada, combine=True)
+    # the delta form end to end with a stand-in local optimiser (p -= 0.1 * g): start + Adasum_r(p_r - start)
+    run(ada)
+    before = flat['param'].clone()
+    lo, hi = ada.hull()
+    start = flat['param'][lo:hi].clone()
+    with torch.no_grad():
+        for (o, n) in ranges:
+            flat['param'][o:o + n] -= 0.1 * flat['grad'][o:o + n]
+    ada.combine_deltas(flat['param'], start)
+    out['adasum_delta'] = (flat['param'] - before).clone().numpy()
     out['segments'] = [offs[k] for k in names]
     q.put((rank, out))
     dist.barrier()
@@ -214,3 +228,10 @@ def test_reduce_scatter_all_gather_form_and_adasum(world):
         for lo, hi in segs:
             np.testing.assert_allclose(out['adasum'][lo:hi], want[lo:hi], rtol=1e-5, atol=1e-6)
         assert np.array_equal(out['adasum'], res[0]['adasum'])
+        # hvd.Adasum on a TF1 optimizer combines WEIGHT DELTAS after a local step, not gradients
+        want_delta = _adasum_numpy([-0.1 * v for v in per_rank], segs)
+        for lo, hi in segs:
+            np.testing.assert_allclose(out['adasum_delta'][lo:hi], want_delta[lo:hi], rtol=1e-5, atol=1e-6)
+        assert np.array_equal(out['adasum_delta'], res[0]['adasum_delta'])
+    for r, out in enumerate(res):      # finish() reduced nothing: every rank still holds its own gradient
+        np.testing.assert_allclose(out['adasum_local'], per_rank[r], rtol=1e-6, atol=1e-6)

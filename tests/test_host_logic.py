@@ -190,7 +190,8 @@ def test_cli_flags_of_the_reference_parse():
             '--adam_beta2', '0.939014', '--calc_metrics', '--compute_FID']   # scripts/example_normal_run.jb:70-80
     args, unknown = build_parser().parse_known_args(argv)
     args = finalize_args(args)
-    assert unknown == ['--calc_metrics', '--compute_FID']
+    assert unknown == [] and args.calc_metrics and args.compute_FID       # round 4: the metric flags are honoured (FID: warned, skipped)
+    assert args.validation_fraction == 0.1 and args.test_fraction == 0.1 and args.metrics_every_nsteps == 128
     assert args.d_adam_beta1 == pytest.approx(0.130724) and args.d_optimizer == 'Adam'
     assert args.filter_spec[0] == [128, 128] and len(args.kernel_spec) >= 5   # ops.py:223-232: 5*16*16 voxels -> list index 2
 

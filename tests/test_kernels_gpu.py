@@ -708,7 +708,11 @@ def test_conv_epilogue_fused_downscale(monkeypatch):
     yp = F.conv3d_act_pool(xg, wg, coef, bg, 0.2)
     gxp, gwp, gbp = torch.autograd.grad(yp, [xg, wg, bg], cl(gy, dtype))
     assert took == [True], 'the two-tensor layout was not used'
-    assert torch.equal(gxp, gxg.detach()), 'data gradient differs between the layouts'
+    # (round 4: the interleaved layouts run the one-pass kernel, the two-tensor layout still the two-pass K split: the same f32
+    # sums in another order, so a few results round to the neighbouring bf16 value)
+    nd = int((gxp.view(torch.int16) != gxg.detach().view(torch.int16)).sum())
+    assert nd <= 1e-3 * gxp.numel(), ('data gradient differs between the layouts', nd)
+    assert float((gxp.float() - gxg.detach().float()).abs().max()) <= 2.0 ** -7 * float(gxg.detach().float().abs().max())
     _mostly_close(gwp, gwr, 2e-3, 4e-3, 'dw (planes)')
     _mostly_close(gbp, gbr, 2e-3, 4e-3, 'db (planes)')
     # ... also when the layer's input is a LeakyReLU output whose mask this data gradient applies in its epilogue
@@ -743,6 +747,7 @@ def test_pooled_backward_gather_equals_the_two_tensor_path_at_the_benchmarked_si
       * with the one-pass kernel switched off (SG_FWD_NO_3P=1) both paths run the K split and are bit-identical, as in
         round 3;
       * weight and bias gradient to f32 summation order."""
+    import ctypes as C
     from saragan_amd import _lib
     from saragan_amd import functional as F
     lib = _lib.load()

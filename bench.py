@@ -65,6 +65,8 @@ def parse():
     ap.add_argument('--no-extras', action='store_true', help='skip the fp32 and loader-in-the-loop legs')
     ap.add_argument('--dump-prof', action='store_true', help='per-shape conv kernel table on stderr')
     ap.add_argument('--cpu-budget-s', type=float, default=14.0)
+    ap.add_argument('--dry-run', action='store_true',
+                    help='plumbing rehearsal of the N-rank launch on CPU tensors over gloo: no GPU, no throughput (see dry_run)')
     args = ap.parse_args()
     c = CONFIGS[args.config]
     for k in ('size', 'phase', 'latent', 'batch', 'dtype', 'alpha'):
@@ -86,7 +88,7 @@ def spawn_ranks(args):
     import torch
     have = torch.cuda.device_count()
     stack = bool(int(os.environ.get('SARAGAN_BENCH_STACK_RANKS', '0')))    # rehearsal: several ranks share one GPU (gloo)
-    if have < args.gpus and not (stack and have >= 1):
+    if have < args.gpus and not (stack and have >= 1) and not args.dry_run:
         print(f'bench.py: --gpus {args.gpus} but only {have} device(s) are visible', file=sys.stderr)
         return 3
     with socket.socket() as s:
@@ -465,17 +467,89 @@ def loader_leg(args, cfg, device, nsteps, barrier, snap=None):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+SETTLE_STEPS_MULTI_RANK = 60      # untimed steps after the warm-up when world > 1 (the count must match across ranks)
+
+
+def dry_run(args, rank, world):
+    """`--dry-run`: the plumbing of an N-rank launch exercised WITHOUT a GPU, so that the first real 8-GPU run cannot fail on
+    it: spawn_ranks (or torch.distributed.run) -> rendezvous on 127.0.0.1 -> the gradient reducer's bucketed all-reduce (gloo,
+    CPU tensors) inside every step -> W warm-up steps, the fixed SETTLE_STEPS_MULTI_RANK settle steps, K timed steps bracketed
+    by barriers -> MAX-reduce of the ranks' durations -> ONE JSON line from rank 0.  The line says "dry_run": true and carries
+    no throughput: nothing here measures anything but the launch path."""
+    import torch
+    from saragan_amd import parallel
+    numel = 1 << 18
+    param = torch.zeros(numel)
+    grad = torch.zeros(numel)
+    p_ = torch.nn.Parameter(param)
+    p_.grad = grad
+    red = parallel.GradientAllReducer(bucket_bytes=256 << 10)
+
+    def step(i):
+        grad.fill_(float(rank + 1) * (i + 1))
+        red.begin(grad, [(0, numel)], [p_])
+        red.finish()                                   # every bucket goes out here (no autograd hooks in the rehearsal)
+        param.add_(grad, alpha=-1e-3 * red.grad_scale)
+
+    def barrier():
+        if torch.distributed.is_initialized():
+            torch.distributed.barrier()
+
+    it = 0
+    for _ in range(args.warmup):
+        step(it)
+        it += 1
+    settle = SETTLE_STEPS_MULTI_RANK if world > 1 else 0
+    for _ in range(settle):
+        step(it)
+        it += 1
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(it)
+        it += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    same = True
+    if torch.distributed.is_initialized():
+        t = torch.tensor([dt], dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+        lo, hi = param.clone(), param.clone()
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        same = bool(torch.equal(lo, hi))
+    want = -1e-3 * sum(r + 1 for r in range(world)) / world * sum(range(1, it + 1))     # the averaged updates, in closed form
+    ok = same and abs(float(param[0]) - want) <= 1e-4 * abs(want)
+    if rank == 0:
+        print(json.dumps(dict(dry_run=True, metric='plumbing rehearsal on CPU tensors (gloo): no GPU work, no throughput',
+                              value=None, unit=None, n_gpus=world, steps=args.steps, warmup=args.warmup,
+                              ms_per_step=round(dt / args.steps * 1e3, 3), higher_is_better=True, scaling='weak',
+                              vs_baseline=None, dtype=None, data='synthetic',
+                              config=dict(workload='dry run', settle=dict(steps=settle), collective=parallel.collective_info(),
+                                          replicas_identical=same, update_matches_closed_form=ok))), flush=True)
+    if not ok:
+        raise SystemExit('dry run: the ranks disagree after the all-reduced updates')
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.dry_run:
+        os.environ['SARAGAN_DIST_BACKEND'] = 'gloo'
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(spawn_ranks(args))
     import ctypes as C
     import torch
     from saragan_amd import _lib, parallel
-    rank, world, local = parallel.init_distributed()
+    rank, world, local = parallel.init_distributed('gloo' if args.dry_run else None)
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: every rank must be started (torch.distributed.run, '
                          f'or plain `python bench.py --gpus N`, which spawns them)')
+    if args.dry_run:
+        return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU (the HIP path has no CPU fallback)')
     device = torch.device('cuda', local % max(1, torch.cuda.device_count()))   # (rehearsals may stack ranks on one GPU)
@@ -529,10 +603,10 @@ def main():
     if not os.environ.get('SARAGAN_BENCH_NO_SETTLE'):
         pi = args.warmup
         if world > 1:
-            for _ in range(60):
+            for _ in range(SETTLE_STEPS_MULTI_RANK):
                 step(pi)
                 pi += 1
-            preheat = dict(steps=60, rule='fixed (ranks must agree)')
+            preheat = dict(steps=SETTLE_STEPS_MULTI_RANK, rule='fixed (ranks must agree)')
         else:
             chunk_ms, t_begin = [], time.perf_counter()
             while True:

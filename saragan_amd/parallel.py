@@ -8,6 +8,9 @@ CPU for tests).  Replaces the reference's Horovod usage on the hot path:
 xGMI is point-to-point (7 links per GPU): large buckets amortise the ring's latency, but the bucket that becomes
 ready LAST is exposed (the generator's parameter-heavy low-resolution layers finish its backward), so the default
 is 32 MiB (SARAGAN_BUCKET_MIB overrides); the whole gradient of a small network still goes out as one message.
+SARAGAN_DP_GRAD_DTYPE=bf16 sends every bucket as bfloat16 (Horovod's Compression.fp16 of pgan_pytorch/main.py:149, with the
+wider exponent): the f32 gradients are rounded once into a staging bucket, summed by the collective in bf16, and widened back
+into the f32 flat buffer that the optimiser kernel reads and accumulates from in f32 -- half the bytes per xGMI link.
 SARAGAN_DP_ALGO selects how a bucket is summed: "allreduce" (default: one dist.all_reduce, RCCL picks the algorithm) or
 "rs_ag" (reduce-scatter then all-gather issued by hand -- on a fully connected xGMI node each of the two is one direct
 exchange over all 7 links; offered so that the first 8-GPU run can A/B it against RCCL's own choice).
@@ -91,6 +94,10 @@ class GradientAllReducer:
         self.algo = os.environ.get('SARAGAN_DP_ALGO', 'allreduce')
         if self.algo not in ('allreduce', 'rs_ag'):
             raise ValueError(f'SARAGAN_DP_ALGO must be "allreduce" or "rs_ag", got {self.algo!r}')
+        self.grad_dtype = os.environ.get('SARAGAN_DP_GRAD_DTYPE', 'f32')
+        if self.grad_dtype not in ('f32', 'bf16'):
+            raise ValueError(f'SARAGAN_DP_GRAD_DTYPE must be "f32" or "bf16", got {self.grad_dtype!r}')
+        self._widen = []       # (bf16 staging bucket, f32 slice it came from): copied back after the waits
         # in-order queues (RCCL: every collective of a group runs on that group's stream in issue order) let the
         # all-gather be issued right behind its reduce-scatter; other backends (gloo) get an explicit wait in between
         self._ordered = dist.is_initialized() and dist.get_backend(group) == 'nccl'
@@ -136,6 +143,7 @@ class GradientAllReducer:
             b['left'] = b['params']
             b['launched'] = False
         self._handles = []
+        self._widen = []
         self._armed = True
         if roots is not None:
             reach = reachable_leaves(roots)
@@ -152,6 +160,13 @@ class GradientAllReducer:
         b['launched'] = True
         if self.world_size > 1 or (forced() and dist.is_initialized()):
             view = self._flat[b['off']:b['off'] + b['len']]
+            if self.grad_dtype == 'bf16':      # one rounding on the way out; the collective sums in bf16
+                st = b.get('stage')
+                if st is None or st.numel() != view.numel() or st.device != view.device:
+                    st = b['stage'] = torch.empty(view.numel(), dtype=torch.bfloat16, device=view.device)
+                st.copy_(view)
+                self._widen.append((st, view))
+                view = st
             if self.algo == 'rs_ag':
                 self._launch_rs_ag(view)
             else:
@@ -195,6 +210,9 @@ class GradientAllReducer:
             span[0].record()
         for h in self._handles:
             h.wait()           # NCCL/RCCL: the current stream waits for the collective's stream; gloo: the host does
+        for st, view in self._widen:
+            view.copy_(st)     # back into the f32 buffer the optimiser reads (its state and arithmetic stay f32)
+        self._widen = []
         if span is not None:
             span[1].record()
             self._spans.append(span)
@@ -318,6 +336,8 @@ def collective_info(group=None):
         return None
     info = dict(backend=dist.get_backend(group), world_size=dist.get_world_size(group),
                 algo=os.environ.get('SARAGAN_DP_ALGO', 'allreduce'))
+    if os.environ.get('SARAGAN_DP_GRAD_DTYPE', 'f32') != 'f32':
+        info['grad_dtype'] = os.environ['SARAGAN_DP_GRAD_DTYPE']
     if info['backend'] == 'nccl':
         try:
             info['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())

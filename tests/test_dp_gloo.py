@@ -162,6 +162,14 @@ def _worker_algos(rank, world, port, q):
     except RuntimeError as e:           # a backend without reduce_scatter_tensor / all_gather_into_tensor
         out['rs_ag'] = f'unsupported: {e}'
     os.environ['SARAGAN_DP_ALGO'] = 'allreduce'
+    os.environ['SARAGAN_DP_GRAD_DTYPE'] = 'bf16'
+    try:
+        red16 = parallel.GradientAllReducer(bucket_bytes=44)
+        assert red16.grad_dtype == 'bf16'
+        out['bf16'] = run(red16)
+    except RuntimeError as e:           # a backend that cannot sum bfloat16
+        out['bf16'] = f'unsupported: {e}'
+    del os.environ['SARAGAN_DP_GRAD_DTYPE']
     ada = parallel.DistributedOptimizer(type('O', (), {})(), op=parallel.Adasum).distributed
     assert isinstance(ada, parallel.AdasumReducer) and ada.grad_scale == 1.0
     local = run(ada)                 # delta form: finish() leaves the gradients LOCAL (Horovod's _DistributedAdasumOptimizer)
@@ -223,6 +231,14 @@ def test_reduce_scatter_all_gather_form_and_adasum(world):
         if isinstance(out['rs_ag'], str):
             pytest.skip(out['rs_ag'])
         np.testing.assert_allclose(out['rs_ag'], want_sum, rtol=1e-6, atol=1e-6)
+        # SARAGAN_DP_GRAD_DTYPE=bf16: every rank's gradient is rounded once and the partial sums are rounded as the collective
+        # forms them: within (world) half-ulps of bf16 of the sum of magnitudes -- and identical on every rank
+        assert not isinstance(out['bf16'], str), out['bf16']      # gloo sums bfloat16 in this torch
+        if True:
+            mag = np.sum([np.abs(v) for v in per_rank], axis=0)
+            assert np.all(np.abs(out['bf16'] - want_sum) <= world * 2.0 ** -8 * mag + 1e-12)
+            assert np.array_equal(out['bf16'], res[0]['bf16'])
+            assert np.abs(out['bf16'] - want_sum).max() > 0          # it did go through bf16
         segs = [(o, o + n) for o, n in out['segments']]
         want = _adasum_numpy(per_rank, segs)
         for lo, hi in segs:

@@ -117,3 +117,80 @@ def test_single_rank_rccl_collectives_execute(golden_dir, algo):
     fx = load_step_fixture(os.path.join(golden_dir, NAME), torch.float64)
     for k, ref in fx['p1'].items():
         np.testing.assert_allclose(res[0][k], ref.numpy(), rtol=1e-4, atol=3e-5, err_msg=k)
+
+
+def _worker_captured(rank, world, port, golden, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0',
+                      SARAGAN_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    import saragan_amd
+    import saragan_amd.optimization as opt
+    from saragan_amd import parallel
+    from saragan_amd.ExtendedEMA import ExtendedEMA
+    from saragan_amd.networks import loss as L
+    from saragan_amd.networks.ops import ScalarVariable
+    from saragan_amd.networks.pgan.discriminator import discriminator
+    from saragan_amd.networks.pgan.generator import generator
+    from saragan_amd.varstore import VariableStore, set_compute_dtype, use_store
+    from tests.stepfix import BASE_SHAPE, FILTER_SPEC, KERNEL_SPEC, LATENT, load_step_fixture
+    parallel.init_distributed()
+    saragan_amd.set_deterministic(True)
+    fx = load_step_fixture(os.path.join(golden, NAME), torch.float64)
+    n = fx['real'].shape[0] // world
+    set_compute_dtype(torch.float32)
+    out = {}
+    for mode in ('0', '1'):
+        os.environ['SARAGAN_HIPGRAPH'] = mode
+        store = VariableStore('cuda', seed=100)
+        L.set_random_source(L.RandomSource(77 + rank, 'cuda'))
+        og = parallel.DistributedOptimizer(opt.AdamOptimizer(ScalarVariable(1e-3), 0.0, 0.9))
+        od = parallel.DistributedOptimizer(opt.AdamOptimizer(ScalarVariable(1e-3), 0.0, 0.9))
+        ph = opt.Placeholder([n, 1, 1, 1, 1])
+        with use_store(store):
+            tup = opt.optimize_step(og, od, generator, discriminator, ph, LATENT, ScalarVariable(0.0), fx['phase'], BASE_SHAPE,
+                                    KERNEL_SPEC, FILTER_SPEC, 'leaky_relu', 0.2, 'wgan', fx['cfg']['gp_weight'], 'simultaneous',
+                                    False, False, 0.01, None)
+        store.load_state_dict(fx['p0'], strict=True)
+        graph = tup[0].graph
+        ema = ExtendedEMA(list(store.vars), 0.99, graph=graph)
+        graph._ensure_flat()
+        parallel.broadcast_global_variables(store, 0)
+        ema.reset_to_variables()
+        sess = opt.Session('cuda')
+        g = torch.Generator().manual_seed(9 + rank)
+        losses = []
+        for i in range(5):
+            real = (fx['real'][rank * n:(rank + 1) * n].float() + 0.1 * torch.randn((n, *fx['real'].shape[1:]), generator=g)).cuda()
+            _, _, dl = sess.run([tup[0], tup[1], tup[3]], feed_dict={ph: real})
+            sess.run(ema.apply())
+            losses.append(float(dl))
+        torch.cuda.synchronize()
+        ncap = sum(1 for e in graph.__dict__.get('_captures', {}).values() if 'graph' in e)
+        out[mode] = (ncap, losses, {k: v.detach().cpu().numpy() for k, v in store.vars.items()})
+    q.put((rank, out))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_captured_step_with_a_gradient_reducer_attached(golden_dir):
+    """capture is no longer switched off when a reducer is attached.  The captured region is forward +
+    backward; the bucket collectives and the optimiser launches follow the replay.  Two ranks (gloo, both on cuda:0), five
+    steps: bit-identical to the eager data-parallel run, replicas identical."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_captured, args=(r, world, port, golden_dir, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for r in range(world):
+        (n0, l0, w0), (n1, l1, w1) = res[r]['0'], res[r]['1']
+        assert n0 == 0 and n1 == 1, (n0, n1)
+        assert l0 == l1, (l0, l1)
+        for k in w0:
+            np.testing.assert_array_equal(w0[k], w1[k], err_msg=f'rank {r} {k}')
+    for k in res[0]['1'][2]:
+        np.testing.assert_array_equal(res[0]['1'][2][k], res[1]['1'][2][k])

@@ -326,7 +326,7 @@ def mark(what):
     """SARAGAN_BENCH_MARK=1: wall-clock markers of the legs (tools/clock_trace.sh lines them up with rocm-smi samples)."""
     if os.environ.get('SARAGAN_BENCH_MARK'):
         print(f'MARK {time.time():.3f} {what}', flush=True)
-        if what.startswith('timed region'):      # ... and a marker kernel for tools/trace_windows.py (rocprofv3 --kernel-trace)
+        if what.startswith('timed region'):      # ... and a marker kernel for tools/archive/trace_windows.py (rocprofv3 --kernel-trace)
             import torch
             torch.zeros(3, device='cuda').cumsum(0)
 
@@ -365,7 +365,7 @@ class quiet_collector:
     time: a full pass of Python's cyclic collector over the ~10^6 objects of a torch process takes ~0.1 s, and one landed
     in a 10-step region now and then (a 57.8 ms/step run read 69.5 with every kernel at its usual duration).  Collect
     first, then keep the collector off for the K steps -- what `timeit` does; a step leaves no device memory in cycles
-    (tools/cycle_probe.py), and the product loop freezes its long-lived objects instead (train.py)."""
+    (tools/archive/cycle_probe.py), and the product loop freezes its long-lived objects instead (train.py)."""
 
     def __enter__(self):
         import gc

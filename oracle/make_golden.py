@@ -98,6 +98,20 @@ def reference_goldens():
     for name, q in G.named_parameters():
         arrs['p:' + name] = q
     npz('ref_generator_p1.npz', **arrs)
+    # --- generators of phases 2 and 3 with fade-in, plus the input gradient of sum(out) (round 4).  The port's block runs its
+    # second stage as conv -> norm -> act (network_dict.py:287-289): the oracle reproduces these with torch_port_order=True
+    for phase in (2, 3):
+        G = R.Generator(phase, num_phases, base_dim, latent, base_shape, 'leaky_relu', param=leak)
+        G.double()
+        z = torch.randn(3, latent, requires_grad=True)
+        alpha = 0.3
+        out = G(z, alpha)
+        (gz,) = torch.autograd.grad((out * torch.linspace(0.5, 1.5, out.numel()).reshape(out.shape)).sum(), z)
+        arrs = dict(z=z, out=out, grad_z=gz, alpha=alpha, leak=leak, base_dim=base_dim, latent=latent, phase=phase,
+                    num_phases=num_phases)
+        for name, q in G.named_parameters():
+            arrs['p:' + name] = q
+        npz(f'ref_generator_p{phase}.npz', **arrs)
     torch.set_default_dtype(torch.float32)
 
 
@@ -139,6 +153,8 @@ def oracle_goldens():
 
 if __name__ == '__main__':
     os.makedirs(GOLD, exist_ok=True)
-    if os.path.isdir(REF):
+    only = sys.argv[1] if len(sys.argv) > 1 else None      # `reference`: only the fixtures produced by running the reference
+    if os.path.isdir(REF) and only in (None, 'reference'):
         reference_goldens()
-    oracle_goldens()
+    if only in (None, 'oracle'):
+        oracle_goldens()

@@ -462,8 +462,12 @@ def init_params(phase, base_shape, latent_dim, kernel_spec, filter_spec, seed=0,
 
 
 def generator(p: Params, z, alpha, phase, base_shape, activation, kernel_spec, filter_spec,
-              param=None, conditioning=None):
-    """pgan/generator.py:74-103 (+ generator_in :26-45, generator_block :48-71)."""
+              param=None, conditioning=None, torch_port_order=False):
+    """pgan/generator.py:74-103 (+ generator_in :26-45, generator_block :48-71).
+    torch_port_order: the second stage of every block as the reference's OWN PyTorch port orders it,
+    conv -> bias -> norm -> act (pgan_pytorch/network_dict.py:287-289) where the TF graph has conv -> bias -> act -> norm
+    (pgan/generator.py:66-70).  Only used to pin this restatement against fixtures produced by running that port
+    (tests/golden/ref_generator_p{2,3}.npz); the product mirrors the TF graph."""
     if conditioning is not None:
         raise NotImplementedError()
     g = 'generator/'
@@ -492,7 +496,10 @@ def generator(p: Params, z, alpha, phase, base_shape, activation, kernel_spec, f
             x = conv3d(upscale3d(x), w1, activation, param)
         x = pn_stored(act(apply_bias(x, p[b + 'conv_1/bias']), activation, param))
         x = conv3d(x, p[b + 'conv_2/weight'], activation, param)
-        x = pn_stored(act(apply_bias(x, p[b + 'conv_2/bias']), activation, param))
+        if torch_port_order:
+            x = act(pixel_norm(apply_bias(x, p[b + 'conv_2/bias'])), activation, param)
+        else:
+            x = pn_stored(act(apply_bias(x, p[b + 'conv_2/bias']), activation, param))
     x_out = _q(apply_bias(conv3d(x, p[g + f'to_rgb_{phase}/weight'], 'linear'), p[g + f'to_rgb_{phase}/bias']))
     if x_upsample is not None:
         if _EMU['on'] and float(alpha) == 1.0:

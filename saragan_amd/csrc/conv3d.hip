@@ -2770,7 +2770,7 @@ static int launch_pw_fwd(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st,
     const int rows = 256 / (s->cout / E);
     // Grid: EIGHT trips per block (never fewer blocks than the 2048 a full chip holds).  This write stream is sensitive to
     // how far apart the blocks in flight write: at 32 x 128 x 128, n32, 8192 blocks of 32 trips ran at 4.4 TB/s, 2048 of 128
-    // (all resident, in lockstep) at 5.1-5.6, 32768 of 8 at 6.1-6.2, 131072 of 2 at 4.0 (tools/pw_probe.py) -- blocks that
+    // (all resident, in lockstep) at 5.1-5.6, 32768 of 8 at 6.1-6.2, 131072 of 2 at 4.0 (tools/archive/pw_probe.py) -- blocks that
     // live for a few trips are dispatched in order and sweep memory nearly sequentially.
     const int64_t full = (nvox + rows - 1) / rows;
     int64_t nb = (full + 7) / 8;

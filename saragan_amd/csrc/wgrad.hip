@@ -1589,7 +1589,7 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
       const int rows = 256 / (cb / E);
       int64_t nb = (nvox + rows - 1) / rows;
       // (one round of four blocks per CU: measured at 32 x 128 x 128, 768 / 1024 / 1536 / 2048 blocks read 4.7 / 5.2 / 4.9 /
-      // 3.9 TB/s -- every block ends in an LDS reduction and a row of partial sums, tools/pww_probe.py)
+      // 3.9 TB/s -- every block ends in an LDS reduction and a row of partial sums, tools/archive/pww_probe.py)
       if (nb > PW_WGRAD_MAX_BLOCKS) nb = PW_WGRAD_MAX_BLOCKS;
       float* part = reinterpret_cast<float*>(workspace);
       const int ones = (dbias != nullptr && small_is_cin) ? 1 : 0;   // the big side is dy: its column sums are the bias gradient

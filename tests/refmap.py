@@ -56,3 +56,20 @@ def generator_p1_params(npz):
     out[g + 'to_rgb_1/weight'] = oidhw_to_dhwio(npz['p:torgb_current.conv.weight'])
     out[g + 'to_rgb_1/bias'] = npz['p:torgb_current.conv.bias']
     return out
+
+
+def generator_params(npz, phase):
+    """Reference Generator(phase) parameters -> TF names (phase >= 1)."""
+    out = generator_p1_params(npz)
+    g = 'generator/'
+    del out[g + 'to_rgb_1/weight'], out[g + 'to_rgb_1/bias']
+    out[g + f'to_rgb_{phase}/weight'] = oidhw_to_dhwio(npz['p:torgb_current.conv.weight'])
+    out[g + f'to_rgb_{phase}/bias'] = npz['p:torgb_current.conv.bias']
+    if phase > 1:
+        out[g + f'to_rgb_{phase - 1}/weight'] = oidhw_to_dhwio(npz['p:torgb_prev.conv.weight'])
+        out[g + f'to_rgb_{phase - 1}/bias'] = npz['p:torgb_prev.conv.bias']
+    for i in range(2, phase + 1):
+        for j in (1, 2):
+            out[g + f'generator_block_{i}/conv_{j}/weight'] = oidhw_to_dhwio(npz[f'p:blocks.block_phase_{i}.conv{j}.weight'])
+            out[g + f'generator_block_{i}/conv_{j}/bias'] = npz[f'p:blocks.block_phase_{i}.conv{j}.bias']
+    return out

@@ -11,7 +11,8 @@ pytestmark = pytest.mark.gpu
 
 def _args(data, logdir):
     from saragan_amd.main import build_parser, finalize_args
-    argv = ['pgan', str(data) + '/', '--start_shape', '(1, 4, 4, 4)', '--final_shape', '(1, 16, 16, 16)',
+    argv = ['pgan', str(data) + '/', '--start_shape', '(1, 4, 4, 4)', '--final_shape', '(1, 32, 32, 32)',      # utils.get_num_phases = log2(32 / 4) = 3 phases: 4^3, 8^3, 16^3
+           
             '--starting_phase', '2', '--ending_phase', '3', '--base_batch_size', '8', '--latent_dim', '16',
             '--noise_stddev', '0.01', '--mixing_nimg', '16', '--stabilizing_nimg', '16', '--loss_fn', 'logistic',
             '--gp_weight', '1', '--data_mean', '1024', '--data_stddev', '1024', '--logdir', str(logdir),

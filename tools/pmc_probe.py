@@ -38,6 +38,8 @@ CONVS = [  # n, (d,h,w), cin, cout (all 3x3x3): the >= 1 ms/step entries of `ben
 
 def main():
     lib = _lib.load()
+    # round 4: the interleaved 64 -> 32 layers run ONE pass (csrc/conv3p.hip) unless SG_FWD_NO_3P=1 keeps the two-pass K split
+    one_pass = os.environ.get('SG_FWD_NO_3P', '0') != '1'
     dt = _lib.SG_BF16
     dev = torch.device('cuda:0')
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -78,6 +80,8 @@ def main():
         fws_bytes = lib.sg_conv3d_fwd_workspace(C.byref(shp), dt)
         fws = torch.empty(max(16, fws_bytes), device=dev, dtype=torch.uint8)
         per_call = 2 if fws_bytes else 1
+        if fws_bytes and cin == 64 and one_pass:
+            per_call = 1
         if fws_bytes:
             for e_ in (ep_plain, ep_mask):
                 e_.workspace, e_.workspace_bytes = fws.data_ptr(), fws_bytes
@@ -98,7 +102,7 @@ def main():
             ep_pl = ConvEpilogue(None, 0, 0.2, 0, 1e-8, None, bits.data_ptr(), 0.2, None)
             ep_pl.workspace, ep_pl.workspace_bytes, ep_pl.x_plane_channels = fws.data_ptr(), fws_bytes, 32
             twice(f'fwd mask_bits, x as two 32-channel tensors {name}', 'conv_fwd', vox * (cin + cout) * 2 + vox * nw * 4 + 27 * cin * cout * 2, flops,
-                  lambda: _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep_pl), dt, st)), per_call)
+                  lambda: _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), y.data_ptr(), C.byref(shp), C.byref(ep_pl), dt, st)), 2)
         if cin <= 32 and cout % 32 == 0:      # the fused first stage of downscale3d (sg_conv_epilogue.pool)
             yp = torch.empty(n, d // 2, h, w // 2, cout, device=dev, dtype=torch.bfloat16)
             ep_pool = ConvEpilogue(bias.data_ptr(), 1, 0.2, 0, 1e-8, None, None, 0.0, sout.data_ptr())
@@ -163,8 +167,10 @@ def main():
         ep.in_mask_bits, ep.in_mask_slope, ep.in_gain = bits64.data_ptr(), 0.2, 0.125
         # algorithmic bytes: pooled gradient once, the input's sign words, output + its mask words, weights
         alg = vox / 8 * 64 * 2 + vox * 2 * 4 + vox * 32 * 2 + vox * 4 + 27 * 64 * 32 * 2
-        twice(f'fwd masked gather (K split) n{n} {d}x{h}x{w} 64->32', 'conv_fwd3s', alg, 2.0 * vox * 64 * 32 * 27,
-              lambda: _lib.check(lib.sg_conv3d_fwd(gyh.data_ptr(), wp.data_ptr(), gx.data_ptr(), C.byref(shp), C.byref(ep), dt, st)), 2)
+        twice(f'fwd masked gather ({"one pass" if one_pass else "K split"}) n{n} {d}x{h}x{w} 64->32', 'conv_fwd3p' if one_pass else 'conv_fwd3s', alg,
+              2.0 * vox * 64 * 32 * 27,
+              lambda: _lib.check(lib.sg_conv3d_fwd(gyh.data_ptr(), wp.data_ptr(), gx.data_ptr(), C.byref(shp), C.byref(ep), dt, st)),
+              1 if one_pass else 2)
         shw = ConvShape(n, d, h, w, 32, 64, 3, 3, 3, 0)
         wsb = lib.sg_conv3d_wgrad_workspace(C.byref(shw), dt)
         ws = torch.empty(wsb, device=dev, dtype=torch.uint8)

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round-4 evidence (one gpurun call): counter passes over the hot shapes (ONE counter group per pass, --kernel-trace only, as
+# MI355X_MICROARCH.md prescribes), the kernel-stats trace of the bench command, the clock the isolated PMC launches ran at.
+# Results under gpurun_out/final/; `PROFILE_TAG=r04_ python tools/refresh_profiles.py` copies them into profiles/.
+R="$GRAFT_REPO_ROOT"
+O=$R/gpurun_out/final
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+run() { local t=$1; shift; timeout -k 10 "$t" "$@"; local rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT: $*"; exit 1; fi; return $rc; }
+( while true; do echo "T $(date +%s.%N) $(rocm-smi --showclocks --showpower 2>/dev/null | grep -E 'sclk|Power' | sed -E 's/.*: //' | tr '\n' '|')"; sleep 0.5; done ) > $O/pmc_clock_samples.txt &
+SMI=$!
+echo "pmc_rd begins $(date +%s.%N)" > $O/pmc_pass_times.txt
+run 250 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_rd -o rd -- python3 $R/tools/pmc_probe.py > $O/pmc_rd.log 2>&1 || { kill $SMI; exit 1; }
+echo "pmc_wr begins $(date +%s.%N)" >> $O/pmc_pass_times.txt
+run 250 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_wr -o wr -- python3 $R/tools/pmc_probe.py > $O/pmc_wr.log 2>&1 || { kill $SMI; exit 1; }
+echo "pmc_mfma begins $(date +%s.%N)" >> $O/pmc_pass_times.txt
+run 250 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_mfma -o mf -- python3 $R/tools/pmc_probe.py > $O/pmc_mf.log 2>&1 || { kill $SMI; exit 1; }
+echo "pmc_sq begins $(date +%s.%N)" >> $O/pmc_pass_times.txt
+run 250 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -o sq -- python3 $R/tools/pmc_probe.py > $O/pmc_sq.log 2>&1 || { kill $SMI; exit 1; }
+echo "pmc passes end $(date +%s.%N)" >> $O/pmc_pass_times.txt
+kill $SMI
+cp $R/gpurun_out/pmc_manifest.json $O/pmc_manifest.json
+run 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o bench -- python3 $R/bench.py --steps 10 --warmup 3 --no-extras --no-cpu-baseline > $O/prof_bench.log 2>&1 || exit 1
+cd $R
+run 300 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
+run 200 python bench.py --dump-prof --steps 5 --warmup 3 --no-extras --no-cpu-baseline > /dev/null 2> $O/bench_conv_table.txt
+for c in 1 2 4 5; do run 200 python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_config$c.json 2> $O/bench_config$c.err; done
+ls $O

@@ -285,10 +285,10 @@ def cpu_baseline(args, cfg, budget_s):
 
 def pmc_traffic(entry, dtype):
     """Bytes per launch that crossed the L2's memory side for this (kind, shape), from the committed rocprofv3 counter
-    passes (profiles/r03_pmc_traffic.json, else r02 / r01: FETCH_SIZE x2 + WRITE_SIZE; tools/pmc_probe.py +
+    passes (profiles/r04_pmc_traffic.json, else r03 / r02 / r01: FETCH_SIZE x2 + WRITE_SIZE; tools/pmc_probe.py +
     tools/pmc_summary.py; the counters cannot be read from inside this process).  Mean over the epilogue variants
     measured; None when this shape / batch / dtype was not part of the counter run."""
-    for name in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
+    for name in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json', 'r01_pmc_traffic.json'):
         path = os.path.join(ROOT, 'profiles', name)
         if not os.path.exists(path):
             continue
@@ -447,7 +447,7 @@ def loader_leg(args, cfg, device, nsteps, barrier, snap=None):
             sess.run(cfg['ema_op'])
         # ~2 s of untimed steps: after the second or two of GPU idle spent writing the files the board's power averaging
         # lets the chip overshoot its sustained clocks, and a short leg would read up to 17 % faster than the main one
-        # (profiles/r02_clock_trace.txt)
+        # (DESIGN_NOTES.md section 5, profiles/r02_clock_trace.txt)
         for i in range(max(30, args.warmup + 5)):
             step(i)
         if snap is not None:      # those steps were for the board: the timed ones train on from the post-warm-up state, as the
@@ -594,7 +594,7 @@ def main():
         step(i)
     snap = snapshot_state(cfg)      # the state the timed region starts from (and every extra leg: see restore_state)
     # Settle: on a fresh lease some boxes run the first seconds of sustained load ~13 % slower and then switch, between two
-    # steps, to the rate every later process sees (profiles/r03_leg_windows.txt: the MFMA-bound kernels
+    # steps, to the rate every later process sees (DESIGN_NOTES.md section 5, profiles/r03_leg_windows.txt: the MFMA-bound kernels
     # take 0.75-0.83x their earlier duration, the HBM-bound ones are unchanged -- the board's state, not the program's).
     # More untimed steps, in chunks of 5 timed by HIP events, until three consecutive chunks agree to 1 % and at least 3 s
     # have passed (at most 10 s); with several ranks a fixed 60 steps (the count must match across ranks).  The model state
@@ -763,7 +763,7 @@ def main():
                                     f": pgan '{args.size}' phase {args.phase} G+D step, "
                                     f"{'volumes' if args.dims == 3 else 'images'} {'x'.join(str(v) for v in sh[2:])}, "
                                     f"{args.loss}-gp, simultaneous, alpha {args.alpha}",
-                           fade_branch=('pruned: alpha is exactly 0 or 1, results identical (DESIGN.md 4.5; '
+                           fade_branch=('pruned: alpha is exactly 0 or 1, results identical (DESIGN_NOTES.md 4.5; '
                                         'SARAGAN_NO_LERP_PRUNE=1 runs it)') if (float(args.alpha) in (0.0, 1.0) and
                                         not int(os.environ.get('SARAGAN_NO_LERP_PRUNE', '0'))) else 'computed',
                            timed_region_s=dict(wall=round(sw.wall, 4), hip_events=round(sw.gpu, 4)),
@@ -800,7 +800,7 @@ def main():
             extras['loader_in_loop'] = loader_leg(args, cfg, device, max(3, args.steps), barrier, snap)
             if float(args.alpha) in (0.0, 1.0):
                 # the same step with the faded-out lerp branch computed as the reference's graph does (it contributes exact
-                # zeros: DESIGN.md 4.5); `value` is measured with the branch pruned
+                # zeros: DESIGN_NOTES.md 4.5); `value` is measured with the branch pruned
                 from saragan_amd.networks import ops as _ops
                 prune, _ops._NO_LERP_PRUNE = _ops._NO_LERP_PRUNE, True
                 restore_state(cfg, snap)

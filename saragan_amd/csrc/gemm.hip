@@ -1,7 +1,7 @@
 // GEMM-tiled convolution for the LOW-RESOLUTION levels (whole-plane tiles, D*H*W <= 1024 voxels per sample, >= 128
 // channels): pgan/generator.py:26-45 (generator_in ... block 3) and pgan/discriminator.py:48-68 at 1x4x4, 2x8x8, 4x16x16.
 // There the spatial kernels of conv3d.hip run at 0.02-0.3 of the MFMA peak: a block owned 128 voxels x 32 output
-// channels and streamed its whole weight slab per tile -- 256 MB through L2 for a 4.7 MB weight tensor.
+// channels and streamed its whole weight slab per tile -- 256 MB through L2 for a 4.7 MB weight tensor (DESIGN_NOTES.md section 7).
 //
 // Here the batch is folded into M: a block owns 256 consecutive voxels (1 plane of 16x16, one 2x8x8 sample pair, sixteen
 // 1x4x4 samples) x 128 output channels, eight waves as 4 (M) x 2 (N), each 64 x 64 (four accumulator tiles: every fragment

@@ -1,6 +1,6 @@
 """Diagnostic: is the step time of bench.py's workload stationary within one process?  Runs the bench step in chunks of 10
 with HIP-event timing: 8 chunks back to back, a 2 s idle pause, 8 more chunks, a pause with the caching allocator emptied,
-8 more.  Prints ms/step per chunk.  usage: python tools/boost_probe.py   """
+8 more.  Prints ms/step per chunk.  usage: python tools/boost_probe.py   (see DESIGN_NOTES.md section 5)"""
 import os
 import sys
 import time

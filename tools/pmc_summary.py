@@ -60,7 +60,7 @@ def main():
            'calibration': {'axpby_read_GiB': cal_r, 'axpby_write_GiB': cal_w}, 'entries': []}
     for m, r, w, b, g in zip(manifest[1:], R[1:], W[1:], MB[1:], GA[1:]):
         fr, fw = 2.0 * r[2] * 1024, w[2] * 1024
-        e = {'tag': m['tag'], 'kernel': r[1].split('(')[0][:70], 'read_bytes': fr, 'write_bytes': fw, 'traffic_bytes': fr + fw,
+        e = {'tag': m['tag'], 'kernel': r[1].replace('(anonymous namespace)::', '').split('(')[0][:70], 'read_bytes': fr, 'write_bytes': fw, 'traffic_bytes': fr + fw,
              'algorithmic_bytes': m['algorithmic_bytes'], 'traffic_over_algorithmic': (fr + fw) / m['algorithmic_bytes']}
         kind = 'fwd' if m['tag'].startswith('fwd') else ('wgrad' if m['tag'].startswith('wgrad') else 'elementwise')
         e['kind'] = kind

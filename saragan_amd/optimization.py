@@ -412,7 +412,16 @@ class StepGraph:
                 for host_ms, e0, e1 in ent.pop('probes', []):
                     e1.synchronize()
                     ent['ratios'].append(host_ms / max(1e-6, e0.elapsed_time(e1)))
-                if not ent['ratios'] or min(ent['ratios']) < 0.8:      # the device is the bottleneck: nothing to gain
+                worst = min(ent['ratios']) if ent['ratios'] else 0.0
+                if dist_ids and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+                    # every rank must take the SAME path: the eager step launches its buckets from autograd hooks as they become
+                    # ready, the captured one launches them in order after the replay -- ranks that disagree would issue their
+                    # collectives in different orders.  The decision is the minimum over ranks (all ranks reach this point at the
+                    # same step of the same key).
+                    t = torch.tensor([worst], device=real.device, dtype=torch.float64)
+                    torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+                    worst = float(t.item())
+                if worst < 0.8:      # the device is the bottleneck: nothing to gain
                     ent['decided'] = 'eager'
                     return eager()
             # ---- capture

@@ -363,6 +363,25 @@ def test_config4_m_phase7_fade_in_step():
     set_compute_dtype(torch.float32)
 
 
+def test_config4_whole_step_bf16_against_fp32():
+    """configs[3] at its own size (pgan 'm' phase 7, [2,1,64,256,256], fade-in alpha 0.5, freeze train ops): one whole step in
+    fp32 and in bf16 on the HIP path, as test_config3_whole_step_properties does for configs[2] -- losses and the sample agree,
+    every bf16 gradient norm of the trained (new-layer) variables is within 10 % of the fp32 run's.  (The fp64 oracle cannot
+    follow at this size: a step is hours of CPU.  The same network at oracle-sized batches / smaller phases is compared layer by
+    layer and as whole steps in test_config_step_against_oracle.)"""
+    case = make_case('m', 7, 512, 2, alpha=0.5, loss_fn='wgan', seed=42, dtype=torch.float32)
+    f32 = _grad_norms(case, torch.float32)
+    b16 = _grad_norms(case, torch.bfloat16)
+    assert abs(b16['gen_loss'] - f32['gen_loss']) <= 3e-2 * max(1.0, abs(f32['gen_loss']))
+    assert abs(b16['disc_loss'] - f32['disc_loss']) <= 3e-2 * max(1.0, abs(f32['disc_loss']))
+    assert rel_l2(b16['sample'], f32['sample']) <= 2e-2
+    assert f32['norms'] and all('block_7' in k or 'rgb_7' in k for k in f32['norms'])      # freeze ops: the new layers only
+    bad = {k: (b16['norms'][k], v) for k, v in f32['norms'].items() if abs(b16['norms'][k] - v) > 0.10 * v + 1e-12}
+    assert not bad, bad
+    from saragan_amd.varstore import set_compute_dtype
+    set_compute_dtype(torch.float32)
+
+
 def test_gradient_penalty_through_the_fused_gather_matches_the_materialised_path(monkeypatch):
     """The gradient penalty of the benchmarked discriminator (pgan 's' phase 6, bf16, 32x128x128, batch 4 -- the smallest
     batch whose 128^2 level fills the gather kernels' grid) with the pooled layer's backward through the fused masked gather

@@ -379,6 +379,9 @@ static int launch_wgrad(WgradArgs& a, const sg_conv_shape* s, hipStream_t st) {
   // 512 -> 512 layers of the 2x8x8 level, 229 against 179 us at batch 64: the third block of a CU runs as a tail.
   int P = sg_cdiv(sg_cfg().wgrad_v1_blocks > 0 ? sg_cfg().wgrad_v1_blocks : 512, pairs);
   if (P > a.ntiles) P = a.ntiles;
+  // reproducible mode: every block stores a whole slab, and the workspace holds wgrad_slab_count() of them -- a block target
+  // raised by SG_WGRAD_V1_BLOCKS must not write past it
+  if (a.slab != 0 && P > wgrad_slab_count(s)) P = wgrad_slab_count(s);
   if (P < 1) P = 1;
   for (int tap0 = 0; tap0 < a.taps; tap0 += 4 * WG_MAXT) {
     a.tap0 = tap0;

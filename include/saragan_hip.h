@@ -276,6 +276,10 @@ int sg_axpby(const void* a, const void* b, void* out, float wa, float wb, int64_
  * fade-in of a step captured as a hipGraph, whose alpha moves every step (networks/ops.py:4-23, optuna_objective.py:446-467:
  * the reference feeds alpha as a graph variable too).  Same f32 arithmetic as sg_axpby. */
 int sg_axpby_dev(const void* a, const void* b, void* out, const float* w, int64_t numel, sg_dtype dt, sg_stream_t st);
+/* out[s][i] = gamma[s]*a[s][i] + (1-gamma[s])*b[s][i], one f32 DEVICE weight per batch sample, f32 arithmetic, one rounding:
+ * the gradient penalty's interpolates `gamma*real + (1-gamma)*fake` (networks/loss.py:70-71, :133-134). */
+int sg_lerp_rows(const void* a, const void* b, const float* gamma, void* out, int32_t n, int64_t per_sample, sg_dtype dt,
+                 sg_stream_t st);
 /* out = x + stddev * N(0,1), counter-based Philox4x32-10 keyed by (seed, element index)
  * (instance noise, networks/loss.py:122-123). */
 int sg_add_noise(const void* x, void* out, float stddev, uint64_t seed, uint64_t offset, int64_t numel,

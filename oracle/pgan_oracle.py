@@ -678,12 +678,12 @@ def forward_simultaneous(p: Params, real, z, noise_real, noise_fake, gamma, alph
     gen_sample = generator(p, z, alpha, base_shape=base_shape, **net)
     if _EMU['on']:
         # saragan_amd/networks/loss.py: images and noise enter in bf16, sg_axpby adds in f32 and stores bf16; the
-        # interpolates are torch bf16 arithmetic (every op rounds); with the wgan loss D(real) and D(fake) are ONE pass
-        # over the concatenated batch (forward_simultaneous, `link`), which is what decides the pooling fusion per layer
+        # interpolates are ONE kernel since round 4 (sg_lerp_rows: f32 weights, f32 arithmetic, one rounding); with the wgan loss
+        # D(real) and D(fake) are ONE pass over the concatenated batch (forward_simultaneous, `link`), which is what decides the
+        # pooling fusion per layer
         real_n = _q(_q(real) + _q(noise_real) * noise_stddev)
         fake_n = _q(gen_sample + _q(noise_fake) * noise_stddev)
-        gq = _q(gamma)
-        interpolates = _q(_q(gq * real_n) + _q(_q(1 - gq) * fake_n.detach())).detach().requires_grad_(True)
+        interpolates = _q(gamma * real_n + (1 - gamma) * fake_n.detach()).detach().requires_grad_(True)
         if loss_fn == 'wgan':
             both = discriminator(p, torch.cat([real_n, fake_n], dim=0), alpha, latent_dim=latent_dim, **net)
             disc_real, disc_fake_g = both[:real.shape[0]], both[real.shape[0]:]

@@ -84,6 +84,7 @@ SIGNATURES = {
     'sg_trilinear_up2x': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, C.c_int, _p]),
     'sg_axpby': (C.c_int, [_p, _p, _p, _f, _f, _i64, C.c_int, _p]),
     'sg_axpby_dev': (C.c_int, [_p, _p, _p, _p, _i64, C.c_int, _p]),
+    'sg_lerp_rows': (C.c_int, [_p, _p, _p, _p, _i32, _i64, C.c_int, _p]),
     'sg_add_noise': (C.c_int, [_p, _p, _f, _u64, _u64, _i64, C.c_int, _p]),
     'sg_add_noise_dev': (C.c_int, [_p, _p, _f, _u64, _p, _u64, _i64, C.c_int, _p]),
     'sg_sumsq_ndhwc_keep_w': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, C.c_int, _p]),

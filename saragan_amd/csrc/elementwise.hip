@@ -715,6 +715,32 @@ __global__ void axpby_kernel(const T* __restrict__ a, const T* __restrict__ b, T
   }
 }
 
+// out[s][i] = g_s * a[s][i] + (1 - g_s) * b[s][i] with one weight per batch sample: the gradient penalty's interpolates
+// (networks/loss.py:133-134, :70-71).  f32 arithmetic from the f32 weight, ONE rounding to T.
+template <typename T>
+__global__ void lerp_rows_kernel(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ gamma, T* __restrict__ out,
+                                 int64_t per_sample, int64_t numel) {
+  constexpr int E = Piece<T>::E;
+  const int64_t tid0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+  if (per_sample % E == 0) {
+    const int64_t nv = numel / E, pv = per_sample / E;
+    for (int64_t i = tid0; i < nv; i += stride) {
+      const float g = gamma[i / pv], h = 1.f - g;
+      Piece<T> pa, pb;
+      pa.load(a + i * E);
+      pb.load(b + i * E);
+#pragma unroll
+      for (int e = 0; e < E; ++e) pa.v[e] = g * pa.v[e] + h * pb.v[e];
+      pa.store(out + i * E);
+    }
+  } else {
+    for (int64_t i = tid0; i < numel; i += stride) {
+      const float g = gamma[i / per_sample];
+      out[i] = sg_traits<T>::from_f(g * sg_traits<T>::to_f(a[i]) + (1.f - g) * sg_traits<T>::to_f(b[i]));
+    }
+  }
+}
+
 // Philox4x32-10 (Salmon et al. 2011), counter = element index / 4, key = seed.
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
                                               uint32_t k1, uint32_t out[4]) {
@@ -1232,6 +1258,21 @@ extern "C" int sg_axpby_dev(const void* a, const void* b, void* out, const float
   const int E = dt == SG_BF16 ? 8 : 4;
   const int blocks = grid_trips(numel / E + 1, 256, 2);
 #define L(T) hipLaunchKernelGGL((axpby_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)a, (const T*)b, (T*)out, 0.f, 0.f, numel, w)
+  SG_DISPATCH(dt, L(bf16_t), L(float));
+#undef L
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
+extern "C" int sg_lerp_rows(const void* a, const void* b, const float* gamma, void* out, int32_t n, int64_t per_sample, sg_dtype dt,
+                            sg_stream_t st) {
+  if (!a || !b || !gamma || !out || n < 1 || per_sample < 1) return SG_EINVAL;
+  if (!sg_aligned16(a) || !sg_aligned16(b) || !sg_aligned16(out)) return SG_EALIGN;
+  hipStream_t hs = sg_st(st);
+  const int64_t numel = (int64_t)n * per_sample;
+  const int E = dt == SG_BF16 ? 8 : 4;
+  const int blocks = grid_trips(numel / E + 1, 256, 2);
+#define L(T) hipLaunchKernelGGL((lerp_rows_kernel<T>), dim3(blocks), dim3(256), 0, hs, (const T*)a, (const T*)b, gamma, (T*)out, per_sample, numel)
   SG_DISPATCH(dt, L(bf16_t), L(float));
 #undef L
   SG_LAUNCH_CHECK();

@@ -1393,6 +1393,24 @@ def lerp(a, b, wa, wb):
     return _Axpby.apply(a, b, wa, wb)
 
 
+def interpolate_rows(gamma, a, b):
+    """gamma * a + (1 - gamma) * b with one weight per batch sample (gamma: [N, 1, 1, 1, 1] or [N], f32): the gradient
+    penalty's interpolates (networks/loss.py:70-71, :133-134) in ONE launch with one rounding (sg_lerp_rows).  No gradient:
+    every caller detaches the result (the penalty differentiates with respect to the interpolates, not through them)."""
+    lib = _lib.load()
+    _req_cuda(a, b, gamma)
+    a, b = ndhwc(a.detach()), ndhwc(b.detach())
+    if a.shape != b.shape or a.dtype != b.dtype:
+        raise ValueError('interpolate_rows: operands differ in shape or dtype')
+    g = gamma.detach().reshape(-1).float().contiguous()
+    if g.numel() != a.shape[0]:
+        raise ValueError('interpolate_rows: one weight per batch sample')
+    out = torch.empty_like(a)
+    check(lib.sg_lerp_rows(_ptr(a), _ptr(b), _ptr(g), _ptr(out), a.shape[0], a.numel() // a.shape[0], _dt(a), _stream()),
+          'sg_lerp_rows')
+    return out
+
+
 def add_noise(x, stddev, seed, offset=0):
     return _AddNoise.apply(x, stddev, seed, offset)
 

@@ -189,8 +189,8 @@ def forward_discriminator(generator, discriminator, real_image_input, latent_dim
                param=leakiness)
     disc_fake_d = discriminator(gen_sample_noisy.detach(), alpha, phase, **net).float()
     disc_real = discriminator(real_image_input, alpha, phase, is_reuse=True, **net).float()
-    gamma = rng.gamma(real_image_input.shape[0], real_image_input.device).to(real_image_input.dtype)
-    interpolates = gamma * real_image_input + (1 - gamma) * gen_sample_noisy.detach()
+    gamma = rng.gamma(real_image_input.shape[0], real_image_input.device)
+    interpolates = F.interpolate_rows(gamma, real_image_input, gen_sample_noisy)      # f32 weights, one rounding
     slopes = torch.sqrt(_gradient_slopes_sq(discriminator, interpolates, alpha, phase, latent_dim, activation,
                                             kernel_spec, filter_spec, leakiness, keep_w=False))
     if loss_fn == 'wgan':
@@ -239,8 +239,8 @@ def forward_simultaneous(generator, discriminator, real_image_input, latent_dim,
         disc_fake_g = discriminator(fake_in, alpha, phase, **net).float()
         disc_fake_d = disc_fake_g
         disc_real = discriminator(real_image_input, alpha, phase, is_reuse=True, **net).float()
-    gamma = rng.gamma(real_image_input.shape[0], real_image_input.device).to(real_image_input.dtype)
-    interpolates = gamma * real_image_input + (1 - gamma) * gen_sample_noisy.detach()
+    gamma = rng.gamma(real_image_input.shape[0], real_image_input.device)
+    interpolates = F.interpolate_rows(gamma, real_image_input, gen_sample_noisy)      # f32 weights, one rounding
     # quirk Q1 belongs to the 3-D tree's 5-D tensors; the 2-D tree reduces its 4-D gradient over every non-batch axis
     keep_w = not getattr(discriminator, 'sg_gp_full_reduction', False)
     slopes = torch.sqrt(_gradient_slopes_sq(discriminator, interpolates, alpha, phase, latent_dim, activation,

@@ -1324,6 +1324,7 @@ __global__ __launch_bounds__(512) void conv_fwd3s_kernel(ConvFwdArgs a) {
   // start of the off-phase that needs them, their ~3 us under load made the off-phase longer than the MFMA phase:
   // in-kernel stamps, 5.1k against 4.6k cycles.)  `stg` is therefore live across the MFMA phase.
   const bool no_stage = (a.dbg_flags & 1) != 0, no_epi = (a.dbg_flags & 2) != 0;
+  if ((a.dbg_flags & 2048) && grp == 1) __builtin_amdgcn_s_setprio(1);      // diagnostic: static priority for the younger wave group
   if (items_mine > 0) {
     enter_column_P();
     enter_column_E();

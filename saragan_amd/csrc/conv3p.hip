@@ -269,6 +269,7 @@ __global__ __launch_bounds__(512) void conv_fwd3p_kernel(ConvFwdArgs a) {
   if (tid < 32) bias_lds[tid] = a.bias != nullptr ? a.bias[tid] : 0.f;
 
   const bool no_stage = (a.dbg_flags & 1) != 0, no_epi = (a.dbg_flags & 2) != 0;
+  if ((a.dbg_flags & 2048) && grp == 1) __builtin_amdgcn_s_setprio(1);      // diagnostic: static priority for the younger wave group
   if (items_mine > 0) {
     enter_column_P();
     enter_column_E();

@@ -72,7 +72,7 @@ static int conv_shape_ok(const sg_conv_shape* s) {
 extern "C" size_t sg_conv3d_packed_bytes(const sg_conv_shape* s, sg_dtype dt) {
   if (!conv_shape_ok(s)) return 0;
   // [MFMA fragment image][plain f32 [taps][cin][cout] copy for the small-channel VALU kernels, where they take the layer]
-  return (size_t)conv_nchunk(s, dt) * (s->kd * s->kh * s->kw) * conv_ntile(s) * 1024 + sg_small_tail_bytes(s);
+  return (size_t)conv_nchunk(s, dt) * (s->kd * s->kh * s->kw) * conv_ntile(s) * 1024 + sg_small_tail_bytes(s) + sg_fwd3p16_packed_bytes(s, dt);
 }
 
 extern "C" int sg_conv3d_pack_weights(const float* w, float coef, int transpose_flip, void* wp,
@@ -91,6 +91,8 @@ extern "C" int sg_conv3d_pack_weights(const float* w, float coef, int transpose_
   else
     hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, sg_st(st), a);
   SG_LAUNCH_CHECK();
+  if (sg_fwd3p16_packed_bytes(s, dt))      // (these shapes have no small-channel tail: the second image follows the first directly)
+    return sg_fwd3p16_pack(w, coef, a.flip, reinterpret_cast<char*>(wp) + (size_t)a.nchunk * a.taps * a.ntile * 1024, sg_st(st));
   if (sg_small_tail_bytes(s))
     return sg_small_pack(w, coef, a.flip, reinterpret_cast<char*>(wp) + (size_t)a.nchunk * a.taps * a.ntile * 1024, s, dt, sg_st(st));
   return SG_OK;

@@ -44,3 +44,6 @@ enum : int { SG_EP_SIGN = 1, SG_EP_MASK = 2, SG_EP_PN = 4, SG_EP_POOL = 8, SG_EP
 
 // conv3p.hip: one-pass 64 -> 32 sliding-accumulator kernel (replaces the two-pass K split where it applies)
 int sg_launch_fwd3p(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used);
+// its v_mfma_f32_16x16x32_bf16 variant (SG_FWD3P_16=1) reads a fragment image of its own, packed behind the standard one
+size_t sg_fwd3p16_packed_bytes(const sg_conv_shape* s, sg_dtype dt);
+int sg_fwd3p16_pack(const float* w, float coef, int flip, void* dst, hipStream_t st);

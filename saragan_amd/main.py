@@ -63,7 +63,9 @@ def build_parser():
     p.add_argument('--optim_strategy', default='simultaneous', choices=['simultaneous', 'alternate'])
     p.add_argument('--use_adasum', default=False, action='store_true')
     p.add_argument('--hipgraph', default=False, action='store_true',
-                   help='(not in the reference) replay forward + backward of the training step as one hipGraph: SARAGAN_HIPGRAPH=1')
+                   help='(not in the reference) always replay the training step as one hipGraph (SARAGAN_HIPGRAPH=1); by default a '
+                        'phase is captured when its steps measure host-bound')
+    p.add_argument('--no_hipgraph', default=False, action='store_true', help='(not in the reference) never capture: SARAGAN_HIPGRAPH=0')
     p.add_argument('--ema_beta', type=float, default=0.99)
     p.add_argument('--noise_stddev', type=float, required=True)
     p.add_argument('--optimizer', type=none_or_str, choices=[None, 'Adam', 'SGD', 'Momentum', 'Adadelta'], default='Adam')
@@ -134,9 +136,9 @@ def main(argv=None):
     if unknown:
         print(f'ignoring flags outside the hot path: {unknown}')
     args = finalize_args(args)
-    if getattr(args, 'hipgraph', False):
+    if getattr(args, 'hipgraph', False) or getattr(args, 'no_hipgraph', False):
         import os
-        os.environ['SARAGAN_HIPGRAPH'] = '1'
+        os.environ['SARAGAN_HIPGRAPH'] = '1' if args.hipgraph else '0'
     from .train import run_training
     out = run_training(args, max_steps_per_phase=args.max_steps_per_phase)
     for ph, st in out['stats'].items():

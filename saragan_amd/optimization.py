@@ -453,10 +453,10 @@ class StepGraph:
             # assert_no_live_accumulate_grad): the last step's outputs are dropped first, then the invariant is CHECKED.
             self.last = None
             F.clear_pack_cache()      # every weight image the step uses is packed INSIDE the graph, from the current weights
-            self.assert_no_live_accumulate_grad([p for _, p in self.store.trainable('generator/')] +
-                                                [p for _, p in self.store.trainable('discriminator/')])
             marks = []
             try:
+                self.assert_no_live_accumulate_grad([p for _, p in self.store.trainable('generator/')] +
+                                                    [p for _, p in self.store.trainable('discriminator/')])
                 torch.cuda.synchronize()
                 pool = self.__dict__.get('_cap_pool')
                 if pool is None:
@@ -466,10 +466,19 @@ class StepGraph:
                     if not dist_ids:
                         for tid, info in ent['pend']:
                             self._finish(tid, info, ent['out'], apply=tid in want_train, lr_dev=lr_dev.get(tid), marks=marks)
+            except BaseException:
+                # nothing was applied: the optimisers' step counts go back, and this key stays on the eager path from now on
+                # (the error itself is the caller's to see: a capture that failed half-way is not retried silently)
+                for _, o, _ in ent['opt']:
+                    o.t -= 1
+                ent['decided'] = 'eager'
+                for k_ in ('real', 'rnd', 'scalars', 'opt', 'out', 'pend'):
+                    ent.pop(k_, None)
+                raise
             finally:
-                ent['rnd'].counting = False
                 L.set_random_source(base)
                 F.clear_pack_cache()
+            ent['rnd'].counting = False
             ent['marks'] = marks
             # replays need the captured launches and the output buffers, not the Python autograd graph: without it the
             # AccumulateGrad nodes made on the capturing stream go away too (a later eager step would find them on the

@@ -7,6 +7,7 @@ moves every step, and a learning-rate schedule replay one graph).  SARAGAN_HIPGR
 the step is captured when it turns out host-bound -- which these toy steps are."""
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -157,3 +158,54 @@ def test_capture_refuses_a_live_autograd_graph():
         opt.StepGraph.assert_no_live_accumulate_grad(ps)
     del y
     opt.StepGraph.assert_no_live_accumulate_grad(ps)
+
+
+def test_a_capture_that_cannot_start_raises_and_leaves_the_run_usable(golden_dir, monkeypatch):
+    """Somebody keeps the previous step's autograd graph alive (here: a spy that stores the undetached loss): the capture must
+    not begin -- a Python error, not a crash in hipStreamEndCapture --, the optimisers' step counts are put back, and the key
+    stays eager afterwards."""
+    import saragan_amd.optimization as opt
+    from saragan_amd.ExtendedEMA import ExtendedEMA
+    from saragan_amd.networks import loss as L
+    from saragan_amd.networks.ops import ScalarVariable
+    from saragan_amd.networks.pgan.discriminator import discriminator
+    from saragan_amd.networks.pgan.generator import generator
+    from saragan_amd.varstore import VariableStore, set_compute_dtype, use_store
+    fx = load_step_fixture(os.path.join(golden_dir, NAME), torch.float64)
+    monkeypatch.setenv('SARAGAN_HIPGRAPH', '1')
+    set_compute_dtype(torch.float32)
+    kept = []
+    real_compute = opt.StepGraph._compute_simultaneous
+
+    def spy(self, real, train_ids, net_args, out, arm_dist=True):
+        pend = real_compute(self, real, train_ids, net_args, out, arm_dist=arm_dist)
+        kept[:] = [out['disc_loss']]            # holds the graph of the step that just ran
+        return pend
+    monkeypatch.setattr(opt.StepGraph, '_compute_simultaneous', spy)
+    try:
+        store = VariableStore('cuda', seed=0)
+        L.set_random_source(L.RandomSource(99, 'cuda'))
+        og = opt.AdamOptimizer(ScalarVariable(1e-3, 'g_lr'), 0.0, 0.9)
+        od = opt.AdamOptimizer(ScalarVariable(1e-3, 'd_lr'), 0.0, 0.9)
+        ph = opt.Placeholder([4, 1, 1, 1, 1])
+        with use_store(store):
+            tup = opt.optimize_step(og, od, generator, discriminator, ph, LATENT, ScalarVariable(0.0, 'alpha'), fx['phase'],
+                                    BASE_SHAPE, KERNEL_SPEC, FILTER_SPEC, 'leaky_relu', 0.2, 'wgan', fx['cfg']['gp_weight'],
+                                    'simultaneous', False, False, 0.01, None)
+        store.load_state_dict(dict(fx['p0']), strict=True)
+        ExtendedEMA(list(store.vars.keys()), 0.99, graph=tup[0].graph)
+        sess = opt.Session('cuda')
+        real = fx['real'].float().cuda()
+        for _ in range(2):                        # the two eager warm-up steps of the key
+            sess.run([tup[0], tup[1]], feed_dict={ph: real})
+        assert (og.t, od.t) == (2, 2)
+        with pytest.raises(RuntimeError, match='AccumulateGrad'):
+            sess.run([tup[0], tup[1]], feed_dict={ph: real})
+        assert (og.t, od.t) == (2, 2)             # nothing was applied, nothing was counted
+        kept.clear()
+        _, _, dl = sess.run([tup[0], tup[1], tup[3]], feed_dict={ph: real})      # the key went back to the eager path
+        assert (og.t, od.t) == (3, 3) and np.isfinite(float(dl))
+        assert not any('graph' in e for e in tup[0].graph.__dict__['_captures'].values())
+    finally:
+        set_compute_dtype(torch.float32)
+        L.set_random_source(None)

@@ -42,6 +42,7 @@ struct sg_config {
   int fwd3_gx, fwd3_no_lean;                 // SG_FWD3_GX (0 = automatic), SG_FWD3_NO_LEAN
   int fwd4_gx, fwd4_no_lean, fwd4_no_wres;   // SG_FWD4_GX (0 = automatic), SG_FWD4_NO_LEAN, SG_FWD4_NO_WRES
   int wgrad_v1, wgrad_no_v3, wgrad_no_lean;  // SG_WGRAD_V1, SG_WGRAD_NO_V3, SG_WGRAD_NO_LEAN
+  int wgrad_no_w16;                          // SG_WGRAD_NO_W16: 16-wide levels back on conv_wgrad2 (diagnostic)
   int wgrad_v1_blocks;                       // SG_WGRAD_V1_BLOCKS: block target of the generic weight-gradient kernel (0: default)
   int dbg_flags;                             // SG_DBG_FLAGS
   int no_small;                              // SG_NO_SMALL: the small-channel 2-D layers through the MFMA kernels (A/B, tests)

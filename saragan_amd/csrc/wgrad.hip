@@ -1003,9 +1003,9 @@ __global__ __launch_bounds__(512) void conv_wgrad3_kernel(WgradArgs a) {
 // hardware zero fill) instead of 64-bit pointer selects per piece: the staging of one tile took 4.8-5.8k cycles
 // to ISSUE, as long as the MFMA phase it should hide behind.
 // ------------------------------------------------------------------------------------------------------
-template <int PF>
+template <int PF, int TW = 32>   // TW = 32: tiles 2 x 4 x 32 (a W row is two 16-voxel K steps); TW = 16: tiles 2 x 8 x 16 (one K step per row)
 struct sg_wgrad_tile_lean {
-  static constexpr int MAXT = 7, TH = 4, HW = 34;
+  static constexpr int MAXT = 7, TH = 128 / TW, HW = TW + 2, KPL = TW / 16;
   static constexpr int IPS = 1 + MAXT, NI = 16 * IPS, RING = PF + 1;
   typedef s16x4 frag_t;
   struct Ctx {
@@ -1016,7 +1016,7 @@ struct sg_wgrad_tile_lean {
   template <int I>
   static __device__ __forceinline__ void load(const Ctx& c, frag_t (&a0)[RING], frag_t (&a1)[RING], frag_t (&b0)[2],
                                               frag_t (&b1)[2]) {
-    constexpr int ks = I / IPS, r = I % IPS, line = ks / 2, half = ks % 2, td = line / TH, th = line % TH;
+    constexpr int ks = I / IPS, r = I % IPS, line = ks / KPL, half = ks % KPL, td = line / TH, th = line % TH;
     if constexpr (r == 0) {
       asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b0[ks & 1]) : "v"(c.yb), "n"(ks * 1024));
       asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b1[ks & 1]) : "v"(c.yb), "n"(ks * 1024 + 256));
@@ -1070,17 +1070,20 @@ struct sg_wgrad_tile_lean {
   }
 };
 
-template <bool UPS, bool DYM = false>   // UPS: x is the half-resolution tensor, gathered nearest-x2 (upscale3d fused into the
-                                        // layer); DYM: dy is the half-resolution gradient of a pooled layer, gathered
-                                        // nearest-x2, scaled and LeakyReLU-masked while it is staged
+template <bool UPS, bool DYM = false, int TW = 32>   // UPS: x is the half-resolution tensor, gathered nearest-x2 (upscale3d fused into
+                                        // the layer); DYM: dy is the half-resolution gradient of a pooled layer, gathered
+                                        // nearest-x2, scaled and LeakyReLU-masked while it is staged; TW = 16: the 16-wide levels
+                                        // (4 x 16 x 16) in tiles of 2 x 8 x 16 voxels, halo planes of 10 x 18 rows
 __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
   static_assert(!(UPS && DYM), "one gathered operand at a time");
+  static_assert(TW == 32 || TW == 16, "tile width");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int TAPS = 27, MAXT = 7;
-  constexpr int HH = 6, HW = 34, PB = 208 * 64, XB = 4 * PB, YB = 256 * 64, BUF = XB + YB;
-  constexpr int XPIECES = PB / 1024;                 // 13 1-KiB pieces per halo plane
+  constexpr int TH = 128 / TW, HH = TH + 2, HW = TW + 2, PB = 208 * 64, XB = 4 * PB, YB = 256 * 64, BUF = XB + YB;
+  static_assert(HH * HW <= 208, "halo plane slot");
+  constexpr int XPIECES = (HH * HW + 15) / 16;       // 13 (12) 1-KiB pieces per halo plane
   constexpr uint32_t DEAD = 0x80000000u;             // byte offset beyond every buffer: the DMA writes zeros
-  const sg_tile_geom& g = a.g;                       // TN=1, TD=2, TH=4, TW=32, HD=4, HH=6, HW=34, no up-sampling (host-checked)
+  const sg_tile_geom& g = a.g;                       // TN=1, TD=2, TH x TW = 4 x 32 | 8 x 16, HD=4, HH=TH+2, HW=TW+2 (host-checked)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave8 >> 2, wave = wave8 & 3;
@@ -1125,8 +1128,8 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
 #pragma unroll
   for (int k = 0; k < MAXY; ++k) {
     const int it = (wave + 4 * k) * 64 + lane;
-    const int row = it >> 2, c = co_t * 32 + (it & 3) * 8;   // row = (td * 4 + th) * 32 + tw
-    const int tw = row & 31, th = (row >> 5) & 3, td = row >> 7;
+    const int row = it >> 2, c = co_t * 32 + (it & 3) * 8;   // row = (td * TH + th) * TW + tw
+    const int tw = row & (TW - 1), th = (row / TW) & (TH - 1), td = row >> 7;
     if constexpr (DYM) {   // (tile origins are even: the halved coordinates are per-lane constants relative to the halved origin)
       rely[k] = c < cout ? (uint32_t)(((((th >> 1) * (W >> 1)) + (tw >> 1)) * cout + c) * 2) : 0xC0000000u;
       relm[k] = c < cout ? (uint32_t)((((td * H + th) * W + tw) * a.coT + co_t) * 4 + (it & 3)) : 0xC0000000u;
@@ -1147,9 +1150,9 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
   auto enter_column = [&]() {
     const int col = cfirst + (2 * cj + grp) * per_x;
     const int c1 = (int)sg_div((uint32_t)col, g.fnTw);
-    const int w0 = (col - c1 * g.nTw) * 32;
+    const int w0 = (col - c1 * g.nTw) * TW;
     const int c2 = (int)sg_div((uint32_t)c1, g.fnTh);
-    const int h0 = (c1 - c2 * g.nTh) * 4;
+    const int h0 = (c1 - c2 * g.nTh) * TH;
     const int n0 = c2;
     rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.x)) + n0 * xsb, 0, (int)xsb, 0x00020000);
     ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.dy)) + n0 * ysb, 0, (int)ysb, 0x00020000);
@@ -1168,7 +1171,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
       vkx[k] = (t1 & t2 & 0x8080u) == 0x8080u ? relx[k] + (uint32_t)tile_off : DEAD;
     }
     const int col_off = DYM ? ((h0 >> 1) * (W >> 1) + (w0 >> 1)) * cout * 2 : (h0 * W + w0) * cout * 2;
-    const int rows_left = H - h0;                                // W is a multiple of 32 (host-checked): every tw is inside
+    const int rows_left = H - h0;                                // W is a multiple of TW (host-checked): every tw is inside
 #pragma unroll
     for (int k = 0; k < MAXY; ++k) {
       const bool in = crdy[k] < rows_left && rely[k] < DEAD;
@@ -1249,11 +1252,11 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
       a.dbg[grp * 128 + dbgi] = __builtin_amdgcn_s_memtime();
     ++dbgi;
   };
-  typedef sg_wgrad_tile_lean<5> KT;
+  typedef sg_wgrad_tile_lean<5, TW> KT;
   auto mfma_phase = [&](int q) {
     const int dq = q % nTd;
     const int pbase = 2 * dq - 1 + 8;                             // plane of halo index 0 (kept non-negative)
-    KT::Ctx c;
+    typename KT::Ctx c;
     c.yb = yl0;
     c.ones_last = ones_last;
 #pragma unroll
@@ -1297,14 +1300,37 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
       __syncthreads();
     }
   }
+  // The two groups' sums are added through LDS (every tile is done and the loop ended on a barrier: the staging buffers are
+  // free), so a block sends ONE set of partial sums to memory.  Measured at 4 x 16 x 16, 128 -> 128, batch 32 (256 blocks): the
+  // f32 atomics of 2 x 256 groups were 32 of the kernel's 68 us (tools/w16_probe.py, SG_DETERMINISTIC A/B).
+  {
+    char* cbuf = smem + ((wave * MAXT) << 12) + lane * 16;
+    if (grp == 1) {
+#pragma unroll
+      for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+        for (int i4 = 0; i4 < 4; ++i4)
+          *reinterpret_cast<f32x4*>(cbuf + ((j * 4 + i4) << 10)) = f32x4{acc[j][4 * i4], acc[j][4 * i4 + 1], acc[j][4 * i4 + 2], acc[j][4 * i4 + 3]};
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j)
+#pragma unroll
+      for (int i4 = 0; i4 < 4; ++i4) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(cbuf + ((j * 4 + i4) << 10));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[j][4 * i4 + e] += o[e];
+      }
+  }
   const int r = lane & 31, hh = lane >> 5;
   if (ones_last && (items_mine > 0 || a.slab != 0) && hh == 0 && co_t * 32 + r < cout)   // row 0 of the ones product = column sums
-    sg_wg_out(a.dbias + (int64_t)(blockIdx.x * 2 + grp) * a.bslab + co_t * 32 + r, acc[MAXT - 1][0], a.slab != 0);
+    sg_wg_out(a.dbias + (int64_t)blockIdx.x * a.bslab + co_t * 32 + r, acc[MAXT - 1][0], a.slab != 0);
 #pragma unroll
   for (int j = 0; j < MAXT; ++j) {
     const int tap = wave + 4 * j;
     if (tap < TAPS && (items_mine > 0 || a.slab != 0)) {
-      float* dst = a.dwt + (int64_t)(blockIdx.x * 2 + grp) * a.slab + ((((int64_t)tap * a.ciT + ci_t) * a.coT + co_t) << 10);
+      float* dst = a.dwt + (int64_t)blockIdx.x * a.slab + ((((int64_t)tap * a.ciT + ci_t) * a.coT + co_t) << 10);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
@@ -1317,11 +1343,14 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
 template <int KD, int KH, int KW>
 static int launch_wgrad3(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used) {
   *used = false;
-  a.g = sg_make_geom(s, 256, /*prefer_w32=*/true, /*td=*/2, /*th=*/4);
+  // 16-wide levels (4 x 16 x 16): the lean kernel in tiles of 2 x 8 x 16 voxels
+  const bool w16 = KD == 3 && KH == 3 && KW == 3 && s->w == 16 && (s->h % 8) == 0 && (s->d % 2) == 0 && !a.dy_mask &&
+                   !sg_cfg().wgrad_no_lean && !sg_cfg().wgrad_no_w16;
+  a.g = sg_make_geom(s, 256, /*prefer_w32=*/true, /*td=*/2, /*th=*/w16 ? 8 : 4);
   const sg_tile_geom& g = a.g;
-  if (g.TW != 32 || g.TN != 1 || g.TD * g.TH * g.TW != 256) return SG_OK;
+  if (g.TW != (w16 ? 16 : 32) || g.TN != 1 || g.TD * g.TH * g.TW != 256) return SG_OK;
   if (g.HD != 2 && g.HD != 4) return SG_OK;          // ring slots are addressed with a mask
-  if (g.TD != 2 || g.TH != 4) return SG_OK;           // the unrolled K loop is written for 2 x 4 x 32 tiles
+  if (g.TD != 2 || g.TH != (w16 ? 8 : 4)) return SG_OK;   // the unrolled K loops are written for 2 x 4 x 32 and 2 x 8 x 16 tiles
   if (g.HH > 127 || g.HW > 127) return SG_OK;
   if ((s->cin % 8) || (s->cout % 8)) return SG_OK;
   // staging offsets are relative to the tile's first sample (64-bit tile bases): TN samples must fit 31 bits
@@ -1330,6 +1359,8 @@ static int launch_wgrad3(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   const int pairs = a.ciT * a.coT;
   int gx = (256 / pairs) / 8 * 8;
   if (gx < 8) gx = 8;
+  if (w16)      // few columns at these levels: rather fewer blocks (>= 128) than the tap-per-wave kernel
+    while (gx > 8 && ncol < 2 * gx && (gx - 8) * pairs >= 128) gx -= 8;
   if (ncol < 2 * gx || g.nTd < 2) return SG_OK;      // needs >= 2 columns per block and something to slide over
   a.gy = a.g;
   a.ntiles = ncol * g.nTd;
@@ -1338,14 +1369,30 @@ static int launch_wgrad3(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   if (a.plane_rows / 16 > 16) return SG_OK;           // <= 4 pieces per wave per plane
   a.xbytes = g.HD * a.plane_rows * 64;
   a.ybytes = 256 * 64;
-  const size_t lds = 2ull * (a.xbytes + a.ybytes);
+  size_t lds = 2ull * (a.xbytes + a.ybytes);
   if (lds > 160 * 1024) return SG_OK;
   a.tap0 = 0; a.taps_blk = a.taps;
   a.nslab = 2 * gx;      // (both wave groups of a block keep sums of their own)
   // the lean variant: 3x3x3 without fused up-sampling, whole 32-wide rows, one sample of either tensor below 2 GiB
   const bool lean = KD == 3 && KH == 3 && KW == 3 && g.HH == 6 && g.HW == 34 && g.HD == 4 && a.plane_rows == 208 &&
                     s->w % 32 == 0 && !sg_cfg().wgrad_no_lean && (!g.ups || ((s->d | s->h | s->w) & 1) == 0);
-  if (a.dy_mask) {     // half-resolution dy, gathered and masked while staged: the lean kernel only
+  const bool lean16 = w16 && g.HH == 10 && g.HW == 18 && g.HD == 4 && (!g.ups || ((s->d | s->h | s->w) & 1) == 0);
+  if (w16 && !lean16) return SG_OK;
+  if (lean16 || lean) a.nslab = gx;                   // (the lean kernels add their two groups' sums before they leave the block)
+  if (lean16) {        // (halo plane slots of 208 rows like the 32-wide kernel's)
+    lds = 2ull * (4 * 208 * 64 + 256 * 64);
+    if (g.ups) {
+      auto kern = conv_wgrad3l_kernel<true, false, 16>;
+      SG_ALLOW_160K_LDS(kern);
+      SG_KNAME("conv_wgrad3l<ups,w16>");
+      hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);
+    } else {
+      auto kern = conv_wgrad3l_kernel<false, false, 16>;
+      SG_ALLOW_160K_LDS(kern);
+      SG_KNAME("conv_wgrad3l<w16>");
+      hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);
+    }
+  } else if (a.dy_mask) {     // half-resolution dy, gathered and masked while staged: the lean kernel only
     if (!lean || g.ups || ((s->d | s->h | s->w) & 1)) return SG_OK;
     auto kern = conv_wgrad3l_kernel<false, true>;
     SG_ALLOW_160K_LDS(kern);

@@ -1343,3 +1343,62 @@ def test_pixel_norm_stage_with_a_conv_and_a_to_rgb_consumer(monkeypatch, rgb_fir
     ref = torch.autograd.grad([r2, ri], lr, [g2, gi])
     for name, a, r in zip(['dx'] + names, got, ref):
         _mostly_close(a, r, 3e-2, 3e-2, name, max_bad=5e-3)
+
+
+W16_CASES = [
+    # n, cin, cout, (d, h, w), ups, with bias gradient
+    (8, 128, 128, (4, 16, 16), False, True),     # the 4 x 16 x 16 level of the 'm' network
+    (32, 64, 64, (4, 16, 16), False, False),     # few columns: the grid shrinks to keep two columns per block
+    (8, 256, 64, (4, 16, 16), True, True),       # conv3d(upscale3d(x)): x is the 2 x 8 x 8 level
+    (16, 40, 72, (6, 24, 16), False, True),      # ragged: channels not multiples of 32, H = 3 tiles, D = 3 slides
+    (4, 32, 32, (2, 8, 16), False, True),        # a single D tile per column: stays on the tap-per-wave kernel
+]
+
+
+@pytest.mark.parametrize('case', W16_CASES, ids=[f'{c[1]}to{c[2]}at{"x".join(map(str, c[3]))}{"ups" if c[4] else ""}' for c in W16_CASES])
+def test_wgrad_16_wide_levels_on_the_sliding_halo_kernel(case, sg_env, monkeypatch):
+    """conv_wgrad3l in tiles of 2 x 8 x 16 voxels (the 4 x 16 x 16 levels; discriminator.py:48-68, generator.py:26-45 at
+    phase 3): against the fp64 oracle, and within f32 rounding (the sums run in another order) of the tap-per-wave
+    kernel it replaces (SG_WGRAD_NO_W16=1)."""
+    import ctypes as C
+    from saragan_amd import _lib
+    from saragan_amd import functional as F
+    n, cin, cout, sp, ups, want_db = case
+    dtype = torch.bfloat16
+    xs = tuple(v // 2 for v in sp) if ups else sp
+    x = rnd((n, cin, *xs), 301, dtype)
+    gy = rnd((n, cout, *sp), 302, dtype)
+    xr = x.clone()
+    wr = torch.zeros((3, 3, 3, cin, cout), dtype=torch.float64, requires_grad=True)
+    yr = O.conv3d(O.upscale3d(xr) if ups else xr, wr, 'linear', None)
+    coef = O.runtime_coef(wr.shape, 'linear', None)
+    (gwr,) = torch.autograd.grad(yr, [wr], gy)
+    lib = _lib.load()
+
+    def run():
+        lib.sg_prof_enable(1)
+        dw, db = F.raw_wgrad(cl(x, dtype), cl(gy, dtype), (3, 3, 3), coef, ups=ups, want_db=want_db)
+        torch.cuda.synchronize()
+        ents = (_lib.ProfEntry * 8)()
+        cnt = C.c_int32(0)
+        lib.sg_prof_collect(ents, 8, C.byref(cnt))
+        lib.sg_prof_enable(0)
+        return dw, db, [ents[i].kernel.decode() for i in range(cnt.value)]
+
+    monkeypatch.setattr(F, '_NO_SUBPIXEL', True)   # (a sub-pixel weight gradient would take an up-sampled layer first)
+    dw, db, names = run()
+    sg_env(SG_WGRAD_NO_W16=1)
+    dw0, db0, names0 = run()
+    expect = 'conv_wgrad3l<ups,w16>' if ups else 'conv_wgrad3l<w16>'
+    if sp[0] >= 4:
+        assert names == [expect], names
+    else:
+        assert names != [expect]
+    assert names0 != [expect]
+    ref = gwr.numpy()
+    np.testing.assert_allclose(dw.double().cpu().numpy(), ref, rtol=2e-3, atol=2e-3 * np.abs(ref).max(), err_msg='dw vs oracle')
+    np.testing.assert_allclose(dw.cpu().numpy(), dw0.cpu().numpy(), rtol=1e-4, atol=1e-5 * np.abs(ref).max(), err_msg='dw vs wgrad2')
+    if want_db:
+        dbr = gy.sum(dim=(0, 2, 3, 4)).numpy()
+        np.testing.assert_allclose(db.double().cpu().numpy(), dbr, rtol=1e-4, atol=1e-4 * np.abs(dbr).max(), err_msg='db')
+        np.testing.assert_allclose(db.cpu().numpy(), db0.cpu().numpy(), rtol=1e-4, atol=1e-5 * np.abs(dbr).max())

@@ -64,6 +64,7 @@ SIGNATURES = {
     'sg_conv3d_pw_bwd': (C.c_int, [_p, _p, _p, _p, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
     'sg_conv3d_wgrad_bias': (C.c_int, [_p, _p, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
     'sg_conv3d_wgrad_bias_up_masked': (C.c_int, [_p, _p, _p, _f, _f, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
+    'sg_conv3d_wgrad_bias_accumulate': (C.c_int, [_p, _p, _p, _f, _f, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
     'sg_bias_act_fwd': (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _f, C.c_int, _p]),
     'sg_bias_act_bwd_workspace': (_sz, [_i32]),
     'sg_bias_act_bwd': (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _f, C.c_int, _p]),

@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
 
 __global__ void wgrad_finalize_kernel(const float* __restrict__ dwt, float* __restrict__ dw, float coef, int taps,
                                       int cin, int cout, int ciT, int coT, int nslab, int64_t slab,
-                                      const float* __restrict__ bias_staged = nullptr, float* __restrict__ dbias = nullptr) {
+                                      const float* __restrict__ bias_staged = nullptr, float* __restrict__ dbias = nullptr,
+                                      int accumulate = 0) {
   const int64_t total = (int64_t)taps * cin * cout;
   // the bias gradient the kernel accumulated beside the tile (one memset clears both): out to the caller's buffer
   if (bias_staged != nullptr && blockIdx.x == 0)
@@ -179,7 +180,8 @@ __global__ void wgrad_finalize_kernel(const float* __restrict__ dwt, float* __re
     const float* src = dwt + ((((int64_t)tap * ciT + (ci >> 5)) * coT + (co >> 5)) << 10) + (ci & 31) * 32 + (co & 31);
     float v = src[0];
     for (int b = 1; b < nslab; ++b) v += src[(int64_t)b * slab];      // reproducible mode: the slabs in order
-    dw[i] = coef * v;
+    const float t = __fmul_rn(coef, v);      // (accumulate: the same two roundings as a separate add of the finished gradient)
+    dw[i] = accumulate ? __fadd_rn(dw[i], t) : t;
   }
 }
 
@@ -1617,7 +1619,8 @@ extern "C" int sg_conv3d_wgrad(const void* x, const void* dy, float* dw, float c
 // pw_dx / pw_wmat: sg_conv3d_pw_bwd's extra output and operand (pointwise layers from <= 4 input channels only)
 static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbias, float coef, void* workspace,
                            size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st, void* pw_dx,
-                           const float* pw_wmat, const void* dy_mask = nullptr, float dy_mask_slope = 0.f, float dy_gain = 1.f) {
+                           const float* pw_wmat, const void* dy_mask = nullptr, float dy_mask_slope = 0.f, float dy_gain = 1.f,
+                           int accumulate = 0) {
   if (!conv_shape_ok_w(s) || !x || !dy || !dw || !workspace) return SG_EINVAL;
   if (!sg_aligned16(x) || !sg_aligned16(dy) || !sg_aligned16(workspace)) return SG_EALIGN;
   if (dy_mask && (dt != SG_BF16 || s->kd != 3 || s->kh != 3 || s->kw != 3 || s->upsample_in || (s->cout % 32) ||
@@ -1632,6 +1635,7 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
     const int cs = s->cin < s->cout ? s->cin : s->cout, cb = s->cin < s->cout ? s->cout : s->cin;
     const int E = dt == SG_BF16 ? 8 : 4;
     if (taps1 == 1 && cs <= 4 && !s->upsample_in && cb % E == 0 && cb / E <= 256 && 256 % (cb / E) == 0) {
+      if (accumulate) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }   // (the tile finalize below is the accumulating one)
       const int small_is_cin = s->cin <= s->cout ? 1 : 0;
       const void* sm = small_is_cin ? x : dy;
       const void* bg = small_is_cin ? dy : x;
@@ -1666,6 +1670,7 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
   }
   if (pw_dx) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }   // only the pointwise pass has the extra output
   if (sg_small_wgrad_eligible(s) && !sg_cfg().no_small) {   // 2-D top levels (<= 16 channels): VALU kernel, slab reduction
+    if (accumulate) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }
     const int rc_s = sg_small_wgrad(x, dy, dw, dbias, coef, workspace, workspace_bytes, s, dt, hs);
     prof.done(rc_s);
     return rc_s;
@@ -1728,7 +1733,8 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, hs, a.dwt, dw, coef, a.taps, s->cin,
-                       s->cout, a.ciT, a.coT, det ? a.nslab : 1, a.slab, (const float*)((bias_staged && db_done) ? bias_staged : nullptr), dbias);
+                       s->cout, a.ciT, a.coT, det ? a.nslab : 1, a.slab, (const float*)((bias_staged && db_done) ? bias_staged : nullptr), dbias,
+                       accumulate);
     if (det && dbias && db_done)
       hipLaunchKernelGGL(wgrad_bias_slabs_kernel, dim3((unsigned)sg_cdiv(s->cout, 256)), dim3(256), 0, hs, bias_slabs, dbias, s->cout,
                          a.nslab, a.bslab);
@@ -1755,6 +1761,18 @@ extern "C" int sg_conv3d_wgrad_bias_up_masked(const void* x, const void* dy_half
   if (!mask_bits) return SG_EINVAL;
   if (!sg_aligned16(mask_bits)) return SG_EALIGN;
   return wgrad_bias_impl(x, dy_half, dw, dbias, coef, workspace, workspace_bytes, s, dt, st, nullptr, nullptr, mask_bits, mask_slope, dy_gain);
+}
+
+// dw += coef * sum (the parameter's gradient already holds another contribution: a second use of the weights in the graph, the
+// gradient penalty's second-order term) -- rounded like the finished gradient added afterwards; dbias (optional) is WRITTEN.
+// mask_bits == NULL: plain dy (sg_conv3d_wgrad_bias), else the gathered half-resolution dy (sg_conv3d_wgrad_bias_up_masked).
+// SG_EUNSUPPORTED on the pointwise / small-channel paths (their finalize kernels only write).
+extern "C" int sg_conv3d_wgrad_bias_accumulate(const void* x, const void* dy, const void* mask_bits, float mask_slope, float dy_gain,
+                                               float* dw, float* dbias, float coef, void* workspace, size_t workspace_bytes,
+                                               const sg_conv_shape* s, sg_dtype dt, sg_stream_t st) {
+  if (mask_bits && !sg_aligned16(mask_bits)) return SG_EALIGN;
+  return wgrad_bias_impl(x, dy, dw, dbias, coef, workspace, workspace_bytes, s, dt, st, nullptr, nullptr, mask_bits, mask_slope,
+                         mask_bits ? dy_gain : 1.f, 1);
 }
 
 extern "C" int sg_conv3d_pw_bwd(const void* x, const void* dy, const float* w_mat, float* dw, float* dbias, void* dx,

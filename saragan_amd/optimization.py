@@ -520,17 +520,24 @@ class StepGraph:
         for (o, n) in ranges:
             flat['grad'][o:o + n].zero_()
         params = [self.store.vars[n] for n in names]
+        slots = {}
         for p, n in zip(params, names):      # .grad views may have been replaced by autograd: re-point them
             o, cnt = flat['offsets'][n]
-            p.grad = flat['grad'][o:o + cnt].view(p.shape)
+            p.grad = slots[id(p)] = flat['grad'][o:o + cnt].view(p.shape)
         loss = out['gen_loss'] if tr['net'] == 'generator' else out['disc_loss']
         dist = tr['optimizer'].distributed
         other = 'discriminator/' if tr['net'] == 'generator' else 'generator/'
         link = getattr(out['gen_loss'], 'sg_link', None) if 'gen_loss' in out else None
         if dist is not None and arm_dist:      # (a captured backward launches no collective: they follow the replay)
             roots = [link[0]] if (link is not None and tr['net'] == 'generator') else [loss]
+            dist.land = lambda p: self._land(p, slots)      # (a bucket goes out from the hook of its last parameter)
             dist.begin(flat['grad'], ranges, params, roots if getattr(dist, 'world_size', 1) > 1 else None)
-        with F.skip_param_grads(p for _, p in self.store.trainable(other)):   # e.g. D's weights under the G loss
+        # The kernels write the first gradient of every parameter straight into its slot of the (zeroed) flat buffer and
+        # autograd adopts that tensor as .grad (F.grads_into): .grad starts out unset, and is checked afterwards (_land)
+        for p in params:
+            p.grad = None
+        with F.grads_into({p.data_ptr(): slots[id(p)] for p in params}), \
+                F.skip_param_grads(p for _, p in self.store.trainable(other)):   # e.g. D's weights under the G loss
             if link is None:
                 torch.autograd.backward(loss, inputs=params, retain_graph=retain)
             elif tr['net'] == 'discriminator':   # also deliver d disc_loss / d fake for the generator's backward
@@ -541,7 +548,24 @@ class StepGraph:
                 if leaf.grad is None:
                     raise RuntimeError('linked generator backward before the discriminator backward')
                 torch.autograd.backward(start, grad_tensors=leaf.grad * factor, inputs=params, retain_graph=retain)
+        for p in params:
+            self._land(p, slots)
         return dict(prefix=prefix, flat=flat, names=names, ranges=ranges, dist=dist)
+
+    @staticmethod
+    def _land(p, slots):
+        """After backward: p.grad IS p's slot of the flat gradient buffer.  Unreached parameter: the zeros the slot was
+        cleared to; a gradient autograd summed into a tensor of its own (more than one contribution): copied in."""
+        slot = slots[id(p)]
+        g = p.grad
+        if g is None:
+            F.GRAD_DEST_STATS['unreached'] += 1
+        elif g.data_ptr() != slot.data_ptr() or g.dtype != slot.dtype:
+            F.GRAD_DEST_STATS['copied'] += 1
+            slot.copy_(g)
+        elif g is not slot:
+            F.GRAD_DEST_STATS['adopted'] += 1
+        p.grad = slot
 
     def _finish(self, tid, info, out, apply, lr_dev=None, marks=None):
         tr = self.trains[tid]

@@ -106,6 +106,7 @@ class GradientAllReducer:
         self._buckets = []
         self._handles = []
         self._armed = False
+        self.land = None       # optional callable(p): makes sure p.grad lives in the flat buffer before its bucket is counted down
         self.timing = bool(int(os.environ.get('SARAGAN_DP_TIMING', '0')))
         self._spans = []       # (event before the waits, event after): GPU time the compute stream sat in finish()
 
@@ -193,6 +194,8 @@ class GradientAllReducer:
     def _hook(self, p):
         if not self._armed:
             return
+        if self.land is not None and p.grad is not None:
+            self.land(p)
         for bi in self._owner.get(id(p), ()):
             b = self._buckets[bi]
             b['left'] -= 1

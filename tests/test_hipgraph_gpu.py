@@ -209,3 +209,35 @@ def test_a_capture_that_cannot_start_raises_and_leaves_the_run_usable(golden_dir
     finally:
         set_compute_dtype(torch.float32)
         L.set_random_source(None)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_gradients_written_straight_into_the_flat_buffer(golden_dir, dtype, monkeypatch):
+    """F.grads_into: the first gradient of every parameter is written by its kernel into the parameter's slot of the flat
+    gradient buffer and adopted by autograd as .grad; only sums of several contributions (the discriminator's weights under the
+    gradient penalty) are copied in.  Same weights and losses, bit for bit, as with every gradient a tensor of its own that
+    autograd adds onto the zeroed buffer (the round-3 path, SARAGAN_NO_GRAD_DEST=1)."""
+    import saragan_amd
+    from saragan_amd import functional as F
+    saragan_amd.set_deterministic(True)
+    try:
+        for k in F.GRAD_DEST_STATS:
+            F.GRAD_DEST_STATS[k] = 0
+        w1, l1, _ = _run(golden_dir, 4, dtype, captured=False)
+        st = dict(F.GRAD_DEST_STATS)
+        monkeypatch.setattr(F, '_NO_GRAD_DEST', True)
+        for k in F.GRAD_DEST_STATS:
+            F.GRAD_DEST_STATS[k] = 0
+        w0, l0, _ = _run(golden_dir, 4, dtype, captured=False)
+        st0 = dict(F.GRAD_DEST_STATS)
+    finally:
+        saragan_amd.set_deterministic(False)
+    assert l0 == l1
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k
+    print(st, st0)
+    # phase 3: 4 steps x (generator backward + discriminator backward); every reached parameter's gradient was claimed and adopted
+    # in place; the discriminator's filters' second contribution (gradient penalty) was added by the weight-gradient kernels
+    # (left to a copy: layers on the pointwise kernels with two contributions -- from_rgb and the last dense layer, 1 channel wide)
+    assert st['claimed'] > 0 and st['accumulated'] > 0 and st['adopted'] + st['copied'] == st['claimed'] and st['copied'] <= 2 * 4, st
+    assert st0['claimed'] == 0 and st0['adopted'] == 0 and st0['accumulated'] == 0 and st0['copied'] == st['claimed'], (st, st0)

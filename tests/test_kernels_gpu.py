@@ -1402,3 +1402,64 @@ def test_wgrad_16_wide_levels_on_the_sliding_halo_kernel(case, sg_env, monkeypat
         dbr = gy.sum(dim=(0, 2, 3, 4)).numpy()
         np.testing.assert_allclose(db.double().cpu().numpy(), dbr, rtol=1e-4, atol=1e-4 * np.abs(dbr).max(), err_msg='db')
         np.testing.assert_allclose(db.cpu().numpy(), db0.cpu().numpy(), rtol=1e-4, atol=1e-5 * np.abs(dbr).max())
+
+
+@pytest.mark.parametrize('case', [(2, 32, 32, (4, 16, 32), False), (2, 32, 64, (4, 128, 256), True), (4, 64, 64, (1, 8, 8), False), (2, 1, 16, (4, 8, 8), None)])
+def test_wgrad_accumulate_equals_the_add_of_the_finished_gradient(case):
+    """sg_conv3d_wgrad_bias_accumulate (a second contribution to a parameter's gradient, optimization.py:128-163 over
+    networks/loss.py:136-140): dw += coef * sum, bit for bit what adding the finished gradient gives; the bias gradient is
+    written; declined (SG_EUNSUPPORTED) on the pointwise path."""
+    import ctypes as C
+    from saragan_amd import _lib
+    from saragan_amd import functional as F
+    n, cin, cout, sp, masked = case
+    dtype = torch.bfloat16
+    lib = _lib.load()
+    k = (1, 1, 1) if masked is None else ((1, 3, 3) if sp[0] == 1 else (3, 3, 3))
+    x = cl(rnd((n, cin, *sp), 401, dtype), dtype)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    shp = _lib.ConvShape(n, *sp, cin, cout, *k, 0)
+    ws_bytes = lib.sg_conv3d_wgrad_workspace(C.byref(shp), _lib.SG_BF16)
+    ws = torch.empty(ws_bytes, device=dev(), dtype=torch.uint8)
+    first = torch.randn((*k, cin, cout), device=dev())
+    if masked:
+        half = tuple(v // 2 for v in sp)
+        gy = cl(rnd((n, cout, *half), 402, dtype), dtype)
+        bits = torch.randint(-2 ** 31, 2 ** 31 - 1, (n * sp[0] * sp[1] * sp[2], cout // 32), device=dev(), dtype=torch.int32)
+        ref = torch.empty_like(first)
+        _lib.check(lib.sg_conv3d_wgrad_bias_up_masked(x.data_ptr(), gy.data_ptr(), bits.data_ptr(), 0.2, 0.125, ref.data_ptr(), None, 0.05,
+                                                      ws.data_ptr(), ws_bytes, C.byref(shp), _lib.SG_BF16, st))
+        margs = (bits.data_ptr(), 0.2, 0.125)
+    else:
+        gy = cl(rnd((n, cout, *sp), 402, dtype), dtype)
+        ref, _ = F.raw_wgrad(x, gy, k, 0.05)
+        margs = (None, 0.0, 1.0)
+    acc = first.clone()
+    db = torch.full((cout,), 7.0, device=dev())
+    rc = lib.sg_conv3d_wgrad_bias_accumulate(x.data_ptr(), gy.data_ptr(), *margs, acc.data_ptr(), None if masked else db.data_ptr(), 0.05,
+                                             ws.data_ptr(), ws_bytes, C.byref(shp), _lib.SG_BF16, st)
+    if masked is None:
+        assert rc == _lib.SG_EUNSUPPORTED and torch.equal(acc, first)
+        return
+    _lib.check(rc)
+    import saragan_amd
+    if not masked:      # atomics: the sums themselves differ from launch to launch in the last bits unless reproducible
+        np.testing.assert_allclose(acc.cpu().numpy(), (first + ref).cpu().numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+        dbr = gy.float().sum(dim=(0, 2, 3, 4))
+        np.testing.assert_allclose(db.cpu().numpy(), dbr.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(dbr.abs().max()))
+    saragan_amd.set_deterministic(True)
+    try:
+        ws2 = torch.empty(lib.sg_conv3d_wgrad_workspace(C.byref(shp), _lib.SG_BF16), device=dev(), dtype=torch.uint8)
+        ref2 = torch.empty_like(first)
+        acc2 = first.clone()
+        if masked:
+            _lib.check(lib.sg_conv3d_wgrad_bias_up_masked(x.data_ptr(), gy.data_ptr(), bits.data_ptr(), 0.2, 0.125, ref2.data_ptr(), None,
+                                                          0.05, ws2.data_ptr(), ws2.numel(), C.byref(shp), _lib.SG_BF16, st))
+        else:
+            _lib.check(lib.sg_conv3d_wgrad_bias(x.data_ptr(), gy.data_ptr(), ref2.data_ptr(), None, 0.05, ws2.data_ptr(), ws2.numel(),
+                                                C.byref(shp), _lib.SG_BF16, st))
+        _lib.check(lib.sg_conv3d_wgrad_bias_accumulate(x.data_ptr(), gy.data_ptr(), *margs, acc2.data_ptr(), None, 0.05, ws2.data_ptr(),
+                                                       ws2.numel(), C.byref(shp), _lib.SG_BF16, st))
+        assert torch.equal(acc2, first + ref2)
+    finally:
+        saragan_amd.set_deterministic(False)

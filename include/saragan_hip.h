@@ -195,16 +195,23 @@ int sg_conv3d_wgrad_bias(const void* x, const void* dy, float* dw_dhwio, float* 
 int sg_conv3d_wgrad_bias_up_masked(const void* x, const void* dy_half, const void* mask_bits, float mask_slope, float dy_gain,
                                    float* dw, float* dbias, float coef, void* workspace, size_t workspace_bytes,
                                    const sg_conv_shape* s, sg_dtype dt, sg_stream_t st);
-/* dw_dhwio += coef * sum: the weights are used more than once in the graph a training step differentiates (the
- * discriminator under WGAN-GP: networks/loss.py:136-140 differentiates D a second time, optimization.py:128-163 asks for one
- * gradient per variable) and the parameter's gradient buffer already holds the other contribution.  The sum is rounded to f32
- * before it is added -- the value tf.gradients' add_n of the two finished gradients has.  dbias (optional) is WRITTEN, not
- * added to.  mask_bits == NULL: x / dy as sg_conv3d_wgrad_bias; else dy is the half-resolution gradient of
- * sg_conv3d_wgrad_bias_up_masked.  SG_EUNSUPPORTED where the layer runs on the pointwise (<= 4 channels on one side) or the
- * small-channel (<= 16, 2-D top levels) kernels. */
-int sg_conv3d_wgrad_bias_accumulate(const void* x, const void* dy, const void* mask_bits, float mask_slope, float dy_gain,
-                                    float* dw_dhwio, float* dbias, float coef, void* workspace, size_t workspace_bytes,
-                                    const sg_conv_shape* s, sg_dtype dt, sg_stream_t st);
+/* sg_conv3d_wgrad_bias (mask_bits == NULL) / sg_conv3d_wgrad_bias_up_masked (mask_bits != NULL) with options:
+ * SG_WGRAD_ACCUMULATE: dw_dhwio += coef * sum -- the weights are used more than once in the graph a training step
+ *   differentiates (the discriminator under WGAN-GP: networks/loss.py:136-140 differentiates D a second time,
+ *   optimization.py:128-163 asks for one gradient per variable) and the parameter's gradient buffer already holds the other
+ *   contribution.  The sum is rounded to f32 before it is added: the value tf.gradients' add_n of the two finished gradients
+ *   has.  dbias (optional) is WRITTEN, not added to.
+ * SG_WGRAD_CLEAN_WORKSPACE: the caller keeps the workspace between calls; its first sg_conv3d_wgrad_clean_bytes(s, dt) bytes are
+ *   zero on entry and are left zero (the finalize pass clears what it reads), and the call launches no memset.  (A failed
+ *   call leaves the workspace undefined: clear it before the next use.)
+ * SG_EUNSUPPORTED, with nothing touched, where the layer runs on the pointwise (<= 4 channels on one side) or the small-channel
+ * (<= 16, 2-D top levels) kernels. */
+#define SG_WGRAD_ACCUMULATE 1u
+#define SG_WGRAD_CLEAN_WORKSPACE 2u
+int sg_conv3d_wgrad_bias_ex(const void* x, const void* dy, const void* mask_bits, float mask_slope, float dy_gain,
+                            float* dw_dhwio, float* dbias, float coef, unsigned flags, void* workspace, size_t workspace_bytes,
+                            const sg_conv_shape* s, sg_dtype dt, sg_stream_t st);
+size_t sg_conv3d_wgrad_clean_bytes(const sg_conv_shape* s, sg_dtype dt);
 
 /* Whole backward of a pointwise convolution FROM cin <= 4 channels (from_rgb, pgan/discriminator.py:9-12) in one pass over
  * dy: dw, dbias as sg_conv3d_wgrad_bias, and dx[n,d,h,w,cin] = sum_c dy[..,c] * w_mat[j][c] (w_mat: [cin][cout] f32, the

@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(_HERE, 'libsaragan_hip.so')
 SG_F32, SG_BF16 = 0, 1
 SG_OPT_SGD, SG_OPT_MOMENTUM, SG_OPT_ADADELTA = 0, 1, 2
 SG_EUNSUPPORTED = -4
+SG_WGRAD_ACCUMULATE, SG_WGRAD_CLEAN_WORKSPACE = 1, 2      # sg_conv3d_wgrad_bias_ex flags
 
 
 class ConvShape(C.Structure):
@@ -64,7 +65,8 @@ SIGNATURES = {
     'sg_conv3d_pw_bwd': (C.c_int, [_p, _p, _p, _p, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
     'sg_conv3d_wgrad_bias': (C.c_int, [_p, _p, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
     'sg_conv3d_wgrad_bias_up_masked': (C.c_int, [_p, _p, _p, _f, _f, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
-    'sg_conv3d_wgrad_bias_accumulate': (C.c_int, [_p, _p, _p, _f, _f, _p, _p, _f, _p, _sz, _SHP, C.c_int, _p]),
+    'sg_conv3d_wgrad_bias_ex': (C.c_int, [_p, _p, _p, _f, _f, _p, _p, _f, C.c_uint, _p, _sz, _SHP, C.c_int, _p]),
+    'sg_conv3d_wgrad_clean_bytes': (_sz, [_SHP, C.c_int]),
     'sg_bias_act_fwd': (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _f, C.c_int, _p]),
     'sg_bias_act_bwd_workspace': (_sz, [_i32]),
     'sg_bias_act_bwd': (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _f, C.c_int, _p]),

@@ -164,24 +164,39 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(WgradArgs a) {
   }
 }
 
-__global__ void wgrad_finalize_kernel(const float* __restrict__ dwt, float* __restrict__ dw, float coef, int taps,
+__global__ void wgrad_finalize_kernel(float* __restrict__ dwt, float* __restrict__ dw, float coef, int taps,
                                       int cin, int cout, int ciT, int coT, int nslab, int64_t slab,
-                                      const float* __restrict__ bias_staged = nullptr, float* __restrict__ dbias = nullptr,
-                                      int accumulate = 0) {
+                                      float* __restrict__ bias_staged = nullptr, float* __restrict__ dbias = nullptr,
+                                      int accumulate = 0, int clean = 0) {
   const int64_t total = (int64_t)taps * cin * cout;
   // the bias gradient the kernel accumulated beside the tile (one memset clears both): out to the caller's buffer
+  // clean: every word read here is set back to zero -- the next call on this workspace starts without a memset
   if (bias_staged != nullptr && blockIdx.x == 0)
-    for (int c = threadIdx.x; c < cout; c += blockDim.x) dbias[c] = bias_staged[c];
+    for (int c = threadIdx.x; c < cout; c += blockDim.x) {
+      dbias[c] = bias_staged[c];
+      if (clean) bias_staged[c] = 0.f;
+    }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int co = (int)(i % cout);
     int64_t q = i / cout;
     int ci = (int)(q % cin);
     int tap = (int)(q / cin);
-    const float* src = dwt + ((((int64_t)tap * ciT + (ci >> 5)) * coT + (co >> 5)) << 10) + (ci & 31) * 32 + (co & 31);
+    float* src = dwt + ((((int64_t)tap * ciT + (ci >> 5)) * coT + (co >> 5)) << 10) + (ci & 31) * 32 + (co & 31);
     float v = src[0];
+    if (clean) src[0] = 0.f;
     for (int b = 1; b < nslab; ++b) v += src[(int64_t)b * slab];      // reproducible mode: the slabs in order
     const float t = __fmul_rn(coef, v);      // (accumulate: the same two roundings as a separate add of the finished gradient)
     dw[i] = accumulate ? __fadd_rn(dw[i], t) : t;
+  }
+  // clean: the padding rows / columns of partial 32 x 32 tiles too (some kernels add what their staging left there; nobody
+  // reads it, but the next layer on this workspace may have more channels)
+  if (clean && ((cin & 31) || (cout & 31))) {
+    const int64_t padded = ((int64_t)taps * ciT * coT) << 10;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < padded; i += (int64_t)gridDim.x * blockDim.x) {
+      const int co = (int)((i >> 10) % coT) * 32 + (int)(i & 31);
+      const int ci = (int)(((i >> 10) / coT) % ciT) * 32 + (int)((i >> 5) & 31);
+      if (ci >= cin || co >= cout) dwt[i] = 0.f;
+    }
   }
 }
 
@@ -345,7 +360,9 @@ extern "C" size_t sg_conv3d_wgrad_workspace(const sg_conv_shape* s, sg_dtype dt)
   if (!conv_shape_ok_w(s)) return 0;
   // [tile / partial sums (x slabs in reproducible mode)][bias-gradient fallback][bias slabs]
   const size_t ns = sg_cfg().deterministic ? (size_t)wgrad_slab_count(s) : 1;
-  const size_t gen = ns * wgrad_tile_bytes(s) + sg_bias_act_bwd_workspace(s->cout) + (ns > 1 ? ns * wgrad_bias_slab_bytes(s) : 0);
+  // (+ one bias row: with SG_WGRAD_CLEAN_WORKSPACE the bias fallback's scratch starts behind the staged bias row, which stays clean)
+  const size_t gen = ns * wgrad_tile_bytes(s) + sg_bias_act_bwd_workspace(s->cout) + (ns > 1 ? ns * wgrad_bias_slab_bytes(s) : 0) +
+                     wgrad_bias_slab_bytes(s);
   const size_t small = sg_small_wgrad_workspace(s);                              // per-block slabs of the small-channel kernel
   return gen > small ? gen : small;
 }
@@ -1620,7 +1637,9 @@ extern "C" int sg_conv3d_wgrad(const void* x, const void* dy, float* dw, float c
 static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbias, float coef, void* workspace,
                            size_t workspace_bytes, const sg_conv_shape* s, sg_dtype dt, sg_stream_t st, void* pw_dx,
                            const float* pw_wmat, const void* dy_mask = nullptr, float dy_mask_slope = 0.f, float dy_gain = 1.f,
-                           int accumulate = 0) {
+                           unsigned flags = 0) {
+  const int accumulate = (flags & SG_WGRAD_ACCUMULATE) ? 1 : 0;
+  const bool clean_ws = (flags & SG_WGRAD_CLEAN_WORKSPACE) != 0;
   if (!conv_shape_ok_w(s) || !x || !dy || !dw || !workspace) return SG_EINVAL;
   if (!sg_aligned16(x) || !sg_aligned16(dy) || !sg_aligned16(workspace)) return SG_EALIGN;
   if (dy_mask && (dt != SG_BF16 || s->kd != 3 || s->kh != 3 || s->kw != 3 || s->upsample_in || (s->cout % 32) ||
@@ -1635,7 +1654,7 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
     const int cs = s->cin < s->cout ? s->cin : s->cout, cb = s->cin < s->cout ? s->cout : s->cin;
     const int E = dt == SG_BF16 ? 8 : 4;
     if (taps1 == 1 && cs <= 4 && !s->upsample_in && cb % E == 0 && cb / E <= 256 && 256 % (cb / E) == 0) {
-      if (accumulate) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }   // (the tile finalize below is the accumulating one)
+      if (accumulate || clean_ws) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }   // (the tile finalize below is the one that accumulates / cleans)
       const int small_is_cin = s->cin <= s->cout ? 1 : 0;
       const void* sm = small_is_cin ? x : dy;
       const void* bg = small_is_cin ? dy : x;
@@ -1670,7 +1689,7 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
   }
   if (pw_dx) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }   // only the pointwise pass has the extra output
   if (sg_small_wgrad_eligible(s) && !sg_cfg().no_small) {   // 2-D top levels (<= 16 channels): VALU kernel, slab reduction
-    if (accumulate) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }
+    if (accumulate || clean_ws) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }
     const int rc_s = sg_small_wgrad(x, dy, dw, dbias, coef, workspace, workspace_bytes, s, dt, hs);
     prof.done(rc_s);
     return rc_s;
@@ -1688,7 +1707,7 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
     prof.done(SG_EWORKSPACE);
     return SG_EWORKSPACE;
   }
-  if (!det)      // (reproducible mode: every block of the grid stores its whole slab, nothing to clear)
+  if (!det && !clean_ws)      // (reproducible mode: every block of the grid stores its whole slab, nothing to clear)
     e = hipMemsetAsync(workspace, 0, bias_staged ? tile_al + (size_t)s->cout * sizeof(float) : tile_bytes, hs);
   if (e != hipSuccess) { prof.done((int)e); return (int)e; }
   WgradArgs a;
@@ -1733,8 +1752,8 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(wgrad_finalize_kernel, dim3(blocks), dim3(256), 0, hs, a.dwt, dw, coef, a.taps, s->cin,
-                       s->cout, a.ciT, a.coT, det ? a.nslab : 1, a.slab, (const float*)((bias_staged && db_done) ? bias_staged : nullptr), dbias,
-                       accumulate);
+                       s->cout, a.ciT, a.coT, det ? a.nslab : 1, a.slab, (bias_staged && db_done) ? bias_staged : nullptr, dbias,
+                       accumulate, (clean_ws && !det) ? 1 : 0);
     if (det && dbias && db_done)
       hipLaunchKernelGGL(wgrad_bias_slabs_kernel, dim3((unsigned)sg_cdiv(s->cout, 256)), dim3(256), 0, hs, bias_slabs, dbias, s->cout,
                          a.nslab, a.bslab);
@@ -1742,7 +1761,8 @@ static int wgrad_bias_impl(const void* x, const void* dy, float* dw, float* dbia
     if (e2 != hipSuccess) rc = (int)e2;
   }
   if (rc == SG_OK && dbias && !db_done)
-    rc = sg_bias_act_bwd(dy, nullptr, nullptr, dbias, reinterpret_cast<char*>(workspace) + ns_max * wgrad_tile_bytes(s),
+    rc = sg_bias_act_bwd(dy, nullptr, nullptr, dbias,
+                         reinterpret_cast<char*>(workspace) + ns_max * wgrad_tile_bytes(s) + (clean_ws ? wgrad_bias_slab_bytes(s) : 0),
                          (int64_t)s->n * s->d * s->h * s->w, s->cout, 0.f, dt, st);
   prof.done(rc);
   return rc;
@@ -1763,16 +1783,29 @@ extern "C" int sg_conv3d_wgrad_bias_up_masked(const void* x, const void* dy_half
   return wgrad_bias_impl(x, dy_half, dw, dbias, coef, workspace, workspace_bytes, s, dt, st, nullptr, nullptr, mask_bits, mask_slope, dy_gain);
 }
 
-// dw += coef * sum (the parameter's gradient already holds another contribution: a second use of the weights in the graph, the
-// gradient penalty's second-order term) -- rounded like the finished gradient added afterwards; dbias (optional) is WRITTEN.
-// mask_bits == NULL: plain dy (sg_conv3d_wgrad_bias), else the gathered half-resolution dy (sg_conv3d_wgrad_bias_up_masked).
-// SG_EUNSUPPORTED on the pointwise / small-channel paths (their finalize kernels only write).
-extern "C" int sg_conv3d_wgrad_bias_accumulate(const void* x, const void* dy, const void* mask_bits, float mask_slope, float dy_gain,
-                                               float* dw, float* dbias, float coef, void* workspace, size_t workspace_bytes,
-                                               const sg_conv_shape* s, sg_dtype dt, sg_stream_t st) {
+// sg_conv3d_wgrad_bias / sg_conv3d_wgrad_bias_up_masked (mask_bits != NULL) with options:
+//   SG_WGRAD_ACCUMULATE       dw += coef * sum (the parameter's gradient already holds another contribution: a second use of the
+//                             weights in the graph, the gradient penalty's second-order term) -- rounded like the finished
+//                             gradient added afterwards; dbias (optional) is WRITTEN.
+//   SG_WGRAD_CLEAN_WORKSPACE  the workspace's first sg_conv3d_wgrad_clean_bytes() bytes are zero on entry (the caller keeps the
+//                             buffer between calls) and are zero again when the call has drained: the finalize pass clears
+//                             what it reads, and no memset is launched.
+// SG_EUNSUPPORTED (nothing touched) on the pointwise / small-channel paths: their finalize kernels only write, and their
+// partial sums do not leave the workspace clean.
+extern "C" int sg_conv3d_wgrad_bias_ex(const void* x, const void* dy, const void* mask_bits, float mask_slope, float dy_gain,
+                                       float* dw, float* dbias, float coef, unsigned flags, void* workspace, size_t workspace_bytes,
+                                       const sg_conv_shape* s, sg_dtype dt, sg_stream_t st) {
   if (mask_bits && !sg_aligned16(mask_bits)) return SG_EALIGN;
+  if (flags & ~(unsigned)(SG_WGRAD_ACCUMULATE | SG_WGRAD_CLEAN_WORKSPACE)) return SG_EINVAL;
   return wgrad_bias_impl(x, dy, dw, dbias, coef, workspace, workspace_bytes, s, dt, st, nullptr, nullptr, mask_bits, mask_slope,
-                         mask_bits ? dy_gain : 1.f, 1);
+                         mask_bits ? dy_gain : 1.f, flags);
+}
+
+extern "C" size_t sg_conv3d_wgrad_clean_bytes(const sg_conv_shape* s, sg_dtype dt) {
+  (void)dt;
+  if (!conv_shape_ok_w(s)) return 0;
+  const size_t tile_bytes = (size_t)(s->kd * s->kh * s->kw) * sg_cdiv(s->cin, 32) * sg_cdiv(s->cout, 32) * 4096;
+  return ((tile_bytes + 255) & ~(size_t)255) + (size_t)s->cout * sizeof(float);
 }
 
 extern "C" int sg_conv3d_pw_bwd(const void* x, const void* dy, const float* w_mat, float* dw, float* dbias, void* dx,

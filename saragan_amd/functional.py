@@ -236,6 +236,36 @@ def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel
     return y, scale, signs
 
 
+_CLEAN_WS = {}            # (device, workspace bytes) -> kept workspace, zero between calls (SG_WGRAD_CLEAN_WORKSPACE)
+_CLEAN_WS_DECLINED = set()   # shapes whose kernels do not leave the workspace clean (pointwise / small-channel paths)
+_NO_CLEAN_WS = bool(int(os.environ.get('SARAGAN_NO_CLEAN_WS', '0')))   # diagnostic: a fresh workspace + memset per weight gradient
+
+
+def _wgrad_launch(lib, x, dy, mask, mask_slope, gain, dw, db, coef, accumulate, shp, dt):
+    """One filter (+ bias) gradient through sg_conv3d_wgrad_bias_ex.  The kernels sum their tiles into a zeroed workspace; the
+    workspace of a layer is kept between calls and cleared by the pass that reads it (SG_WGRAD_CLEAN_WORKSPACE) instead of a
+    hipMemsetAsync per call -- 37 launches per step at the benchmarked configuration.  Returns the library's code."""
+    flags = _lib.SG_WGRAD_ACCUMULATE if accumulate else 0
+    ws_bytes = lib.sg_conv3d_wgrad_workspace(C.byref(shp), dt)
+    skey = (shp.n, shp.d, shp.h, shp.w, shp.cin, shp.cout, shp.kd, shp.kh, shp.kw, shp.upsample_in, dt, mask is not None)
+    if not _NO_CLEAN_WS and skey not in _CLEAN_WS_DECLINED:
+        key = (x.device, ws_bytes)
+        ws = _CLEAN_WS.get(key)
+        if ws is None:
+            ws = _CLEAN_WS[key] = torch.zeros(ws_bytes, device=x.device, dtype=torch.uint8)
+        rc = lib.sg_conv3d_wgrad_bias_ex(_ptr(x), _ptr(dy), _ptr(mask), float(mask_slope), float(gain), _ptr(dw), _ptr(db), float(coef),
+                                         flags | _lib.SG_WGRAD_CLEAN_WORKSPACE, _ptr(ws), ws_bytes, C.byref(shp), dt, _stream())
+        if rc == 0:
+            return 0
+        if rc != _lib.SG_EUNSUPPORTED:
+            _CLEAN_WS.pop(key, None)         # a failed call leaves the workspace undefined
+            return rc
+        _CLEAN_WS_DECLINED.add(skey)         # (declined before anything was touched)
+    ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
+    return lib.sg_conv3d_wgrad_bias_ex(_ptr(x), _ptr(dy), _ptr(mask), float(mask_slope), float(gain), _ptr(dw), _ptr(db), float(coef),
+                                       flags, _ptr(ws), ws_bytes, C.byref(shp), dt, _stream())
+
+
 def raw_wgrad(x, dy, k, coef, ups=False, want_db=False, w_ptr=0, b_ptr=0):
     """dw[kd,kh,kw,cin,cout] (f32) = coef * sum_v x[v+tap] (x) dy[v]; optionally db[cout] = sum_v dy[v].
     w_ptr / b_ptr: data_ptr of the parameters these are the gradients of (grads_into)."""
@@ -259,22 +289,18 @@ def raw_wgrad(x, dy, k, coef, ups=False, want_db=False, w_ptr=0, b_ptr=0):
                                                  C.byref(low), dt, _stream()), 'sg_upconv3d_subpixel_wgrad')
             return dw, db
     shp = _shape(n, d, h, w, cin, cout, k, ups)
-    ws_bytes = lib.sg_conv3d_wgrad_workspace(C.byref(shp), dt)
-    ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
     acc = _grad_acc(w_ptr, (k[0], k[1], k[2], cin, cout))
     if acc is not None:       # a further contribution to a gradient that is in its slot already: added there, nothing returned
         db = _f32_out(b_ptr, (cout,), x.device) if want_db else None      # (the bias gradient is written, not added)
-        rc = lib.sg_conv3d_wgrad_bias_accumulate(_ptr(x), _ptr(dy), None, 0.0, 1.0, _ptr(acc), _ptr(db), float(coef), _ptr(ws), ws_bytes,
-                                                 C.byref(shp), dt, _stream())
+        rc = _wgrad_launch(lib, x, dy, None, 0.0, 1.0, acc, db, coef, True, shp, dt)
         if rc != _lib.SG_EUNSUPPORTED:
-            check(rc, 'sg_conv3d_wgrad_bias_accumulate')
+            check(rc, 'sg_conv3d_wgrad_bias_ex (accumulate)')
             GRAD_DEST_STATS['accumulated'] += 1
             return None, db
         _unclaim(b_ptr, db)
     dw = _f32_out(w_ptr, (k[0], k[1], k[2], cin, cout), x.device)
     db = _f32_out(b_ptr, (cout,), x.device) if want_db else None
-    check(lib.sg_conv3d_wgrad_bias(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), float(coef), _ptr(ws), ws_bytes,
-                                   C.byref(shp), dt, _stream()), 'sg_conv3d_wgrad_bias')
+    check(_wgrad_launch(lib, x, dy, None, 0.0, 1.0, dw, db, coef, False, shp, dt), 'sg_conv3d_wgrad_bias_ex')
     return dw, db
 
 
@@ -358,7 +384,7 @@ def _grad_out(ptr, shape):
 def _grad_acc(ptr, shape):
     """The slot registered for parameter `ptr` when a gradient HAS been written to it in this backward (by a kernel of this
     module: the alias is with autograd, waiting for the parameter's other contributions) -- a kernel that accumulates
-    (sg_conv3d_wgrad_bias_accumulate) adds the next contribution in place and the Function returns None for it."""
+    (sg_conv3d_wgrad_bias_ex, SG_WGRAD_ACCUMULATE) adds the next contribution in place and the Function returns None for it."""
     if not ptr or not _GRAD_DEST or torch.is_grad_enabled():
         return None
     ent = _GRAD_DEST.get(ptr)
@@ -902,26 +928,22 @@ class _PooledDgradGather(torch.autograd.Function):
             n, _, d, h, wd = _dims(ggx_)
             dt = _dt(ggx_)
             shp = _shape(n, d, h, wd, 32, 64, (3, 3, 3), False)
-            ws_bytes = lib.sg_conv3d_wgrad_workspace(C.byref(shp), dt)
-            ws = torch.empty(ws_bytes, device=ggx.device, dtype=torch.uint8)
             acc = _grad_acc(w.data_ptr(), (3, 3, 3, 32, 64))
             rc = _lib.SG_EUNSUPPORTED
             if acc is not None:      # the first-order contribution is in the slot already: this one is added there
-                rc = lib.sg_conv3d_wgrad_bias_accumulate(_ptr(ggx_), _ptr(gy_), _ptr(signs), slope, 0.125, _ptr(acc), None, coef,
-                                                         _ptr(ws), ws_bytes, C.byref(shp), dt, _stream())
+                rc = _wgrad_launch(lib, ggx_, gy_, signs, slope, 0.125, acc, None, coef, True, shp, dt)
             if rc != _lib.SG_EUNSUPPORTED:
-                check(rc, 'sg_conv3d_wgrad_bias_accumulate')
+                check(rc, 'sg_conv3d_wgrad_bias_ex (gathered dy, accumulate)')
                 GRAD_DEST_STATS['accumulated'] += 1
                 return g_gy, None, None, None, None, None, None
             dw = _f32_out(w.data_ptr(), (3, 3, 3, 32, 64), ggx.device)
-            rc = lib.sg_conv3d_wgrad_bias_up_masked(_ptr(ggx_), _ptr(gy_), _ptr(signs), slope, 0.125, _ptr(dw), None, coef,
-                                                    _ptr(ws), ws_bytes, C.byref(shp), dt, _stream())
+            rc = _wgrad_launch(lib, ggx_, gy_, signs, slope, 0.125, dw, None, coef, False, shp, dt)
             if rc == _lib.SG_EUNSUPPORTED:      # the materialised pair, as the plain path computes it
                 _unclaim(w.data_ptr(), dw)
                 g_full = _Up.apply(gy_, 0.125, signs, slope, (2, 2, 2))
                 dw, _ = raw_wgrad(ggx_, g_full, (3, 3, 3), coef, False, False, w.data_ptr())
             else:
-                check(rc, 'sg_conv3d_wgrad_bias_up_masked')
+                check(rc, 'sg_conv3d_wgrad_bias_ex (gathered dy)')
             g_w = dw.reshape(w.shape) if dw is not None else None
         return g_gy, g_w, None, None, None, None, None
 
@@ -964,18 +986,19 @@ def _pooled_backward_gather(gy, x, w, signs, coef, slope, in_info, want_gx, want
         check(rc, 'sg_conv3d_fwd (masked gather)')
     if want_gw or want_db:
         shp = _shape(n, d, h, wd, 32, 64, k, False)
-        ws_bytes = lib.sg_conv3d_wgrad_workspace(C.byref(shp), dt)
-        ws = torch.empty(ws_bytes, device=gy.device, dtype=torch.uint8)
-        dw = _f32_out(w.data_ptr() if want_gw else 0, (3, 3, 3, 32, 64), gy.device)
+        acc = _grad_acc(w.data_ptr(), (3, 3, 3, 32, 64)) if want_gw else None
+        dw = acc if acc is not None else _f32_out(w.data_ptr() if want_gw else 0, (3, 3, 3, 32, 64), gy.device)
         gb = _f32_out(b_ptr, (64,), gy.device) if want_db else None
-        rc = lib.sg_conv3d_wgrad_bias_up_masked(_ptr(x), _ptr(gy), _ptr(signs), float(slope), 0.125, _ptr(dw), _ptr(gb), float(coef),
-                                                _ptr(ws), ws_bytes, C.byref(shp), dt, st)
+        rc = _wgrad_launch(lib, x, gy, signs, slope, 0.125, dw, gb, coef, acc is not None, shp, dt)
         if rc == _lib.SG_EUNSUPPORTED:
-            _unclaim(w.data_ptr(), dw)
+            if acc is None:
+                _unclaim(w.data_ptr(), dw)
             _unclaim(b_ptr, gb)
             return None
-        check(rc, 'sg_conv3d_wgrad_bias_up_masked')
-        gw = dw.reshape(w.shape) if want_gw else None
+        check(rc, 'sg_conv3d_wgrad_bias_ex (gathered dy)')
+        if acc is not None:
+            GRAD_DEST_STATS['accumulated'] += 1
+        gw = dw.reshape(w.shape) if (want_gw and acc is None) else None
     return gx, gw, gb
 
 

@@ -1406,9 +1406,10 @@ def test_wgrad_16_wide_levels_on_the_sliding_halo_kernel(case, sg_env, monkeypat
 
 @pytest.mark.parametrize('case', [(2, 32, 32, (4, 16, 32), False), (2, 32, 64, (4, 128, 256), True), (4, 64, 64, (1, 8, 8), False), (2, 1, 16, (4, 8, 8), None)])
 def test_wgrad_accumulate_equals_the_add_of_the_finished_gradient(case):
-    """sg_conv3d_wgrad_bias_accumulate (a second contribution to a parameter's gradient, optimization.py:128-163 over
-    networks/loss.py:136-140): dw += coef * sum, bit for bit what adding the finished gradient gives; the bias gradient is
-    written; declined (SG_EUNSUPPORTED) on the pointwise path."""
+    """sg_conv3d_wgrad_bias_ex.  SG_WGRAD_ACCUMULATE (a second contribution to a parameter's gradient, optimization.py:128-163
+    over networks/loss.py:136-140): dw += coef * sum, bit for bit what adding the finished gradient gives; the bias gradient is
+    written.  SG_WGRAD_CLEAN_WORKSPACE: a kept workspace that is zero on entry is zero again afterwards, no memset in between.
+    Both declined (SG_EUNSUPPORTED, nothing touched) on the pointwise path."""
     import ctypes as C
     from saragan_amd import _lib
     from saragan_amd import functional as F
@@ -1436,12 +1437,26 @@ def test_wgrad_accumulate_equals_the_add_of_the_finished_gradient(case):
         margs = (None, 0.0, 1.0)
     acc = first.clone()
     db = torch.full((cout,), 7.0, device=dev())
-    rc = lib.sg_conv3d_wgrad_bias_accumulate(x.data_ptr(), gy.data_ptr(), *margs, acc.data_ptr(), None if masked else db.data_ptr(), 0.05,
-                                             ws.data_ptr(), ws_bytes, C.byref(shp), _lib.SG_BF16, st)
+    rc = lib.sg_conv3d_wgrad_bias_ex(x.data_ptr(), gy.data_ptr(), *margs, acc.data_ptr(), None if masked else db.data_ptr(), 0.05,
+                                     _lib.SG_WGRAD_ACCUMULATE, ws.data_ptr(), ws_bytes, C.byref(shp), _lib.SG_BF16, st)
+    kept = torch.zeros(ws_bytes, device=dev(), dtype=torch.uint8)
     if masked is None:
         assert rc == _lib.SG_EUNSUPPORTED and torch.equal(acc, first)
+        rc = lib.sg_conv3d_wgrad_bias_ex(x.data_ptr(), gy.data_ptr(), *margs, acc.data_ptr(), None, 0.05, _lib.SG_WGRAD_CLEAN_WORKSPACE,
+                                         kept.data_ptr(), ws_bytes, C.byref(shp), _lib.SG_BF16, st)
+        assert rc == _lib.SG_EUNSUPPORTED and torch.equal(acc, first) and int(kept.count_nonzero()) == 0
         return
     _lib.check(rc)
+    # the kept workspace: two calls in a row without a memset, same result as the plain entry point, clean afterwards
+    clean_bytes = lib.sg_conv3d_wgrad_clean_bytes(C.byref(shp), _lib.SG_BF16)
+    assert 0 < clean_bytes <= ws_bytes
+    for _ in range(2):
+        got = torch.empty_like(first)
+        gdb = torch.empty(cout, device=dev())
+        _lib.check(lib.sg_conv3d_wgrad_bias_ex(x.data_ptr(), gy.data_ptr(), *margs, got.data_ptr(), gdb.data_ptr(), 0.05,
+                                               _lib.SG_WGRAD_CLEAN_WORKSPACE, kept.data_ptr(), ws_bytes, C.byref(shp), _lib.SG_BF16, st))
+        np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
+        assert int(kept[:clean_bytes].count_nonzero()) == 0
     import saragan_amd
     if not masked:      # atomics: the sums themselves differ from launch to launch in the last bits unless reproducible
         np.testing.assert_allclose(acc.cpu().numpy(), (first + ref).cpu().numpy(), rtol=1e-5, atol=1e-5 * float(ref.abs().max()))
@@ -1458,8 +1473,38 @@ def test_wgrad_accumulate_equals_the_add_of_the_finished_gradient(case):
         else:
             _lib.check(lib.sg_conv3d_wgrad_bias(x.data_ptr(), gy.data_ptr(), ref2.data_ptr(), None, 0.05, ws2.data_ptr(), ws2.numel(),
                                                 C.byref(shp), _lib.SG_BF16, st))
-        _lib.check(lib.sg_conv3d_wgrad_bias_accumulate(x.data_ptr(), gy.data_ptr(), *margs, acc2.data_ptr(), None, 0.05, ws2.data_ptr(),
-                                                       ws2.numel(), C.byref(shp), _lib.SG_BF16, st))
+        _lib.check(lib.sg_conv3d_wgrad_bias_ex(x.data_ptr(), gy.data_ptr(), *margs, acc2.data_ptr(), None, 0.05, _lib.SG_WGRAD_ACCUMULATE,
+                                               ws2.data_ptr(), ws2.numel(), C.byref(shp), _lib.SG_BF16, st))
         assert torch.equal(acc2, first + ref2)
     finally:
         saragan_amd.set_deterministic(False)
+
+
+def test_kept_wgrad_workspace_is_shared_by_layers_of_any_channel_count(monkeypatch):
+    """SG_WGRAD_CLEAN_WORKSPACE through functional.raw_wgrad: layers whose workspaces have the same size share one kept buffer.
+    A 16-channel layer (partial 32 x 32 tiles, the generic kernel, bias gradient by the fallback pass) must leave it clean for a
+    32-channel layer that follows (sliding-halo kernel with the bias gradient in its spare tap) -- same results as with a fresh
+    workspace and a memset per call."""
+    from saragan_amd import functional as F
+    dtype = torch.bfloat16
+    shapes = [(2, 16, 32, (4, 8, 8)), (2, 32, 32, (5, 128, 256)), (2, 24, 8, (3, 5, 7)), (2, 32, 32, (4, 16, 32))]
+    data = [(cl(rnd((n, ci, *sp), 500 + i, dtype), dtype), cl(rnd((n, co, *sp), 600 + i, dtype), dtype)) for i, (n, ci, co, sp) in enumerate(shapes)]
+
+    def sweep():
+        out = []
+        for _ in range(2):
+            for x, gy in data:
+                out.append(F.raw_wgrad(x, gy, (3, 3, 3), 0.05, False, want_db=True))
+        torch.cuda.synchronize()
+        return out
+
+    F._CLEAN_WS.clear()
+    F._CLEAN_WS_DECLINED.clear()
+    kept = sweep()
+    assert len(F._CLEAN_WS) >= 1 and not F._CLEAN_WS_DECLINED
+    monkeypatch.setattr(F, '_NO_CLEAN_WS', True)
+    fresh = sweep()
+    for (dw, db), (dw0, db0) in zip(kept, fresh):
+        scale = float(dw0.abs().max())
+        np.testing.assert_allclose(dw.cpu().numpy(), dw0.cpu().numpy(), rtol=1e-5, atol=1e-5 * scale)
+        np.testing.assert_allclose(db.cpu().numpy(), db0.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(db0.abs().max()))

@@ -139,6 +139,11 @@ size_t sg_conv3d_packed_bytes(const sg_conv_shape* s, sg_dtype dt);
  * (kD,kH,kW) and transposed in (I,O) (what tf's Conv3DBackpropInputV2 computes for stride 1). */
 int sg_conv3d_pack_weights(const float* w_dhwio, float coef, int transpose_flip, void* wp,
                            const sg_conv_shape* s, sg_dtype dt, sg_stream_t st);
+/* The images of n layers at once -- what n calls of sg_conv3d_pack_weights write, the fragment images in one launch per 56
+ * layers.  After an optimiser step (optimization.py:16-73: every variable of the network moves) all of a network's images are
+ * stale together; w / coef / transpose_flip / wp / shapes are host arrays of n entries. */
+int sg_conv3d_pack_weights_batch(int n, const float* const* w_dhwio, const float* coef, const int* transpose_flip,
+                                 void* const* wp, const sg_conv_shape* shapes, sg_dtype dt, sg_stream_t st);
 /* Bytes of sg_conv_epilogue.workspace that let this shape take its fastest path (0: none needed). */
 size_t sg_conv3d_fwd_workspace(const sg_conv_shape* s, sg_dtype dt);
 /* y = epilogue(conv3d(x, wp)).  x: [n,d,h,w,cin] (or half-res if upsample_in), y: [n,d,h,w,cout]. */

@@ -47,6 +47,7 @@ SIGNATURES = {
     'sg_error_string': (C.c_char_p, [C.c_int]),
     'sg_conv3d_packed_bytes': (_sz, [_SHP, C.c_int]),
     'sg_conv3d_pack_weights': (C.c_int, [_p, _f, C.c_int, _p, _SHP, C.c_int, _p]),
+    'sg_conv3d_pack_weights_batch': (C.c_int, [C.c_int, _p, _p, _p, _p, _p, C.c_int, _p]),
     'sg_conv3d_fwd_workspace': (_sz, [_SHP, C.c_int]),
     'sg_conv3d_fwd': (C.c_int, [_p, _p, _p, _SHP, C.POINTER(ConvEpilogue), C.c_int, _p]),
     'sg_upconv3d_subpixel_supported': (C.c_int, [_SHP, C.c_int]),

@@ -53,6 +53,38 @@ __global__ void pack_weights_kernel(PackArgs a) {
   }
 }
 
+// Many images in one launch (sg_conv3d_pack_weights_batch): blockIdx.y picks the item.  The table travels in the kernel
+// arguments (<= 4 KiB): no device-side table to keep alive, and a captured launch carries its own copy.
+constexpr int SG_PACK_BATCH = 56;
+struct PackBatchArgs {
+  PackArgs item[SG_PACK_BATCH];
+};
+
+template <typename T>
+__global__ void pack_weights_batch_kernel(PackBatchArgs b) {
+  const PackArgs& a = b.item[blockIdx.y];
+  constexpr int CH = sg_traits<T>::CH;
+  constexpr int EPL = CH / 2;
+  const int64_t total = (int64_t)a.nchunk * a.taps * a.ntile * 64 * EPL;
+  T* out = reinterpret_cast<T*>(a.wp);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int e = (int)(i % EPL);
+    int64_t q = i / EPL;
+    int lane = (int)(q % 64); q /= 64;
+    int nt = (int)(q % a.ntile); q /= a.ntile;
+    int tap = (int)(q % a.taps);
+    int chunk = (int)(q / a.taps);
+    int ci = chunk * CH + (lane >> 5) * EPL + e;
+    int co = nt * 32 + (lane & 31);
+    float v = 0.f;
+    if (ci < a.cin && co < a.cout) {
+      v = a.flip ? a.w[((int64_t)(a.taps - 1 - tap) * a.cout + co) * a.cin + ci] : a.w[((int64_t)tap * a.cin + ci) * a.cout + co];
+      v *= a.coef;
+    }
+    out[i] = sg_traits<T>::from_f(v);
+  }
+}
+
 static inline int conv_nchunk(const sg_conv_shape* s, sg_dtype dt) {
   int ch = dt == SG_BF16 ? 16 : 8;
   return sg_cdiv(s->cin, ch);
@@ -95,6 +127,49 @@ extern "C" int sg_conv3d_pack_weights(const float* w, float coef, int transpose_
     return sg_fwd3p16_pack(w, coef, a.flip, reinterpret_cast<char*>(wp) + (size_t)a.nchunk * a.taps * a.ntile * 1024, sg_st(st));
   if (sg_small_tail_bytes(s))
     return sg_small_pack(w, coef, a.flip, reinterpret_cast<char*>(wp) + (size_t)a.nchunk * a.taps * a.ntile * 1024, s, dt, sg_st(st));
+  return SG_OK;
+}
+
+// The images of n layers (what n calls of sg_conv3d_pack_weights write), the MFMA-fragment images in one launch per 56 layers:
+// after an optimiser step every layer's images are stale at once (44 pack launches per step at the benchmarked configuration).
+extern "C" int sg_conv3d_pack_weights_batch(int n, const float* const* w, const float* coef, const int* transpose_flip,
+                                            void* const* wp, const sg_conv_shape* shapes, sg_dtype dt, sg_stream_t st) {
+  if (n < 0 || (n > 0 && (!w || !coef || !transpose_flip || !wp || !shapes))) return SG_EINVAL;
+  if (dt != SG_BF16 && dt != SG_F32) return SG_EINVAL;
+  for (int i = 0; i < n; ++i)
+    if (!conv_shape_ok(&shapes[i]) || !w[i] || !wp[i]) return SG_EINVAL;
+  for (int i0 = 0; i0 < n; i0 += SG_PACK_BATCH) {
+    const int m = n - i0 < SG_PACK_BATCH ? n - i0 : SG_PACK_BATCH;
+    PackBatchArgs b;
+    int64_t most = 0;
+    for (int j = 0; j < SG_PACK_BATCH; ++j) {
+      const int i = i0 + (j < m ? j : 0);         // (unused slots repeat the first item; their blocks are not launched)
+      const sg_conv_shape* s = &shapes[i];
+      PackArgs& a = b.item[j];
+      a.w = w[i]; a.wp = wp[i]; a.coef = coef[i];
+      a.kd = s->kd; a.kh = s->kh; a.kw = s->kw; a.taps = s->kd * s->kh * s->kw;
+      a.cin = s->cin; a.cout = s->cout; a.nchunk = conv_nchunk(s, dt); a.ntile = conv_ntile(s);
+      a.flip = transpose_flip[i] ? 1 : 0;
+      const int64_t total = (int64_t)a.nchunk * a.taps * a.ntile * 64 * (dt == SG_BF16 ? 8 : 4);
+      if (j < m && total > most) most = total;
+    }
+    int blocks = (int)((most + 255) / 256);
+    if (blocks > 256) blocks = 256;               // (grid-stride: m x 256 blocks fill the chip several times over)
+    if (blocks < 1) blocks = 1;
+    if (dt == SG_BF16)
+      hipLaunchKernelGGL(pack_weights_batch_kernel<bf16_t>, dim3((unsigned)blocks, (unsigned)m), dim3(256), 0, sg_st(st), b);
+    else
+      hipLaunchKernelGGL(pack_weights_batch_kernel<float>, dim3((unsigned)blocks, (unsigned)m), dim3(256), 0, sg_st(st), b);
+    SG_LAUNCH_CHECK();
+  }
+  for (int i = 0; i < n; ++i) {                   // the second images of the few layers that have one
+    const sg_conv_shape* s = &shapes[i];
+    char* tail = reinterpret_cast<char*>(wp[i]) + (size_t)conv_nchunk(s, dt) * (s->kd * s->kh * s->kw) * conv_ntile(s) * 1024;
+    int rc = SG_OK;
+    if (sg_fwd3p16_packed_bytes(s, dt)) rc = sg_fwd3p16_pack(w[i], coef[i], transpose_flip[i] ? 1 : 0, tail, sg_st(st));
+    else if (sg_small_tail_bytes(s)) rc = sg_small_pack(w[i], coef[i], transpose_flip[i] ? 1 : 0, tail, s, dt, sg_st(st));
+    if (rc != SG_OK) return rc;
+  }
   return SG_OK;
 }
 

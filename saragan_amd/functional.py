@@ -77,17 +77,64 @@ def _shape(n, d, h, w, cin, cout, k, ups=False):
 
 
 _PACK_CACHE = {}
+_PACK_STATE = {'stale': False}
+_NO_PACK_BATCH = bool(int(os.environ.get('SARAGAN_NO_PACK_BATCH', '0')))   # diagnostic: drop the images, one pack launch per layer and use
+PACK_STATS = {'single': 0, 'batches': 0, 'batched': 0}      # counters for the tests (host side only)
 
 
 def clear_pack_cache():
     """Packed-weight images are reused while the parameter is unchanged (same storage, same version counter): the
-    four discriminator passes and their gradients all read one image per orientation.  The optimiser step bumps
-    the version; Session.run also clears the cache so that buffers do not outlive a step."""
+    four discriminator passes and their gradients all read one image per orientation."""
     _PACK_CACHE.clear()
     _SUBPIX_CACHE.clear()
+    _PACK_STATE['stale'] = False
+
+
+def mark_packs_stale():
+    """The parameters were rewritten behind torch's version counters (the optimiser kernels; a graph capture, which records
+    launches without running them).  The fragment images stay where they are and are rewritten together, one launch for all
+    layers (sg_conv3d_pack_weights_batch), when the next convolution asks for one -- 44 pack launches per step at the
+    benchmarked configuration otherwise.  The few images of other kinds (sub-pixel forms, to_rgb matrices) are dropped and
+    rebuilt on use."""
+    if _NO_PACK_BATCH:
+        return clear_pack_cache()
+    for k in [k for k in _PACK_CACHE if k[0] == 'rgbmat']:
+        del _PACK_CACHE[k]
+    _SUBPIX_CACHE.clear()
+    _PACK_STATE['stale'] = bool(_PACK_CACHE)
+
+
+def live_packs():
+    """The cached images (tensors): a captured graph that reads them keeps them alive."""
+    return [v[0] for v in _PACK_CACHE.values()]
+
+
+def _refresh_packs(lib, st):
+    _PACK_STATE['stale'] = False
+    by_dt = {}
+    for key in list(_PACK_CACHE):
+        if key[0] == 'rgbmat':
+            continue
+        wp, w, shp, w32 = _PACK_CACHE[key]
+        if w._version != key[1] or w.data_ptr() != key[0]:      # modified through torch since: a new key is in use, this one is dead
+            del _PACK_CACHE[key]
+            continue
+        by_dt.setdefault(key[4], []).append((w32, key[2], 1 if key[3] else 0, wp, shp))
+    for dt, items in by_dt.items():
+        n = len(items)
+        ws = (C.c_void_p * n)(*[it[0].data_ptr() for it in items])
+        coefs = (C.c_float * n)(*[it[1] for it in items])
+        flips = (C.c_int * n)(*[it[2] for it in items])
+        wps = (C.c_void_p * n)(*[it[3].data_ptr() for it in items])
+        shapes = (ConvShape * n)(*[it[4] for it in items])
+        check(lib.sg_conv3d_pack_weights_batch(n, ws, coefs, flips, wps, shapes, dt, st), 'sg_conv3d_pack_weights_batch')
+        PACK_STATS['batches'] += 1
+        PACK_STATS['batched'] += n
 
 
 def _packed(w, coef, flip, shp, dt, lib, st):
+    if _PACK_STATE['stale']:
+        _refresh_packs(lib, st)
     key = (w.data_ptr(), w._version, float(coef), bool(flip), dt, shp.cin, shp.cout, shp.kd, shp.kh, shp.kw)
     hit = _PACK_CACHE.get(key)
     if hit is not None:
@@ -98,8 +145,12 @@ def _packed(w, coef, flip, shp, dt, lib, st):
     wp = torch.empty(lib.sg_conv3d_packed_bytes(C.byref(shp), dt), device=w.device, dtype=torch.uint8)
     check(lib.sg_conv3d_pack_weights(_ptr(w32), float(coef), 1 if flip else 0, _ptr(wp), C.byref(shp), dt, st),
           'sg_conv3d_pack_weights')
-    if w.is_leaf or not w.requires_grad:      # only cache long-lived tensors (parameters), not transient gradients
-        _PACK_CACHE[key] = (wp, w)   # holding w keeps its storage (and so the key) from being recycled
+    PACK_STATS['single'] += 1
+    # only long-lived tensors (parameters) are cached, not transient gradients -- and only f32 contiguous ones are refreshed
+    # in place (w32 aliases the parameter: the batch reads the values of the day)
+    if (w.is_leaf or not w.requires_grad) and w32.data_ptr() == w.data_ptr():
+        keep = ConvShape(shp.n, shp.d, shp.h, shp.w, shp.cin, shp.cout, shp.kd, shp.kh, shp.kw, shp.upsample_in)
+        _PACK_CACHE[key] = (wp, w, keep, w32)   # holding w keeps its storage (and so the key) from being recycled
     return wp
 
 
@@ -1585,8 +1636,7 @@ def adam_ema_(p, g, m, v, ema, lr, beta1, beta2, step, eps=1e-8, gscale=1.0, ema
     lib = _lib.load()
     _req_cuda(p, g, m, v, ema)
     if g is not None:
-        _PACK_CACHE.clear()   # the kernel rewrites parameters behind torch's version counters
-        _SUBPIX_CACHE.clear()
+        mark_packs_stale()   # the kernel rewrites parameters behind torch's version counters
     if lr_dev is not None and g is not None:
         check(lib.sg_adam_ema_dev(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(ema), p.numel(), lr_dev.ptr(), float(beta1),
                                   float(beta2), float(eps), float(gscale), float(ema_decay), _stream()), 'sg_adam_ema_dev')
@@ -1601,7 +1651,7 @@ def optim_step_(kind, p, g, s1, s2, ema, lr, h=0.0, eps=0.0, nesterov=False, gsc
     a DevCoef on the device, captured step)."""
     lib = _lib.load()
     _req_cuda(p, g, s1, s2, ema)
-    clear_pack_cache()      # the kernel rewrites parameters behind torch's version counters
+    mark_packs_stale()      # the kernel rewrites parameters behind torch's version counters
     if lr_dev is not None:
         check(lib.sg_optim_step_dev(int(kind), _ptr(p), _ptr(g), _ptr(s1), _ptr(s2), _ptr(ema), p.numel(), lr_dev.ptr(), float(h),
                                     float(eps), 1 if nesterov else 0, float(gscale), float(ema_decay), _stream()),

@@ -252,7 +252,6 @@ class StepGraph:
                 z = L._rng(dev).latent(n, c['latent_dim'], dev)
                 sample = c['generator'](z, alpha, c['phase'], c['base_shape'], activation=c['activation'],
                                         kernel_spec=c['kernel_spec'], filter_spec=c['filter_spec'], param=c['leakiness'])
-            F.clear_pack_cache()
             return [sample.detach() for _ in fetches]
         with use_store(self.store), torch.enable_grad():
             alpha = float(c['alpha'].eval()) if isinstance(c['alpha'], ScalarVariable) else float(c['alpha'])
@@ -280,7 +279,6 @@ class StepGraph:
                     self._finish(tid, self._backward(tid, out), out, apply=tid in want_train)
         static = out.pop('__static__', False)     # a replayed graph's outputs live in buffers the next replay overwrites
         self.last = None if static else out
-        F.clear_pack_cache()
 
         def own(v):       # what the caller gets is his to keep (the eager path returns fresh tensors each step)
             return v.clone() if static and torch.is_tensor(v) else v
@@ -452,7 +450,9 @@ class StepGraph:
             # No live autograd graph may own the parameters' AccumulateGrad nodes when the capture begins (see
             # assert_no_live_accumulate_grad): the last step's outputs are dropped first, then the invariant is CHECKED.
             self.last = None
-            F.clear_pack_cache()      # every weight image the step uses is packed INSIDE the graph, from the current weights
+            # every weight image the step uses is (re)written INSIDE the graph, from the weights of the day: the images of the
+            # eager warm-up steps stay where they are and the first convolution of the graph refreshes them all in one launch
+            F.mark_packs_stale()
             marks = []
             try:
                 self.assert_no_live_accumulate_grad([p for _, p in self.store.trainable('generator/')] +
@@ -477,8 +477,9 @@ class StepGraph:
                 raise
             finally:
                 L.set_random_source(base)
-                F.clear_pack_cache()
+                F.mark_packs_stale()      # (a capture records launches without running them)
             ent['rnd'].counting = False
+            ent['packs'] = F.live_packs()      # the graph reads (and refreshes) these images: they live as long as it does
             ent['marks'] = marks
             # replays need the captured launches and the output buffers, not the Python autograd graph: without it the
             # AccumulateGrad nodes made on the capturing stream go away too (a later eager step would find them on the
@@ -498,6 +499,7 @@ class StepGraph:
             if alpha_class == 'mix' or ent['opt']:
                 sc.flush()
         ent['graph'].replay()
+        F.mark_packs_stale()                   # (the graph's optimiser launches rewrote the parameters)
         ent['rnd'].after_replay()
         out = dict(ent['out'])
         out['__static__'] = True
@@ -600,7 +602,7 @@ class StepGraph:
             start = flat['param'][lo:hi].clone()
             tr['optimizer'].apply(info['prefix'], flat, ranges, gscale, None, 0.0)
             info['dist'].combine_deltas(flat['param'], start)
-            F.clear_pack_cache()
+            F.mark_packs_stale()
         elif apply:
             ema_flat = self.ema.shadow_flat(info['prefix']) if self.ema is not None else None
             ema_decay = self.ema.decay if self.ema is not None else 0.0

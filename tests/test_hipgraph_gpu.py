@@ -241,3 +241,35 @@ def test_gradients_written_straight_into_the_flat_buffer(golden_dir, dtype, monk
     # (left to a copy: layers on the pointwise kernels with two contributions -- from_rgb and the last dense layer, 1 channel wide)
     assert st['claimed'] > 0 and st['accumulated'] > 0 and st['adopted'] + st['copied'] == st['claimed'] and st['copied'] <= 2 * 4, st
     assert st0['claimed'] == 0 and st0['adopted'] == 0 and st0['accumulated'] == 0 and st0['copied'] == st['claimed'], (st, st0)
+
+
+@pytest.mark.parametrize('captured', [False, True])
+def test_weight_images_refreshed_in_one_launch_per_step(golden_dir, captured, monkeypatch):
+    """After an optimiser step every layer's packed weight image is stale at once: the images stay where they are and ONE
+    sg_conv3d_pack_weights_batch launch rewrites them when the next convolution asks for one (eager), or as the first node of the
+    captured step.  Same weights and losses, bit for bit, as with the images dropped and packed one by one on use
+    (SARAGAN_NO_PACK_BATCH=1, the round-3 behaviour)."""
+    import saragan_amd
+    from saragan_amd import functional as F
+    saragan_amd.set_deterministic(True)
+    try:
+        F.clear_pack_cache()
+        for k in F.PACK_STATS:
+            F.PACK_STATS[k] = 0
+        w1, l1, n1 = _run(golden_dir, 6, torch.bfloat16, captured=captured)
+        st = dict(F.PACK_STATS)
+        monkeypatch.setattr(F, '_NO_PACK_BATCH', True)
+        F.clear_pack_cache()
+        for k in F.PACK_STATS:
+            F.PACK_STATS[k] = 0
+        w0, l0, n0 = _run(golden_dir, 6, torch.bfloat16, captured=captured)
+        st0 = dict(F.PACK_STATS)
+    finally:
+        saragan_amd.set_deterministic(False)
+        F.clear_pack_cache()
+    print(st, st0)
+    assert l0 == l1 and n0 == n1 == (1 if captured else 0)
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k
+    assert st0['batches'] == 0 and st['batches'] >= (1 if captured else 5)
+    assert st['single'] < st0['single'] / 2

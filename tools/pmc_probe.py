@@ -33,6 +33,8 @@ CONVS = [  # n, (d,h,w), cin, cout (all 3x3x3): the >= 1 ms/step entries of `ben
     (64, (16, 64, 64), 64, 128),
     (64, (16, 64, 64), 128, 64),
     (64, (8, 32, 32), 128, 128),
+    (32, (4, 16, 16), 128, 128),       # round 4: the 16-wide level (conv_wgrad3l<w16>)
+    (32, (4, 16, 16), 128, 512),
 ]
 
 

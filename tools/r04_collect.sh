@@ -25,4 +25,11 @@ cd $R
 run 300 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
 run 200 python bench.py --dump-prof --steps 5 --warmup 3 --no-extras --no-cpu-baseline > /dev/null 2> $O/bench_conv_table.txt
 for c in 1 2 4 5; do run 200 python bench.py --config $c --steps 20 --warmup 5 --no-cpu-baseline > $O/bench_config$c.json 2> $O/bench_config$c.err; done
+# the reference's own operating point (out.txt: xs phase 5, 64x64x16) at local batch 2 / 4 / 8, and the headline network at 2 / 4
+: > $O/bench_reference_point.jsonl
+for b in 2 4 8; do run 200 python bench.py --config out_txt --batch $b --steps 30 --warmup 5 --no-cpu-baseline --no-extras 2> $O/bench_ref_b$b.err | grep '^{' >> $O/bench_reference_point.jsonl; done
+for b in 2 4; do run 200 python bench.py --batch $b --steps 20 --warmup 5 --no-cpu-baseline --no-extras 2> $O/bench_cfg3_b$b.err | grep '^{' >> $O/bench_reference_point.jsonl; done
+# three more default lines: the spread between launches on one box
+: > $O/bench_repeats.jsonl
+for i in 1 2 3; do run 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras 2>/dev/null | grep '^{' >> $O/bench_repeats.jsonl; done
 ls $O

@@ -96,6 +96,8 @@ def main():
     others = [last_json_line(os.path.join(SRC, f'bench_config{c}.json')) for c in (1, 2, 4, 5)
               if os.path.exists(os.path.join(SRC, f'bench_config{c}.json'))]
     open(os.path.join(DST, TAG + 'bench_other_configs.jsonl'), 'w').write('\n'.join(o for o in others if o) + '\n')
+    copy('bench_reference_point.jsonl', 'bench_reference_point.jsonl')
+    copy('bench_repeats.jsonl', 'bench_repeats.jsonl')
     log = os.path.join(SRC, 'pytest_gpu.log')
     if os.path.exists(log):
         open(os.path.join(DST, TAG + 'pytest_gpu_summary.txt'), 'w').write('\n'.join(open(log).read().splitlines()[-4:]) + '\n')

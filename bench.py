@@ -885,3 +885,6 @@ def main():
 
 if __name__ == '__main__':
     main()
+    _td = getattr(sys.modules.get('torch'), 'distributed', None)
+    if _td is not None and _td.is_available() and _td.is_initialized():      # (normal completion only: every rank gets here)
+        _td.destroy_process_group()

@@ -105,8 +105,9 @@ def mark_packs_stale():
 
 
 def live_packs():
-    """The cached images (tensors): a captured graph that reads them keeps them alive."""
-    return [v[0] for v in _PACK_CACHE.values()]
+    """The cached images and the kept filter-gradient workspaces (tensors): a captured graph whose launches carry their
+    addresses keeps them alive -- the caches themselves are released when the next step graph is built."""
+    return [v[0] for v in _PACK_CACHE.values()] + list(_CLEAN_WS.values())
 
 
 def _refresh_packs(lib, st):
@@ -290,6 +291,12 @@ def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel
 _CLEAN_WS = {}            # (device, workspace bytes) -> kept workspace, zero between calls (SG_WGRAD_CLEAN_WORKSPACE)
 _CLEAN_WS_DECLINED = set()   # shapes whose kernels do not leave the workspace clean (pointwise / small-channel paths)
 _NO_CLEAN_WS = bool(int(os.environ.get('SARAGAN_NO_CLEAN_WS', '0')))   # diagnostic: a fresh workspace + memset per weight gradient
+
+
+def clear_kept_workspaces():
+    """Releases the kept filter-gradient workspaces (a new phase has other layer shapes)."""
+    _CLEAN_WS.clear()
+    _CLEAN_WS_DECLINED.clear()
 
 
 def _wgrad_launch(lib, x, dy, mask, mask_slope, gain, dw, db, coef, accumulate, shp, dt):

@@ -625,6 +625,10 @@ def optimize_step(optimizer_gen, optimizer_disc, generator, discriminator, real_
     if loss_fn not in ('wgan', 'logistic'):
         raise ValueError(f"Unknown loss function: {loss_fn}")
     store = current_store()
+    # a new step graph (a new phase of the progressive run): the packed images and kept workspaces of the previous one are released
+    # (the image cache holds its parameters; within a phase the images stay in place and are refreshed together, functional.py)
+    F.clear_pack_cache()
+    F.clear_kept_workspaces()
     # the architecture's own variable plan (networks/<arch>/variables.py), found from the generator's module the way
     # the reference finds the networks themselves (optuna_objective.py:64-65)
     arch_pkg = getattr(generator, '__module__', '').rsplit('.', 1)[0]

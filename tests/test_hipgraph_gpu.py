@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 NAME = 'oracle_step_p3_wgan_a000.npz'
 
 
-def _run(golden_dir, steps, dtype, captured, mixing=False, clipping=False, keep=False):
+def _run(golden_dir, steps, dtype, captured, mixing=False, clipping=False, keep=False, reload_at=None):
     import saragan_amd.optimization as opt
     from saragan_amd.ExtendedEMA import ExtendedEMA
     from saragan_amd.networks import loss as L
@@ -59,6 +59,8 @@ def _run(golden_dir, steps, dtype, captured, mixing=False, clipping=False, keep=
             g_lr.assign(1e-3 * (1.0 + 0.1 * i))       # a schedule: the step size moves every step
             d_lr.assign(1e-3 * (1.0 - 0.05 * i))
             real = (fx['real'].float() + 0.1 * torch.randn(fx['real'].shape, generator=g)).cuda()
+            if i == reload_at:      # the weights change under the graph (a checkpoint restored mid-run): torch copies, new versions
+                store.load_state_dict({k: v * 0.5 for k, v in fx['p0'].items()}, strict=True)
             res = sess.run(fetch, feed_dict={ph: real})
             gl, dl = res[2], res[3]
             sess.run(ema_op)
@@ -273,3 +275,20 @@ def test_weight_images_refreshed_in_one_launch_per_step(golden_dir, captured, mo
         assert torch.equal(w0[k], w1[k]), k
     assert st0['batches'] == 0 and st['batches'] >= (1 if captured else 5)
     assert st['single'] < st0['single'] / 2
+
+
+def test_weights_restored_between_replays_are_seen_by_the_captured_step(golden_dir):
+    """The captured step rewrites its packed weight images from the weights of the day as its first node: weights that are
+    replaced between two replays (load_state_dict: a checkpoint restored mid-run) are what the next replay computes with --
+    bit-identical to the eager run that does the same."""
+    import saragan_amd
+    saragan_amd.set_deterministic(True)
+    try:
+        w0, l0, n0 = _run(golden_dir, 7, torch.bfloat16, captured=False, reload_at=4)
+        w1, l1, n1 = _run(golden_dir, 7, torch.bfloat16, captured=True, reload_at=4)
+    finally:
+        saragan_amd.set_deterministic(False)
+    assert n0 == 0 and n1 == 1
+    assert l0 == l1
+    for k in w0:
+        assert torch.equal(w0[k], w1[k]), k

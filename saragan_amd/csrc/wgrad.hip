@@ -11,6 +11,7 @@
 #include "common.h"
 #include "prof.h"
 #include <stdlib.h>
+#include <type_traits>
 
 struct WgradArgs {
   const void* x;
@@ -1089,10 +1090,89 @@ struct sg_wgrad_tile_lean {
   }
 };
 
-template <bool UPS, bool DYM = false, int TW = 32>   // UPS: x is the half-resolution tensor, gathered nearest-x2 (upscale3d fused into
+// The same tile on v_mfma_f32_16x16x32_bf16 (the board sustains a higher clock on this shape: DESIGN.md section 5).  A K step is
+// 32 voxels -- a whole 32-wide row, or two 16-wide rows --: operand rows 16 channels, lane l holds channel l & 15 at voxels
+// 8 (l >> 4) .. + 7 of the step (two transposing reads of 4 voxels each; a 32-lane half reads blocks 8 rows apart in the same
+// columns: conflict-free).  Per step and tap: the two 16-channel halves of x (4 reads) against the two halves of dy (4 reads,
+// shared by the wave's 7 taps): 4 MFMAs into the tap's four 16 x 16 accumulator tiles [ci half][co half] -- the same LDS
+// bytes and accumulator registers per FLOP as the 32x32x16 form.
+template <int PF, int TW = 32>
+struct sg_wgrad_tile_lean16 {
+  static constexpr int MAXT = 7, TH = 128 / TW, HW = TW + 2, RPS = 32 / TW;      // RPS: tile rows per K step
+  // instruction slots of a K step: the two halves of dy, then (tap, ci half) -- two reads and (tap slots) two MFMAs of 16 cycles
+  // each: the rhythm of the 32x32x16 loop (two reads per 32-cycle MFMA), so the same prefetch depth fits lgkmcnt's 4 bits
+  static constexpr int NKS = 8, IPS = 2 + 2 * MAXT, NI = NKS * IPS, RING = PF + 1;
+  static_assert(PF * 2 + 2 <= 15, "lgkmcnt is a 4-bit counter");
+  typedef s16x4 frag_t;
+  struct Ctx {
+    int xb[2][MAXT];   // per (td, tap slot): lane part + ring slot + tap shift
+    int yb;            // lane part of the dy image
+    int ones_last;
+  };
+  struct HF { frag_t p[2]; };       // one 16-channel half of an operand: voxels 0-3 and 4-7 of the lane's eight
+  template <int I>
+  static __device__ __forceinline__ void load(const Ctx& c, HF (&a)[RING], HF (&b)[2][2]) {
+    constexpr int ks = I / IPS, r = I % IPS, td = ks / (NKS / 2), th = (ks % (NKS / 2)) * RPS;
+    if constexpr (r < 2) {
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b[ks & 1][r].p[0]) : "v"(c.yb), "n"(ks * 2048 + r * 32));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(b[ks & 1][r].p[1]) : "v"(c.yb), "n"(ks * 2048 + r * 32 + 256));
+    } else {
+      constexpr int t = r - 2, j = t / 2, h = t % 2, SL = (ks * 2 * MAXT + t) % RING;
+      constexpr int off = th * HW * 64 + h * 32;
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a[SL].p[0]) : "v"(c.xb[td][j]), "n"(off));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a[SL].p[1]) : "v"(c.xb[td][j]), "n"(off + 256));
+    }
+  }
+  static __device__ __forceinline__ u32x4 cat(const HF& f) {
+    u32x4 o;
+    o[0] = __builtin_bit_cast(u32x2, f.p[0])[0]; o[1] = __builtin_bit_cast(u32x2, f.p[0])[1];
+    o[2] = __builtin_bit_cast(u32x2, f.p[1])[0]; o[3] = __builtin_bit_cast(u32x2, f.p[1])[1];
+    return o;
+  }
+  template <int I>
+  static __device__ __forceinline__ void step(const Ctx& c, f32x4 (&acc)[MAXT][4], HF (&a)[RING], HF (&b)[2][2]) {
+    if constexpr (I < NI) {
+      if constexpr (I + PF < NI) load<I + PF>(c, a, b);
+      constexpr int ks = I / IPS, r = I % IPS;
+      if constexpr (r >= 2) {
+        constexpr int younger = (NI - 1 - I < PF ? NI - 1 - I : PF) * 2;
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger));
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int t = r - 2, j = t / 2, h = t % 2, SL = (ks * 2 * MAXT + t) % RING;
+        u32x4 af = cat(a[SL]);
+        if constexpr (j == MAXT - 1) {
+          if (c.ones_last) af = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};   // bf16 1.0 x 8
+        }
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb)
+          acc[j][h * 2 + hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, cat(b[ks & 1][hb])),
+                                                                       acc[j][h * 2 + hb], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      step<I + 1>(c, acc, a, b);
+    }
+  }
+  template <int I>
+  static __device__ __forceinline__ void prologue(const Ctx& c, HF (&a)[RING], HF (&b)[2][2]) {
+    if constexpr (I < PF && I < NI) {
+      load<I>(c, a, b);
+      prologue<I + 1>(c, a, b);
+    }
+  }
+  static __device__ __forceinline__ void run(const Ctx& c, f32x4 (&acc)[MAXT][4]) {
+    HF a[RING], b[2][2];
+    SG_KLOOP_BEGIN();
+    prologue<0>(c, a, b);
+    step<0>(c, acc, a, b);
+    SG_KLOOP_END();
+  }
+};
+
+template <bool UPS, bool DYM = false, int TW = 32, bool M16 = false>   // UPS: x is the half-resolution tensor, gathered nearest-x2 (upscale3d fused into
                                         // the layer); DYM: dy is the half-resolution gradient of a pooled layer, gathered
                                         // nearest-x2, scaled and LeakyReLU-masked while it is staged; TW = 16: the 16-wide levels
-                                        // (4 x 16 x 16) in tiles of 2 x 8 x 16 voxels, halo planes of 10 x 18 rows
+                                        // (4 x 16 x 16) in tiles of 2 x 8 x 16 voxels, halo planes of 10 x 18 rows; M16: the
+                                        // K loop on v_mfma_f32_16x16x32_bf16 (sg_wgrad_tile_lean16)
 __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
   static_assert(!(UPS && DYM), "one gathered operand at a time");
   static_assert(TW == 32 || TW == 16, "tile width");
@@ -1124,9 +1204,12 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
 
   const int i16 = lane & 15, q16 = lane >> 4;
   const int qd = i16 >> 2, pp = i16 & 3;
-  const int colb = (16 * (q16 & 1) + 4 * pp) * 2;
-  const int kb = 8 * (q16 >> 1) + qd;
-  const int xl0 = xmine + kb * 64 + colb, yl0 = ymine + kb * 64 + colb;
+  // 32x32x16: lane group g reads voxels 8 (g >> 1) .. + 3 of channels 16 (g & 1) ..; 16x16x32: voxels 8 g .. + 3 of the K step's 32
+  // (its second 16 voxels are the next tile row for 16-wide tiles), the channel half is an instruction offset
+  const int colb = M16 ? 4 * pp * 2 : (16 * (q16 & 1) + 4 * pp) * 2;
+  const int kb = M16 ? 8 * (q16 & 1) + qd : 8 * (q16 >> 1) + qd;
+  const int xl0 = xmine + kb * 64 + colb + (M16 ? (q16 >> 1) * (TW == 32 ? 1024 : HW * 64) : 0);
+  const int yl0 = ymine + kb * 64 + colb + (M16 ? (q16 >> 1) * 1024 : 0);
 
   // plane-local staging tables: this lane's 16-byte pieces of 1-KiB blocks wave, wave+4, ... of a halo plane / the dy tile
   constexpr int MAXP = 4, MAXY = 4;
@@ -1259,11 +1342,15 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
   }
   // bias gradient: wave 3's last slot is spare (27 = 4*7 - 1 taps); it multiplies dy by ones
   const int ones_last = (a.dbias != nullptr && ci_t == 0 && wave == 3) ? 1 : 0;
-  f32x16 acc[MAXT];
+  // 16 accumulator registers per tap: one 32 x 32 tile, or four 16 x 16 tiles [ci half * 2 + co half]
+  typename std::conditional<M16, f32x4[MAXT][4], f32x16[MAXT]>::type acc;
 #pragma unroll
   for (int j = 0; j < MAXT; ++j)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    for (int i = 0; i < 16; ++i) {
+      if constexpr (M16) acc[j][i >> 2][i & 3] = 0.f;
+      else acc[j][i] = 0.f;
+    }
 
   int dbgi = 0;
   auto stamp = [&]() {
@@ -1271,7 +1358,7 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
       a.dbg[grp * 128 + dbgi] = __builtin_amdgcn_s_memtime();
     ++dbgi;
   };
-  typedef sg_wgrad_tile_lean<5, TW> KT;
+  typedef typename std::conditional<M16, sg_wgrad_tile_lean16<5, TW>, sg_wgrad_tile_lean<5, TW>>::type KT;
   auto mfma_phase = [&](int q) {
     const int dq = q % nTd;
     const int pbase = 2 * dq - 1 + 8;                             // plane of halo index 0 (kept non-negative)
@@ -1328,8 +1415,10 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < MAXT; ++j)
 #pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4)
-          *reinterpret_cast<f32x4*>(cbuf + ((j * 4 + i4) << 10)) = f32x4{acc[j][4 * i4], acc[j][4 * i4 + 1], acc[j][4 * i4 + 2], acc[j][4 * i4 + 3]};
+        for (int i4 = 0; i4 < 4; ++i4) {
+          if constexpr (M16) *reinterpret_cast<f32x4*>(cbuf + ((j * 4 + i4) << 10)) = acc[j][i4];
+          else *reinterpret_cast<f32x4*>(cbuf + ((j * 4 + i4) << 10)) = f32x4{acc[j][4 * i4], acc[j][4 * i4 + 1], acc[j][4 * i4 + 2], acc[j][4 * i4 + 3]};
+        }
     }
     __syncthreads();
     if (grp == 1) return;
@@ -1339,21 +1428,47 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
       for (int i4 = 0; i4 < 4; ++i4) {
         const f32x4 o = *reinterpret_cast<const f32x4*>(cbuf + ((j * 4 + i4) << 10));
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[j][4 * i4 + e] += o[e];
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (M16) acc[j][i4][e] += o[e];
+          else acc[j][4 * i4 + e] += o[e];
+        }
       }
   }
-  const int r = lane & 31, hh = lane >> 5;
-  if (ones_last && (items_mine > 0 || a.slab != 0) && hh == 0 && co_t * 32 + r < cout)   // row 0 of the ones product = column sums
-    sg_wg_out(a.dbias + (int64_t)blockIdx.x * a.bslab + co_t * 32 + r, acc[MAXT - 1][0], a.slab != 0);
+  if constexpr (M16) {
+    // D tile [ci half][co half]: lane l holds ci = 16 ha + 4 (l >> 4) + e, co = 16 hb + (l & 15)
+    const int c16 = lane & 15, q4 = lane >> 4;
+    if (ones_last && (items_mine > 0 || a.slab != 0) && q4 == 0) {      // row 0 of the ones product = column sums
 #pragma unroll
-  for (int j = 0; j < MAXT; ++j) {
-    const int tap = wave + 4 * j;
-    if (tap < TAPS && (items_mine > 0 || a.slab != 0)) {
-      float* dst = a.dwt + (int64_t)blockIdx.x * a.slab + ((((int64_t)tap * a.ciT + ci_t) * a.coT + co_t) << 10);
+      for (int hb = 0; hb < 2; ++hb)
+        if (co_t * 32 + 16 * hb + c16 < cout)
+          sg_wg_out(a.dbias + (int64_t)blockIdx.x * a.bslab + co_t * 32 + 16 * hb + c16, acc[MAXT - 1][hb][0], a.slab != 0);
+    }
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
-        sg_wg_out(dst + row * 32 + r, acc[j][i], a.slab != 0);
+    for (int j = 0; j < MAXT; ++j) {
+      const int tap = wave + 4 * j;
+      if (tap < TAPS && (items_mine > 0 || a.slab != 0)) {
+        float* dst = a.dwt + (int64_t)blockIdx.x * a.slab + ((((int64_t)tap * a.ciT + ci_t) * a.coT + co_t) << 10);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            sg_wg_out(dst + (16 * (t >> 1) + 4 * q4 + e) * 32 + 16 * (t & 1) + c16, acc[j][t][e], a.slab != 0);
+      }
+    }
+  } else {
+    const int r = lane & 31, hh = lane >> 5;
+    if (ones_last && (items_mine > 0 || a.slab != 0) && hh == 0 && co_t * 32 + r < cout)   // row 0 of the ones product = column sums
+      sg_wg_out(a.dbias + (int64_t)blockIdx.x * a.bslab + co_t * 32 + r, acc[MAXT - 1][0], a.slab != 0);
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      const int tap = wave + 4 * j;
+      if (tap < TAPS && (items_mine > 0 || a.slab != 0)) {
+        float* dst = a.dwt + (int64_t)blockIdx.x * a.slab + ((((int64_t)tap * a.ciT + ci_t) * a.coT + co_t) << 10);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = (i & 3) + 8 * (i >> 2) + 4 * hh;
+          sg_wg_out(dst + row * 32 + r, acc[j][i], a.slab != 0);
+        }
       }
     }
   }
@@ -1398,35 +1513,33 @@ static int launch_wgrad3(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   const bool lean16 = w16 && g.HH == 10 && g.HW == 18 && g.HD == 4 && (!g.ups || ((s->d | s->h | s->w) & 1) == 0);
   if (w16 && !lean16) return SG_OK;
   if (lean16 || lean) a.nslab = gx;                   // (the lean kernels add their two groups' sums before they leave the block)
+  const bool m16 = sg_cfg().wgrad3l_16 != 0;      // the K loop on v_mfma_f32_16x16x32_bf16
+#define SG_LAUNCH_WGRAD3L(UPS_, DYM_, TW_, NAME_)                                                                     \
+  do {                                                                                                               \
+    if (m16) {                                                                                                       \
+      auto kern = conv_wgrad3l_kernel<UPS_, DYM_, TW_, true>;                                                        \
+      SG_ALLOW_160K_LDS(kern);                                                                                       \
+      SG_KNAME(NAME_);                                                                                               \
+      hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);                          \
+    } else {                                                                                                         \
+      auto kern = conv_wgrad3l_kernel<UPS_, DYM_, TW_, false>;                                                       \
+      SG_ALLOW_160K_LDS(kern);                                                                                       \
+      SG_KNAME(NAME_);                                                                                               \
+      hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);                          \
+    }                                                                                                                \
+  } while (0)
   if (lean16) {        // (halo plane slots of 208 rows like the 32-wide kernel's)
     lds = 2ull * (4 * 208 * 64 + 256 * 64);
-    if (g.ups) {
-      auto kern = conv_wgrad3l_kernel<true, false, 16>;
-      SG_ALLOW_160K_LDS(kern);
-      SG_KNAME("conv_wgrad3l<ups,w16>");
-      hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);
-    } else {
-      auto kern = conv_wgrad3l_kernel<false, false, 16>;
-      SG_ALLOW_160K_LDS(kern);
-      SG_KNAME("conv_wgrad3l<w16>");
-      hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);
-    }
+    if (g.ups) SG_LAUNCH_WGRAD3L(true, false, 16, "conv_wgrad3l<ups,w16>");
+    else SG_LAUNCH_WGRAD3L(false, false, 16, "conv_wgrad3l<w16>");
   } else if (a.dy_mask) {     // half-resolution dy, gathered and masked while staged: the lean kernel only
     if (!lean || g.ups || ((s->d | s->h | s->w) & 1)) return SG_OK;
-    auto kern = conv_wgrad3l_kernel<false, true>;
-    SG_ALLOW_160K_LDS(kern);
-    SG_KNAME("conv_wgrad3l<dy gather>");
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);
+    SG_LAUNCH_WGRAD3L(false, true, 32, "conv_wgrad3l<dy gather>");
   } else if (lean && g.ups) {
-    auto kern = conv_wgrad3l_kernel<true>;
-    SG_ALLOW_160K_LDS(kern);
-    SG_KNAME("conv_wgrad3l<ups>");
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);
+    SG_LAUNCH_WGRAD3L(true, false, 32, "conv_wgrad3l<ups>");
   } else if (lean) {
-    auto kern = conv_wgrad3l_kernel<false>;
-    SG_ALLOW_160K_LDS(kern);
-    SG_KNAME("conv_wgrad3l");
-    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)pairs), dim3(512), lds, st, a);
+    SG_LAUNCH_WGRAD3L(false, false, 32, "conv_wgrad3l");
+#undef SG_LAUNCH_WGRAD3L
   } else {
     auto kern = conv_wgrad3_kernel<KD, KH, KW>;
     SG_ALLOW_160K_LDS(kern);

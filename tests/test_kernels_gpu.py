@@ -1508,3 +1508,25 @@ def test_kept_wgrad_workspace_is_shared_by_layers_of_any_channel_count(monkeypat
         scale = float(dw0.abs().max())
         np.testing.assert_allclose(dw.cpu().numpy(), dw0.cpu().numpy(), rtol=1e-5, atol=1e-5 * scale)
         np.testing.assert_allclose(db.cpu().numpy(), db0.cpu().numpy(), rtol=1e-5, atol=1e-5 * float(db0.abs().max()))
+
+
+@pytest.mark.parametrize('case', [(2, 32, 32, (6, 128, 256), False), (2, 40, 72, (5, 126, 256), False), (8, 128, 128, (4, 16, 16), False),
+                                  (8, 256, 64, (4, 16, 16), True)],
+                         ids=['32to32', 'ragged', 'w16', 'w16ups'])
+def test_wgrad_sliding_halo_kernel_on_the_16x16x32_mfma(case, sg_env, monkeypatch):
+    """SG_WGRAD3L_16=1: conv_wgrad3l's K loop on v_mfma_f32_16x16x32_bf16 (K step = 32 voxels, four 16 x 16 accumulator tiles per tap).
+    A diagnostic variant (measured slower inside the step than the 32x32x16 form: DESIGN_NOTES section 8) that must stay correct: the same
+    sums up to f32 rounding (the tiles are added in another order)."""
+    from saragan_amd import functional as F
+    n, cin, cout, sp, ups = case
+    dtype = torch.bfloat16
+    xs = tuple(v // 2 for v in sp) if ups else sp
+    x = cl(rnd((n, cin, *xs), 701, dtype), dtype)
+    gy = cl(rnd((n, cout, *sp), 702, dtype), dtype)
+    monkeypatch.setattr(F, '_NO_SUBPIXEL', True)
+    dw0, db0 = F.raw_wgrad(x, gy, (3, 3, 3), 0.05, ups=ups, want_db=True)
+    sg_env(SG_WGRAD3L_16=1)
+    dw1, db1 = F.raw_wgrad(x, gy, (3, 3, 3), 0.05, ups=ups, want_db=True)
+    np.testing.assert_allclose(dw1.cpu().numpy(), dw0.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(dw0.abs().max()))
+    np.testing.assert_allclose(db1.cpu().numpy(), db0.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(db0.abs().max()))
+    assert not torch.equal(dw0, torch.zeros_like(dw0))

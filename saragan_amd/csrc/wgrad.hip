@@ -1029,9 +1029,8 @@ struct sg_wgrad_tile_lean {
   static constexpr int IPS = 1 + MAXT, NI = 16 * IPS, RING = PF + 1;
   typedef s16x4 frag_t;
   struct Ctx {
-    int xb[2][MAXT];   // per (td, tap slot): lane part + ring slot + tap shift
+    int xb[2][MAXT];   // per (td, tap slot): lane part + ring slot + tap shift (the bias slot: the block's image of bf16 ones)
     int yb;            // lane part of the dy image
-    int ones_last;
   };
   template <int I>
   static __device__ __forceinline__ void load(const Ctx& c, frag_t (&a0)[RING], frag_t (&a1)[RING], frag_t (&b0)[2],
@@ -1061,9 +1060,6 @@ struct sg_wgrad_tile_lean {
         u32x4 af, bf;
         af[0] = __builtin_bit_cast(u32x2, a0[SL])[0]; af[1] = __builtin_bit_cast(u32x2, a0[SL])[1];
         af[2] = __builtin_bit_cast(u32x2, a1[SL])[0]; af[3] = __builtin_bit_cast(u32x2, a1[SL])[1];
-        if constexpr (j == MAXT - 1) {
-          if (c.ones_last) af = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};   // bf16 1.0 x 8
-        }
         bf[0] = __builtin_bit_cast(u32x2, b0[ks & 1])[0]; bf[1] = __builtin_bit_cast(u32x2, b0[ks & 1])[1];
         bf[2] = __builtin_bit_cast(u32x2, b1[ks & 1])[0]; bf[3] = __builtin_bit_cast(u32x2, b1[ks & 1])[1];
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf),
@@ -1105,9 +1101,8 @@ struct sg_wgrad_tile_lean16 {
   static_assert(PF * 2 + 2 <= 15, "lgkmcnt is a 4-bit counter");
   typedef s16x4 frag_t;
   struct Ctx {
-    int xb[2][MAXT];   // per (td, tap slot): lane part + ring slot + tap shift
+    int xb[2][MAXT];   // per (td, tap slot): lane part + ring slot + tap shift (the bias slot: the block's image of bf16 ones)
     int yb;            // lane part of the dy image
-    int ones_last;
   };
   struct HF { frag_t p[2]; };       // one 16-channel half of an operand: voxels 0-3 and 4-7 of the lane's eight
   template <int I>
@@ -1139,10 +1134,7 @@ struct sg_wgrad_tile_lean16 {
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger));
         __builtin_amdgcn_sched_barrier(0);
         constexpr int t = r - 2, j = t / 2, h = t % 2, SL = (ks * 2 * MAXT + t) % RING;
-        u32x4 af = cat(a[SL]);
-        if constexpr (j == MAXT - 1) {
-          if (c.ones_last) af = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};   // bf16 1.0 x 8
-        }
+        const u32x4 af = cat(a[SL]);
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb)
           acc[j][h * 2 + hb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, cat(b[ks & 1][hb])),
@@ -1181,6 +1173,13 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
   constexpr int TH = 128 / TW, HH = TH + 2, HW = TW + 2, PB = 208 * 64, XB = 4 * PB, YB = 256 * 64, BUF = XB + YB;
   static_assert(HH * HW <= 208, "halo plane slot");
   constexpr int XPIECES = (HH * HW + 15) / 16;       // 13 (12) 1-KiB pieces per halo plane
+  // An image of bf16 ones behind the staging buffers: the bias gradient's tap slot (wave 3's spare one) reads its "x" operand there,
+  // with the offsets of a real tap -- a select per operand register in the K loop (64 v_cndmask per tile and wave, in a loop
+  // that is short of issue slots) cost more than these 12 KiB.
+  constexpr int ONES_OFF = 2 * BUF, ONES_BYTES = 12288;
+  static_assert((TH - 1) * HW * 64 + 2304 + 1024 + 12 * 64 + 64 <= ONES_BYTES, "ones image covers every fragment offset");
+  for (int i = threadIdx.x * 16; i < ONES_BYTES; i += 512 * 16)
+    *reinterpret_cast<u32x4*>(smem + ONES_OFF + i) = u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};
   constexpr uint32_t DEAD = 0x80000000u;             // byte offset beyond every buffer: the DMA writes zeros
   const sg_tile_geom& g = a.g;                       // TN=1, TD=2, TH x TW = 4 x 32 | 8 x 16, HD=4, HH=TH+2, HW=TW+2 (host-checked)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1364,11 +1363,11 @@ __global__ __launch_bounds__(512) void conv_wgrad3l_kernel(WgradArgs a) {
     const int pbase = 2 * dq - 1 + 8;                             // plane of halo index 0 (kept non-negative)
     typename KT::Ctx c;
     c.yb = yl0;
-    c.ones_last = ones_last;
 #pragma unroll
     for (int td = 0; td < 2; ++td)
 #pragma unroll
       for (int j = 0; j < MAXT; ++j) c.xb[td][j] = xl0 + ((pbase + td + tap_kd[j]) & 3) * PB + tap_hw[j];
+    if (ones_last) c.xb[0][MAXT - 1] = c.xb[1][MAXT - 1] = ONES_OFF + (xl0 - xmine);
     KT::run(c, acc);
   };
   const bool stage_first_only = (a.dbg_flags & 1) != 0;
@@ -1513,6 +1512,7 @@ static int launch_wgrad3(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   const bool lean16 = w16 && g.HH == 10 && g.HW == 18 && g.HD == 4 && (!g.ups || ((s->d | s->h | s->w) & 1) == 0);
   if (w16 && !lean16) return SG_OK;
   if (lean16 || lean) a.nslab = gx;                   // (the lean kernels add their two groups' sums before they leave the block)
+  if (lean) lds += 12288;                             // (+ the lean kernels' image of ones, behind the staging buffers)
   const bool m16 = sg_cfg().wgrad3l_16 != 0;      // the K loop on v_mfma_f32_16x16x32_bf16
 #define SG_LAUNCH_WGRAD3L(UPS_, DYM_, TW_, NAME_)                                                                     \
   do {                                                                                                               \
@@ -1529,7 +1529,7 @@ static int launch_wgrad3(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
     }                                                                                                                \
   } while (0)
   if (lean16) {        // (halo plane slots of 208 rows like the 32-wide kernel's)
-    lds = 2ull * (4 * 208 * 64 + 256 * 64);
+    lds = 2ull * (4 * 208 * 64 + 256 * 64) + 12288;   // (+ the image of ones)
     if (g.ups) SG_LAUNCH_WGRAD3L(true, false, 16, "conv_wgrad3l<ups,w16>");
     else SG_LAUNCH_WGRAD3L(false, false, 16, "conv_wgrad3l<w16>");
   } else if (a.dy_mask) {     // half-resolution dy, gathered and masked while staged: the lean kernel only

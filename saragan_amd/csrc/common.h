@@ -143,6 +143,11 @@ __device__ __forceinline__ void sg_mfma_drain(f32x16 (&acc)[N]) {
 // compiler inside the loop.  SG_KLOOP_BEGIN drains the counter first; the assembler comments delimit the region for
 // tests/test_build_resources.py, which disassembles the build and fails on any compiler-emitted LGKM instruction between
 // them and on any instruction of the compiler's that touches an accumulator of the tied MFMAs before the drain.
+// s_waitcnt lgkmcnt(N) as an instruction the compiler SEES (vmcnt / expcnt fields at their maxima: not waited for).  Between two
+// inline-asm statements that touch the same registers -- an in-place MFMA and the next one on that accumulator -- hipcc pads one
+// wait state (`s_nop 0`) unless an instruction of its own stands between them; an inline-asm s_waitcnt does not count, this one
+// does: 0.54 s_nop per MFMA left the sliding-halo loops (an s_nop costs a 4-cycle issue slot in a loop that has 8 per MFMA).
+#define SG_WAIT_LGKM(N) __builtin_amdgcn_s_waitcnt(0xC07F | ((N) << 8))
 #define SG_KLOOP_BEGIN() asm volatile("; SG_KLOOP_BEGIN\n\ts_waitcnt lgkmcnt(0)")
 #define SG_KLOOP_END() asm volatile("; SG_KLOOP_END")
 template <>

@@ -1134,7 +1134,7 @@ struct sg_unrolled_ks2 {
                                               const int (&xa)[9][GC], int wl_off) {
     if constexpr (ST < NS) {
       if constexpr (ST + PF < NS) load<ST + PF>(wfr, xfr, xa, wl_off);
-      asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(younger(ST)));
+      SG_WAIT_LGKM(younger(ST));
       __builtin_amdgcn_sched_barrier(0);
       constexpr int pl = ST & 3;
       if constexpr (pl <= 2) sg_mfma_bf16_acc(acc[0], wfr[ST % RING], xfr[ST % RING]);

@@ -254,3 +254,83 @@ def test_pinned_prefetcher_host_path(tmp_path):
         for _ in range(6):
             bad.next()
     bad.close()
+
+
+def test_gradient_destination_registry():
+    """functional.grads_into (host logic only): a parameter's slot of the flat gradient buffer is handed out ONCE per backward, as a
+    fresh alias; later contributions find it through _grad_acc; a declined launch gives it back; nothing is handed out while a graph of
+    the backward is being recorded."""
+    import torch
+    from saragan_amd import functional as F
+    flat = torch.zeros(64)
+    w = torch.nn.Parameter(torch.ones(2, 3))
+    b = torch.nn.Parameter(torch.ones(3))
+    slots = {w.data_ptr(): flat[8:14].view(2, 3), b.data_ptr(): flat[16:19]}
+    assert F._grad_out(w.data_ptr(), (2, 3)) is None                      # no backward in flight
+    with F.grads_into(slots):
+        with torch.enable_grad():
+            assert F._grad_out(w.data_ptr(), (2, 3)) is None              # create_graph: gradients are graph nodes, not slots
+        with torch.no_grad():
+            assert F._grad_acc(w.data_ptr(), (2, 3)) is None              # nothing written yet
+            a = F._grad_out(w.data_ptr(), (1, 1, 1, 2, 3))
+            assert a is not None and a.data_ptr() == flat[8:14].data_ptr() and a is not slots[w.data_ptr()]
+            assert F._grad_out(w.data_ptr(), (2, 3)) is None              # once
+            acc = F._grad_acc(w.data_ptr(), (2, 3))
+            assert acc is not None and acc.data_ptr() == a.data_ptr()
+            assert F._grad_out(w.data_ptr() + 4, (2, 3)) is None          # not a registered parameter
+            assert F._grad_out(b.data_ptr(), (4,)) is None                # wrong size: not this parameter's gradient
+            other = torch.empty(2, 3)
+            F._unclaim(w.data_ptr(), other)                               # somebody else's tensor: the claim stands
+            assert F._grad_acc(w.data_ptr(), (2, 3)) is not None
+            F._unclaim(w.data_ptr(), a)                                   # the launch that was to write `a` declined
+            assert F._grad_acc(w.data_ptr(), (2, 3)) is None and F._grad_out(w.data_ptr(), (2, 3)) is not None
+            fresh = F._f32_out(b.data_ptr(), (3,), torch.device('cpu'))
+            assert fresh.data_ptr() == flat[16:19].data_ptr()
+            again = F._f32_out(b.data_ptr(), (3,), torch.device('cpu'))
+            assert again.data_ptr() != fresh.data_ptr()                   # a second contribution gets a tensor of its own
+    assert not F._GRAD_DEST
+
+
+def test_autograd_adopts_a_slot_alias_as_grad():
+    """The contract grads_into relies on (torch 2.x AccumulateGrad): an unset .grad adopts, without a copy, a dense gradient tensor
+    nobody else holds -- also when it is a view into another buffer; a second contribution is summed out of place."""
+    import torch
+    flat = torch.zeros(32)
+    slot = flat[4:16].view(3, 4)
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x)
+            return (x * w).sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            (x,) = ctx.saved_tensors
+            out = slot.view(3, 4)
+            out.copy_(x * g)
+            return None, out
+
+    w = torch.nn.Parameter(torch.ones(3, 4))
+    x = torch.arange(12.).view(3, 4)
+    fired = []
+    w.register_post_accumulate_grad_hook(lambda p: fired.append(p.grad.data_ptr() == slot.data_ptr()))
+    Fn.apply(x, w).backward()
+    assert w.grad.data_ptr() == slot.data_ptr() and torch.equal(flat[4:16], x.reshape(-1)) and fired == [True]
+    w.grad = None
+    (Fn.apply(x, w) + (2 * w).sum()).backward()
+    assert w.grad.data_ptr() != slot.data_ptr() and torch.equal(w.grad, x + 2)     # what StepGraph._land copies back
+
+
+def test_packed_image_cache_states():
+    """functional.mark_packs_stale / clear_pack_cache (host logic only)."""
+    from saragan_amd import functional as F
+    F.clear_pack_cache()
+    F.mark_packs_stale()
+    assert F._PACK_STATE['stale'] is False          # nothing cached: nothing to refresh
+    F._PACK_CACHE[('rgbmat', 1)] = (object(), object())
+    F._PACK_CACHE[(123, 0, 1.0, False, 1, 8, 8, 3, 3, 3)] = (object(), object(), object(), object())
+    F.mark_packs_stale()
+    assert F._PACK_STATE['stale'] is True and ('rgbmat', 1) not in F._PACK_CACHE and len(F._PACK_CACHE) == 1
+    F.clear_pack_cache()
+    assert not F._PACK_CACHE and F._PACK_STATE['stale'] is False

@@ -257,6 +257,15 @@ int sg_pixel_norm_act_bwd(const void* dy, const void* y, const float* scale, con
 int sg_pixel_norm_act_bwd_pw(const void* g_small, int32_t cs, const float* w_small, const void* y, const float* scale,
                              const void* y_sign_words, float slope, void* dz, float* dbias, void* workspace,
                              int64_t nvox, int32_t c, sg_dtype dt, sg_stream_t st);
+/* The same pass also returning the pointwise convolution's OWN gradients (to_rgb's filter and bias, pgan/generator.py:13-16), which
+ * need exactly the two tensors it reads: dw_small [c][cs] (a [1,1,1,c,cs] filter) = coef_small * sum_v y[v][ch] * g_small[v][j],
+ * db_small [cs] = sum_v g_small[v][j] -- instead of another pass over y (sg_conv3d_wgrad_bias: 1.07 GB at the benchmarked size).
+ * dbias, dw_small, db_small: each optional.  cs == 1; otherwise SG_EUNSUPPORTED.  workspace >= sg_pixel_norm_act_bwd_pw_wg_workspace(c, cs). */
+size_t sg_pixel_norm_act_bwd_pw_wg_workspace(int32_t c, int32_t cs);
+int sg_pixel_norm_act_bwd_pw_wg(const void* g_small, int32_t cs, const float* w_small, const void* y, const float* scale,
+                                const void* y_sign_words, float slope, void* dz, float* dbias, float* dw_small, float* db_small,
+                                float coef_small, void* workspace, size_t workspace_bytes, int64_t nvox, int32_t c, sg_dtype dt,
+                                sg_stream_t st);
 /* y[n,2d,2h,2w,c] = gain * x[n,d,h,w,c] nearest-neighbour    (upscale3d / avg_unpool3d, ops.py:250-262) */
 int sg_upscale2x(const void* x, void* y, int32_t n, int32_t d, int32_t h, int32_t w, int32_t c,
                  float gain, sg_dtype dt, sg_stream_t st);

@@ -78,6 +78,8 @@ SIGNATURES = {
     'sg_pixel_norm_bwd': (C.c_int, [_p, _p, _p, _p, _i64, _i32, C.c_int, _p]),
     'sg_pixel_norm_act_bwd': (C.c_int, [_p, _p, _p, _p, _f, _p, _p, _p, _i64, _i32, C.c_int, _p]),
     'sg_pixel_norm_act_bwd_pw': (C.c_int, [_p, _i32, _p, _p, _p, _p, _f, _p, _p, _p, _i64, _i32, C.c_int, _p]),
+    'sg_pixel_norm_act_bwd_pw_wg': (C.c_int, [_p, _i32, _p, _p, _p, _p, _f, _p, _p, _p, _p, _f, _p, _sz, _i64, _i32, C.c_int, _p]),
+    'sg_pixel_norm_act_bwd_pw_wg_workspace': (_sz, [_i32, _i32]),
     'sg_upscale2x': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
     'sg_upscale2x_masked': (C.c_int, [_p, _p, _p, _f, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),
     'sg_downscale2x': (C.c_int, [_p, _p, _i32, _i32, _i32, _i32, _i32, _f, C.c_int, _p]),

@@ -249,13 +249,16 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __re
 // pixel norm: a team of TP lanes (power of two <= 64) owns one voxel; KP pieces per lane (1 up to 512 bf16 channels,
 // else 4) and U voxels per loop trip: the loads of all U voxels are issued before the first reduction, which is what
 // the kernel needs to keep enough bytes in flight (one voxel per trip reached 2.8 of 6.3 TB/s).
-template <typename T, bool BWD, int KP, int U, int CS = 0>
+template <typename T, bool BWD, int KP, int U, int CS = 0, bool WG = false>
 __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a, const T* __restrict__ yv,
                                                          const float* __restrict__ scale_in, T* __restrict__ out,
                                                          float* __restrict__ scale_out, int64_t nvox, int c, int tp,
                                                          float eps, const uint32_t* __restrict__ words = nullptr,
                                                          float slope = 0.f, float* __restrict__ part = nullptr,
                                                          const float* __restrict__ wsm = nullptr) {
+  // WG (CS > 0, with `part`): the pointwise convolution's own weight and bias gradient from the same read of y and `a` --
+  // per block, behind the c channel sums: CS rows of sum_v a[v][j] * y[v][ch], then the CS sums of a[v][j]
+  static_assert(!WG || (CS > 0 && KP == 1 && BWD), "weight gradient of the pointwise convolution: fused-gradient form only");
   // BWD with `words`: the LeakyReLU backward of the layer (mask from its sign words) is applied to the result and
   // `part` receives per-block channel sums (the bias gradient): pixel_norm(act(z + b)) differentiated in one pass.
   // CS > 0 (KP == 1): the incoming gradient is not a tensor but the product of a CS-channel tensor `a` [nvox][CS] with
@@ -280,6 +283,13 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a
   for (int k = 0; k < KP; ++k)
 #pragma unroll
     for (int e = 0; e < E; ++e) cs[k][e] = 0.f;
+  float dwr[WG ? CS : 1][E], gsum[WG ? CS : 1];
+#pragma unroll
+  for (int j = 0; j < (WG ? CS : 1); ++j) {
+    gsum[j] = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) dwr[j][e] = 0.f;
+  }
   const int64_t vstride = (int64_t)gridDim.x * teams;
   for (int64_t v0 = (int64_t)blockIdx.x * teams + threadIdx.x / tp; v0 < nvox; v0 += vstride * U) {
     Piece<T> pa[U][KP], py[U][KP];
@@ -319,6 +329,16 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a
 #pragma unroll
           for (int j = 0; j < CS; ++j) t = fmaf(gsv[u][j], wreg[j][e], t);
           pa[u][0].v[e] = t;
+        }
+        if constexpr (WG) {       // (dead voxels and lanes beyond the last piece loaded zeros / are masked below)
+          if (v < nvox && lane_t < P) {
+#pragma unroll
+            for (int j = 0; j < CS; ++j) {
+#pragma unroll
+              for (int e = 0; e < E; ++e) dwr[j][e] = fmaf(gsv[u][j], py[u][0].v[e], dwr[j][e]);
+              if (lane_t == 0) gsum[j] += gsv[u][j];
+            }
+          }
         }
       }
 #pragma unroll
@@ -384,8 +404,34 @@ __global__ __launch_bounds__(256) void pixel_norm_kernel(const T* __restrict__ a
           for (int e = 0; e < E; ++e) {
             float t = 0.f;
             for (int j = 0; j < teams; ++j) t += red[(j * tp + threadIdx.x) * E + e];
-            part[(int64_t)blockIdx.x * c + p * E + e] = t;
+            part[(int64_t)blockIdx.x * (WG ? c * (1 + CS) + CS : c) + p * E + e] = t;
           }
+        }
+      }
+    }
+    if constexpr (WG) {
+      const int64_t row = (int64_t)blockIdx.x * (c * (1 + CS) + CS);
+#pragma unroll
+      for (int j = 0; j < CS; ++j) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < E; ++e) red[threadIdx.x * E + e] = dwr[j][e];
+        __syncthreads();
+        if (threadIdx.x < tp && threadIdx.x < P) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            float t = 0.f;
+            for (int q = 0; q < teams; ++q) t += red[(q * tp + threadIdx.x) * E + e];
+            part[row + c * (1 + j) + threadIdx.x * E + e] = t;
+          }
+        }
+        __syncthreads();
+        red[threadIdx.x] = lane_t == 0 ? gsum[j] : 0.f;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          float t = 0.f;
+          for (int q = 0; q < 256; ++q) t += red[q];
+          part[row + c * (1 + CS) + j] = t;
         }
       }
     }
@@ -1086,6 +1132,70 @@ extern "C" int sg_pixel_norm_act_bwd(const void* dy, const void* y, const float*
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((c + 31) / 32), dim3(1024), 0, hs, part, dbias, blocks, c);
     SG_LAUNCH_CHECK();
   }
+  return SG_OK;
+}
+
+// column sums of `part` ([nb][c0 + c1 + c2]) into three destinations (the middle one scaled): the bias gradient of the stage, the
+// pointwise convolution's weight gradient and its bias gradient
+__global__ __launch_bounds__(1024) void colsum_finalize3_kernel(const float* __restrict__ part, int nb, float* __restrict__ out0, int c0,
+                                                                float* __restrict__ out1, int c1, float coef1, float* __restrict__ out2, int c2) {
+  __shared__ float red[32][33];
+  const int c = c0 + c1 + c2;
+  const int ch = blockIdx.x * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (ch < c) {
+    int b = rg;
+    for (; b + 96 < nb; b += 128) {
+      s0 += part[(int64_t)b * c + ch];
+      s1 += part[(int64_t)(b + 32) * c + ch];
+      s2 += part[(int64_t)(b + 64) * c + ch];
+      s3 += part[(int64_t)(b + 96) * c + ch];
+    }
+    for (; b < nb; b += 32) s0 += part[(int64_t)b * c + ch];
+  }
+  red[rg][threadIdx.x & 31] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (rg == 0 && ch < c) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t += red[k][threadIdx.x];
+    if (ch < c0) { if (out0) out0[ch] = t; }
+    else if (ch < c0 + c1) { if (out1) out1[ch - c0] = coef1 * t; }
+    else if (out2) out2[ch - c0 - c1] = t;
+  }
+}
+
+extern "C" size_t sg_pixel_norm_act_bwd_pw_wg_workspace(int32_t c, int32_t cs) {
+  return (c > 0 && cs > 0) ? (size_t)kBwdBlocks * ((size_t)c * (1 + cs) + cs) * sizeof(float) : 0;
+}
+
+// sg_pixel_norm_act_bwd_pw that ALSO returns the pointwise convolution's own gradients from the same pass over y and g_small:
+// dw_small [c][cs] (the layout of a [1,1,1,c,cs] filter) = coef_small * sum_v y[v][ch] * g_small[v][j], db_small [cs] = sum_v g_small[v][j].
+// cs == 1 (the image layers of the 3-D networks); otherwise SG_EUNSUPPORTED.  dbias / dw_small / db_small: each optional.
+extern "C" int sg_pixel_norm_act_bwd_pw_wg(const void* g_small, int32_t cs, const float* w_small, const void* y, const float* scale,
+                                           const void* y_sign_words, float slope, void* dz, float* dbias, float* dw_small,
+                                           float* db_small, float coef_small, void* workspace, size_t workspace_bytes, int64_t nvox,
+                                           int32_t c, sg_dtype dt, sg_stream_t st) {
+  if (!g_small || !w_small || !y || !scale || !y_sign_words || !dz || !workspace || nvox < 1 || c < 1 || cs < 1 || cs > 4) return SG_EINVAL;
+  if (cs != 1) return SG_EUNSUPPORTED;
+  if (workspace_bytes < sg_pixel_norm_act_bwd_pw_wg_workspace(c, cs)) return SG_EWORKSPACE;
+  hipStream_t hs = sg_st(st);
+  const int E = dt == SG_BF16 ? 8 : 4;
+  const int P = c / E;
+  if ((c % E) != 0 || P > 64 || !sg_aligned16(dz) || !sg_aligned16(y)) return SG_EUNSUPPORTED;
+  const int tp = team_size(P);
+  if (P > tp) return SG_EUNSUPPORTED;
+  const int teams = 256 / tp;
+  const int blocks = grid_for(nvox, teams, kBwdBlocks);
+  float* part = reinterpret_cast<float*>(workspace);
+#define L(T) hipLaunchKernelGGL((pixel_norm_kernel<T, true, 1, 2, 1, true>), dim3(blocks), dim3(256), 0, hs, (const T*)g_small, (const T*)y, scale, (T*)dz, (float*)nullptr, nvox, c, tp, 0.f, (const uint32_t*)y_sign_words, slope, part, w_small)
+  SG_DISPATCH(dt, L(bf16_t), L(float));
+#undef L
+  SG_LAUNCH_CHECK();
+  const int cols = c * (1 + cs) + cs;
+  hipLaunchKernelGGL(colsum_finalize3_kernel, dim3((cols + 31) / 32), dim3(1024), 0, hs, part, blocks, dbias, c, dw_small, c * cs, coef_small,
+                     db_small, cs);
+  SG_LAUNCH_CHECK();
   return SG_OK;
 }
 

@@ -721,6 +721,7 @@ class _ConvBiasAct(torch.autograd.Function):
 
 
 _NO_RGB_FUSION = bool(int(os.environ.get('SARAGAN_NO_RGB_FUSION', '0')))   # diagnostic: to_rgb's data gradient as a tensor
+_NO_RGB_WG_FUSION = bool(int(os.environ.get('SARAGAN_NO_RGB_WG_FUSION', '0')))   # diagnostic: to_rgb's filter gradient as its own pass over y
 
 
 def _rgb_matrix(w_rgb, coef, dtype, small_is_cin=False):
@@ -797,19 +798,43 @@ class _ConvPnActToRgb(torch.autograd.Function):
         nvox = n * d * h * wd
         want_db = ctx.has_b and _wants(ctx, 2, ctx.ptrs[1])
         gw_rgb = gb_rgb = None
-        if g_img is not None:
-            g_img = ndhwc(g_img)
-            want_db_rgb = ctx.has_b_rgb and _wants(ctx, 9, ctx.ptrs[3])
-            if _wants(ctx, 8, ctx.ptrs[2]):
-                gw_rgb, gb_rgb = raw_wgrad(y, g_img, (1, 1, 1), coef_rgb, False, want_db_rgb, ctx.ptrs[2], ctx.ptrs[3])
-                gw_rgb = gw_rgb.reshape(w_rgb.shape) if gw_rgb is not None else None
-            elif want_db_rgb:
-                _, gb_rgb = raw_bias_act_bwd(g_img, None, 0.0, want_dx=False, want_db=True, b_ptr=ctx.ptrs[3])
         if g_img is None and g_y is None:
             return (None,) * 11
         g = gb = None
         cs = w_rgb.shape[-1]
-        if g_img is not None and g_y is None and not _NO_RGB_FUSION and cs <= 4:
+        fuse = g_img is not None and g_y is None and not _NO_RGB_FUSION and cs <= 4
+        want_w_rgb = g_img is not None and _wants(ctx, 8, ctx.ptrs[2])
+        want_db_rgb = g_img is not None and ctx.has_b_rgb and _wants(ctx, 9, ctx.ptrs[3])
+        if g_img is not None:
+            g_img = ndhwc(g_img)
+        done_rgb = False
+        if fuse and cs == 1 and (want_w_rgb or want_db_rgb) and not _NO_RGB_WG_FUSION:
+            # to_rgb's data gradient AND its own filter / bias gradient inside the pixel-norm / LeakyReLU backward pass: all three
+            # need only y and the image gradient, which that pass reads anyway (a separate filter-gradient pass re-read y: 1.07 GB)
+            g = torch.empty_like(y)
+            gb = _f32_out(ctx.ptrs[1], (c,), y.device) if want_db else None
+            gw_rgb = _f32_out(ctx.ptrs[2], tuple(w_rgb.shape), y.device) if want_w_rgb else None
+            gb_rgb = _f32_out(ctx.ptrs[3], (cs,), y.device) if want_db_rgb else None
+            ws_bytes = lib.sg_pixel_norm_act_bwd_pw_wg_workspace(c, cs)
+            ws = torch.empty(ws_bytes, device=y.device, dtype=torch.uint8)
+            rc = lib.sg_pixel_norm_act_bwd_pw_wg(_ptr(g_img), cs, _ptr(_rgb_matrix(w_rgb, coef_rgb, y.dtype)), _ptr(y), _ptr(scale), _ptr(signs),
+                                                 float(slope), _ptr(g), _ptr(gb), _ptr(gw_rgb), _ptr(gb_rgb), float(coef_rgb), _ptr(ws), ws_bytes,
+                                                 nvox, c, _dt(y), _stream())
+            if rc == _lib.SG_EUNSUPPORTED:
+                _unclaim(ctx.ptrs[1], gb)
+                _unclaim(ctx.ptrs[2], gw_rgb)
+                _unclaim(ctx.ptrs[3], gb_rgb)
+                g = gb = gw_rgb = gb_rgb = None
+            else:
+                check(rc, 'sg_pixel_norm_act_bwd_pw_wg')
+                done_rgb = True
+        if g_img is not None and not done_rgb:
+            if want_w_rgb:
+                gw_rgb, gb_rgb = raw_wgrad(y, g_img, (1, 1, 1), coef_rgb, False, want_db_rgb, ctx.ptrs[2], ctx.ptrs[3])
+                gw_rgb = gw_rgb.reshape(w_rgb.shape) if gw_rgb is not None else None
+            elif want_db_rgb:
+                _, gb_rgb = raw_bias_act_bwd(g_img, None, 0.0, want_dx=False, want_db=True, b_ptr=ctx.ptrs[3])
+        if fuse and g is None:
             g = torch.empty_like(y)
             gb = _f32_out(ctx.ptrs[1], (c,), y.device) if want_db else None
             ws = torch.empty(lib.sg_bias_act_bwd_workspace(c), device=y.device, dtype=torch.uint8) if want_db else None

@@ -1530,3 +1530,38 @@ def test_wgrad_sliding_halo_kernel_on_the_16x16x32_mfma(case, sg_env, monkeypatc
     np.testing.assert_allclose(dw1.cpu().numpy(), dw0.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(dw0.abs().max()))
     np.testing.assert_allclose(db1.cpu().numpy(), db0.cpu().numpy(), rtol=1e-4, atol=1e-5 * float(db0.abs().max()))
     assert not torch.equal(dw0, torch.zeros_like(dw0))
+
+
+@pytest.mark.parametrize('dtype', DT)
+def test_to_rgb_filter_gradient_inside_the_pixel_norm_backward(dtype, monkeypatch):
+    """sg_pixel_norm_act_bwd_pw_wg: to_rgb's filter and bias gradient (pgan/generator.py:13-16) from the pass that already reads the
+    stage's output and the image gradient -- the same values, up to f32 summation order, as the separate filter-gradient pass over y
+    (SARAGAN_NO_RGB_WG_FUSION=1), and the same stage gradients bit for bit."""
+    from saragan_amd import functional as F
+    n, cin, c, sp = 2, 16, 32, (4, 12, 16)
+    x = cl(rnd((n, cin, *sp), 801, dtype), dtype).requires_grad_(True)
+    w = rnd((3, 3, 3, cin, c), 802, dtype).float().to(dev()).requires_grad_(True)
+    b = (rnd((c,), 803, torch.float32) * 0.3).float().to(dev()).requires_grad_(True)
+    wr = rnd((1, 1, 1, c, 1), 804, dtype).float().to(dev()).requires_grad_(True)
+    br = (rnd((1,), 805, torch.float32) * 0.3).float().to(dev()).requires_grad_(True)
+    coef = O.runtime_coef(w.shape, 'leaky_relu', 0.2)
+    coef_r = O.runtime_coef(wr.shape, 'linear', None)
+    g_img = cl(rnd((n, 1, *sp), 806, dtype), dtype)
+
+    def grads():
+        img, _ = F.conv3d_pn_to_rgb(x, w, coef, b, False, 0.2, 1e-8, None, wr, coef_r, br)
+        return torch.autograd.grad(img, [x, w, b, wr, br], g_img)
+
+    import saragan_amd
+    saragan_amd.set_deterministic(True)       # (the filter gradient's atomics would differ from run to run in the last bits)
+    try:
+        fused = grads()
+        monkeypatch.setattr(F, '_NO_RGB_WG_FUSION', True)
+        apart = grads()
+    finally:
+        saragan_amd.set_deterministic(False)
+    for name, a, r in zip(('dx', 'dw', 'db'), fused[:3], apart[:3]):
+        assert torch.equal(a, r), name
+    for name, a, r in zip(('dw_rgb', 'db_rgb'), fused[3:], apart[3:]):
+        np.testing.assert_allclose(a.float().cpu().numpy(), r.float().cpu().numpy(), rtol=2e-5, atol=2e-6 * float(r.abs().max()), err_msg=name)
+        assert float(r.abs().max()) > 0

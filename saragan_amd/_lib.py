@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsaragan_hip.so')
+# SARAGAN_LIB: another build of the library (kernel A/B probes under tools/; never set in production)
+LIB_PATH = os.environ.get('SARAGAN_LIB') or os.path.join(_HERE, 'libsaragan_hip.so')
 
 SG_F32, SG_BF16 = 0, 1
 SG_OPT_SGD, SG_OPT_MOMENTUM, SG_OPT_ADADELTA = 0, 1, 2

@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB = os.path.join(HERE, 'libsaragan_hip.so')
-SOURCES = ['conv3d.hip', 'conv3p.hip', 'wgrad.hip', 'elementwise.hip', 'optim.hip', 'prof.hip', 'small.hip', 'subpix.hip', 'gemm.hip', 'metrics.hip']
+SOURCES = ['conv3d.hip', 'conv3p.hip', 'conv3w.hip', 'wgrad.hip', 'elementwise.hip', 'optim.hip', 'prof.hip', 'small.hip', 'subpix.hip', 'gemm.hip', 'metrics.hip']
 HEADERS = ['common.h', 'prof.h', 'conv_args.h', os.path.join('..', '..', 'include', 'saragan_hip.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
 # The MFMA kernels' off-phases share their SIMD with the other wave group's MFMAs, and packed-f32 VALU ops
@@ -18,7 +18,8 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-u
 # -save-temps=obj: the device assembly of exactly the code that ships (build/<name>-hip-amdgcn-amd-amdhsa-gfx950.s) is kept
 # for tests/test_build_resources.py, which checks the hand-counted `s_waitcnt lgkmcnt(N)` regions of the unrolled K loops.
 FILE_FLAGS = {'conv3d.hip': ['-fno-slp-vectorize', '-save-temps=obj'], 'wgrad.hip': ['-fno-slp-vectorize', '-save-temps=obj'],
-              'subpix.hip': ['-fno-slp-vectorize'], 'conv3p.hip': ['-fno-slp-vectorize', '-save-temps=obj'], 'gemm.hip': ['-fno-slp-vectorize']}
+              'subpix.hip': ['-fno-slp-vectorize'], 'conv3p.hip': ['-fno-slp-vectorize', '-save-temps=obj'],
+              'conv3w.hip': ['-fno-slp-vectorize', '-save-temps=obj'], 'gemm.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc():

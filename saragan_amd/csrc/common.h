@@ -38,6 +38,7 @@ struct sg_config {
   int fwd_v1, fwd_no_pw, fwd_no_dense;       // SG_FWD_V1, SG_FWD_NO_PW, SG_FWD_NO_DENSE
   int fwd_no_v3, fwd_no_v3s, fwd_no_v4, fwd_no_v5, fwd_no_ksplit;   // SG_FWD_NO_V3, SG_FWD_NO_V3S, SG_FWD_NO_V4, SG_FWD_NO_V5, SG_FWD_NO_KSPLIT
   int fwd3p_16;                              // SG_FWD3P_16 (default 1): the one-pass 64 -> 32 kernel on v_mfma_f32_16x16x32_bf16; 0: the 32x32x16 form
+  int fwd3s_16;                              // SG_FWD3S_16 (default 1): 32 -> 32k layers on conv_fwd3w (16x16x32, wave-private planes); 0: the sliding-halo kernel
   int fwd_no_3p;                             // SG_FWD_NO_3P: 64 -> 32 layers through the two-pass K split (A/B, tests)
   int fwd3_gx, fwd3_no_lean;                 // SG_FWD3_GX (0 = automatic), SG_FWD3_NO_LEAN
   int fwd4_gx, fwd4_no_lean, fwd4_no_wres;   // SG_FWD4_GX (0 = automatic), SG_FWD4_NO_LEAN, SG_FWD4_NO_WRES

@@ -104,7 +104,7 @@ static int conv_shape_ok(const sg_conv_shape* s) {
 extern "C" size_t sg_conv3d_packed_bytes(const sg_conv_shape* s, sg_dtype dt) {
   if (!conv_shape_ok(s)) return 0;
   // [MFMA fragment image][plain f32 [taps][cin][cout] copy for the small-channel VALU kernels, where they take the layer]
-  return (size_t)conv_nchunk(s, dt) * (s->kd * s->kh * s->kw) * conv_ntile(s) * 1024 + sg_small_tail_bytes(s) + sg_fwd3p16_packed_bytes(s, dt);
+  return (size_t)conv_nchunk(s, dt) * (s->kd * s->kh * s->kw) * conv_ntile(s) * 1024 + sg_small_tail_bytes(s) + sg_pack16_bytes(s, dt);
 }
 
 extern "C" int sg_conv3d_pack_weights(const float* w, float coef, int transpose_flip, void* wp,
@@ -123,8 +123,10 @@ extern "C" int sg_conv3d_pack_weights(const float* w, float coef, int transpose_
   else
     hipLaunchKernelGGL(pack_weights_kernel<float>, dim3(blocks), dim3(256), 0, sg_st(st), a);
   SG_LAUNCH_CHECK();
-  if (sg_fwd3p16_packed_bytes(s, dt))      // (these shapes have no small-channel tail: the second image follows the first directly)
-    return sg_fwd3p16_pack(w, coef, a.flip, reinterpret_cast<char*>(wp) + (size_t)a.nchunk * a.taps * a.ntile * 1024, sg_st(st));
+  if (sg_pack16_bytes(s, dt)) {      // (these shapes have no small-channel tail: the second image follows the first directly)
+    void* tail = reinterpret_cast<char*>(wp) + (size_t)a.nchunk * a.taps * a.ntile * 1024;
+    return sg_pack16_batch(1, &w, &coef, &a.flip, &tail, s, sg_st(st));
+  }
   if (sg_small_tail_bytes(s))
     return sg_small_pack(w, coef, a.flip, reinterpret_cast<char*>(wp) + (size_t)a.nchunk * a.taps * a.ntile * 1024, s, dt, sg_st(st));
   return SG_OK;
@@ -162,14 +164,24 @@ extern "C" int sg_conv3d_pack_weights_batch(int n, const float* const* w, const 
       hipLaunchKernelGGL(pack_weights_batch_kernel<float>, dim3((unsigned)blocks, (unsigned)m), dim3(256), 0, sg_st(st), b);
     SG_LAUNCH_CHECK();
   }
-  for (int i = 0; i < n; ++i) {                   // the second images of the few layers that have one
+  // the second images of the layers that have one: the 16x16x32 fragment images in one launch per 32 layers
+  constexpr int M16 = 64;
+  const float* w16[M16]; float c16[M16]; int f16[M16]; void* d16[M16]; sg_conv_shape s16[M16];
+  int n16 = 0;
+  for (int i = 0; i < n; ++i) {
     const sg_conv_shape* s = &shapes[i];
     char* tail = reinterpret_cast<char*>(wp[i]) + (size_t)conv_nchunk(s, dt) * (s->kd * s->kh * s->kw) * conv_ntile(s) * 1024;
     int rc = SG_OK;
-    if (sg_fwd3p16_packed_bytes(s, dt)) rc = sg_fwd3p16_pack(w[i], coef[i], transpose_flip[i] ? 1 : 0, tail, sg_st(st));
-    else if (sg_small_tail_bytes(s)) rc = sg_small_pack(w[i], coef[i], transpose_flip[i] ? 1 : 0, tail, s, dt, sg_st(st));
+    if (sg_pack16_bytes(s, dt)) {
+      w16[n16] = w[i]; c16[n16] = coef[i]; f16[n16] = transpose_flip[i] ? 1 : 0; d16[n16] = tail; s16[n16] = *s;
+      if (++n16 == M16) {
+        rc = sg_pack16_batch(n16, w16, c16, f16, d16, s16, sg_st(st));
+        n16 = 0;
+      }
+    } else if (sg_small_tail_bytes(s)) rc = sg_small_pack(w[i], coef[i], transpose_flip[i] ? 1 : 0, tail, s, dt, sg_st(st));
     if (rc != SG_OK) return rc;
   }
+  if (n16) return sg_pack16_batch(n16, w16, c16, f16, d16, s16, sg_st(st));
   return SG_OK;
 }
 
@@ -3031,6 +3043,10 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     }
     if (xpl || a.in_mask) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }
     if (dt == SG_BF16 && k333 && !sg_cfg().fwd_no_v3s) {   // sliding-halo variant where its tile fits
+      if (a.nchunk == 2 && sg_cfg().fwd3s_16) {              // ... as wave-private planes + sliding accumulators on 16x16x32 (conv3w.hip)
+        rc = sg_launch_fwd3w(a, s, hs, &used);
+        if (rc != SG_OK || used) { prof.done(rc); return rc; }
+      }
       if (a.nchunk == 2) rc = launch_fwd3s<2>(a, s, hs, &used);
       else if (a.nchunk == 1) rc = launch_fwd3s<1>(a, s, hs, &used);
       if (rc != SG_OK || used) { prof.done(rc); return rc; }

@@ -862,19 +862,6 @@ __global__ __launch_bounds__(512) void conv_fwd3p16_kernel(ConvFwdArgs a) {
 #undef SG_P16_OFF
 }
 
-// weight image of the 16x16x32 variant: [tap][32-channel chunk][channel half] fragments of 1 KiB, lane l of a fragment = A operand
-// row (cout) 16 * ch + (l & 15), K elements (cin) 32 * gi + 8 * (l >> 4) + e
-__global__ void pack_weights16_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, float coef, int flip) {
-  const int total = 27 * 4 * 64 * 8;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int e = i & 7, lane = (i >> 3) & 63, f = i >> 9;
-    const int ch = f & 1, gi = (f >> 1) & 1, tap = f >> 2;
-    const int co = 16 * ch + (lane & 15), ci = 32 * gi + 8 * (lane >> 4) + e;
-    const float v = !flip ? w[(tap * 64 + ci) * 32 + co] : w[((26 - tap) * 32 + co) * 64 + ci];   // as pack_weights_kernel (conv3d.hip)
-    out[i] = (bf16_t)(v * coef);
-  }
-}
-
 template <int EPI, bool UPS, bool INM>
 int launch_fwd3p_inst(const ConvFwdArgs& a, unsigned gx, hipStream_t st) {
   if (sg_cfg().fwd3p_16) {
@@ -890,16 +877,6 @@ int launch_fwd3p_inst(const ConvFwdArgs& a, unsigned gx, hipStream_t st) {
 }
 
 }  // namespace
-
-size_t sg_fwd3p16_packed_bytes(const sg_conv_shape* s, sg_dtype dt) {
-  return (dt == SG_BF16 && s->kd == 3 && s->kh == 3 && s->kw == 3 && s->cin == 64 && s->cout == 32) ? (size_t)P3_WBYTES : 0;
-}
-
-int sg_fwd3p16_pack(const float* w, float coef, int flip, void* dst, hipStream_t st) {
-  hipLaunchKernelGGL(pack_weights16_kernel, dim3(108), dim3(256), 0, st, w, reinterpret_cast<bf16_t*>(dst), coef, flip);
-  SG_LAUNCH_CHECK();
-  return SG_OK;
-}
 
 // bf16, 3 x 3 x 3, 64 -> 32 channels, whole 32-wide rows; optional fused nearest-x2 gather (with the input mask).  Sets
 // *used = false (and launches nothing) for anything else: the caller falls back to the two-pass K split.

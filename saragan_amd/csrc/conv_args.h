@@ -44,6 +44,11 @@ enum : int { SG_EP_SIGN = 1, SG_EP_MASK = 2, SG_EP_PN = 4, SG_EP_POOL = 8, SG_EP
 
 // conv3p.hip: one-pass 64 -> 32 sliding-accumulator kernel (replaces the two-pass K split where it applies)
 int sg_launch_fwd3p(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used);
-// its v_mfma_f32_16x16x32_bf16 variant (SG_FWD3P_16=1) reads a fragment image of its own, packed behind the standard one
-size_t sg_fwd3p16_packed_bytes(const sg_conv_shape* s, sg_dtype dt);
-int sg_fwd3p16_pack(const float* w, float coef, int flip, void* dst, hipStream_t st);
+// conv3w.hip: 32 -> 32k layers with wave-private halo planes and sliding accumulators on v_mfma_f32_16x16x32_bf16 (replaces the
+// sliding-halo kernel where it applies; SG_FWD3S_16=0 switches it off)
+int sg_launch_fwd3w(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used);
+// The v_mfma_f32_16x16x32_bf16 kernels read a fragment image of their own, packed behind the standard one (conv3w.hip):
+// bytes of that image (0: the layer has none) and the packer of n such images in one launch per 32 layers
+size_t sg_pack16_bytes(const sg_conv_shape* s, sg_dtype dt);
+int sg_pack16_batch(int n, const float* const* w, const float* coef, const int* flip, void* const* dst, const sg_conv_shape* shapes,
+                    hipStream_t st);

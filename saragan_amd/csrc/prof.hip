@@ -44,6 +44,7 @@ const sg_config* read_config() {
   c->fwd_no_ksplit = env_int("SG_FWD_NO_KSPLIT", 0);
   c->fwd_no_3p = env_int("SG_FWD_NO_3P", 0);
   c->fwd3p_16 = env_int("SG_FWD3P_16", 1);
+  c->fwd3s_16 = env_int("SG_FWD3S_16", 1);
   c->fwd3_gx = env_int("SG_FWD3_GX", 0);
   c->fwd3_no_lean = env_int("SG_FWD3_NO_LEAN", 0);
   c->fwd4_gx = env_int("SG_FWD4_GX", 0);

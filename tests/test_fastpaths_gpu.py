@@ -19,13 +19,20 @@ def _run(name, sg_env):
     try:
         assert mod.main(), f'{name}: see the captured output'
     finally:
-        for k in ('SG_FWD_NO_V3S', 'SG_FWD_NO_3P', 'SG_FWD_NO_V5', 'SG_WGRAD_NO_LEAN'):
+        for k in ('SG_FWD_NO_V3S', 'SG_FWD_NO_3P', 'SG_FWD_NO_V5', 'SG_WGRAD_NO_LEAN', 'SG_FWD3S_16'):
             os.environ.pop(k, None)
         sg_env()        # fresh configuration snapshot for the tests that follow
 
 
 def test_sliding_halo_variants_match_general_kernels(sg_env):
     _run('check_v3s_variants', sg_env)
+
+
+def test_wave_private_plane_variants_match_sliding_halo_and_torch(sg_env):
+    """conv_fwd3w (csrc/conv3w.hip: wave-private halo planes, sliding accumulators, v_mfma_f32_16x16x32_bf16) in every epilogue
+    variant, forward and data gradient, ragged H, odd D, 64 output channels, batch 1-2 (columns cut into D segments), against the
+    sliding-halo kernel (SG_FWD3S_16=0) and torch fp32."""
+    _run('check_v3w_variants', sg_env)
 
 
 def test_streamed_lean_variants_match_conv_fwd4(sg_env):

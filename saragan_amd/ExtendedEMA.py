@@ -72,12 +72,16 @@ class ExtendedEMA:
                 flat = self._flat(prefix)
                 self._backup[prefix] = flat['param'].clone()
                 flat['param'].copy_(self.shadow_flat(prefix))
+            # the parameters alias the flat buffer (p.data = flat[...]): writing it moves neither data_ptr nor the version
+            # counter the packed weight images are keyed by -- every writer of flat['param'] says so itself
+            F.mark_packs_stale()
         return Op(run, 'assign_ema_weights')
 
     def restore_original_weights(self):
         def run():
             for prefix in ('generator/', 'discriminator/'):
                 self._flat(prefix)['param'].copy_(self._backup[prefix])
+            F.mark_packs_stale()
         return Op(run, 'restore_original_weights')
 
     def ema_update_weights(self):
@@ -85,4 +89,5 @@ class ExtendedEMA:
         def run():
             for prefix in ('generator/', 'discriminator/'):
                 self._flat(prefix)['param'].copy_(self.shadow_flat(prefix))
+            F.mark_packs_stale()
         return Op(run, 'ema_update_weights')

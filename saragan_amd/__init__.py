@@ -20,3 +20,7 @@ def set_deterministic(on=True):
     from . import _lib
     os.environ['SG_DETERMINISTIC'] = '1' if on else '0'
     _lib.load().sg_config_reload()
+    # the kept filter-gradient workspaces are clean only under the mode that used them last (the reproducible finalize pass does
+    # not clear the slabs it read): none survives a switch
+    from . import functional as F
+    F.clear_kept_workspaces()

@@ -353,7 +353,7 @@ def raw_wgrad(x, dy, k, coef, ups=False, want_db=False, w_ptr=0, b_ptr=0):
         rc = _wgrad_launch(lib, x, dy, None, 0.0, 1.0, acc, db, coef, True, shp, dt)
         if rc != _lib.SG_EUNSUPPORTED:
             check(rc, 'sg_conv3d_wgrad_bias_ex (accumulate)')
-            GRAD_DEST_STATS['accumulated'] += 1
+            _note_accumulated(w_ptr)
             return None, db
         _unclaim(b_ptr, db)
     dw = _f32_out(w_ptr, (k[0], k[1], k[2], cin, cout), x.device)
@@ -402,6 +402,7 @@ def _zero_scalar(like):
 _SKIP = {'ptrs': frozenset()}
 _GRAD_DEST = {}      # parameter data_ptr -> [f32 view of the step's flat gradient buffer, claimed]
 _NO_GRAD_DEST = bool(int(os.environ.get('SARAGAN_NO_GRAD_DEST', '0')))   # diagnostic: gradients as tensors of their own, added by autograd
+ACCUMULATED_IN_PLACE = set()   # data_ptr of the parameters whose slot took a later contribution in place during this backward
 GRAD_DEST_STATS = {'claimed': 0, 'accumulated': 0, 'adopted': 0, 'copied': 0, 'unreached': 0}   # counters for the tests (host side only)
 
 
@@ -417,6 +418,7 @@ def grads_into(dest):
     copied in by the caller (StepGraph._land)."""
     prev = dict(_GRAD_DEST)
     _GRAD_DEST.clear()
+    ACCUMULATED_IN_PLACE.clear()
     if not _NO_GRAD_DEST:
         _GRAD_DEST.update({k: [v, False] for k, v in dest.items()})
     try:
@@ -449,6 +451,15 @@ def _grad_acc(ptr, shape):
     if ent is None or not ent[1] or ent[0].numel() != math.prod(shape):
         return None
     return ent[0].view(shape)
+
+
+def _note_accumulated(ptr):
+    """A kernel HAS added a contribution in place to the slot of parameter `ptr` (the launch was not declined).  From here on the
+    slot holds more than what autograd was handed: sound only while every later contribution is made in place too -- one that
+    arrives as a tensor of its own makes the engine sum OUT of place (V1 + T2 elsewhere), and copying that sum over the slot would
+    drop what was added here.  StepGraph._land refuses that case."""
+    ACCUMULATED_IN_PLACE.add(ptr)
+    GRAD_DEST_STATS['accumulated'] += 1
 
 
 def _unclaim(ptr, t):
@@ -1017,7 +1028,7 @@ class _PooledDgradGather(torch.autograd.Function):
                 rc = _wgrad_launch(lib, ggx_, gy_, signs, slope, 0.125, acc, None, coef, True, shp, dt)
             if rc != _lib.SG_EUNSUPPORTED:
                 check(rc, 'sg_conv3d_wgrad_bias_ex (gathered dy, accumulate)')
-                GRAD_DEST_STATS['accumulated'] += 1
+                _note_accumulated(w.data_ptr())
                 return g_gy, None, None, None, None, None, None
             dw = _f32_out(w.data_ptr(), (3, 3, 3, 32, 64), ggx.device)
             rc = _wgrad_launch(lib, ggx_, gy_, signs, slope, 0.125, dw, None, coef, False, shp, dt)
@@ -1080,7 +1091,7 @@ def _pooled_backward_gather(gy, x, w, signs, coef, slope, in_info, want_gx, want
             return None
         check(rc, 'sg_conv3d_wgrad_bias_ex (gathered dy)')
         if acc is not None:
-            GRAD_DEST_STATS['accumulated'] += 1
+            _note_accumulated(w.data_ptr())
         gw = dw.reshape(w.shape) if (want_gw and acc is None) else None
     return gx, gw, gb
 
@@ -1440,12 +1451,22 @@ class DevScalars:
     """The per-step scalars of a captured step (optimization.StepGraph): fade-in weights [alpha, 1 - alpha] and the step size
     of each optimiser.  The host writes them into a pinned mirror (`set`) and `flush()` sends all of them with one
     asynchronous copy before the graph is replayed; the captured kernels read the device copy.  The values are the f32
-    roundings of the doubles the eager path hands to ctypes: the same bits reach the same arithmetic."""
+    roundings of the doubles the eager path hands to ctypes: the same bits reach the same arithmetic.
+    A replayed step costs the host next to nothing, so it runs ahead of the device: the pinned source of a copy that has not
+    executed yet must not be rewritten (with ONE mirror a replay could read the alpha / step size of a later
+    step).  The mirror is a ring of pinned slots, each with the event recorded behind its last copy; a slot is rewritten only
+    after that event (the host waits only if it is RING flushes ahead)."""
+    RING = 8
 
     def __init__(self, device, n=8):
-        self.host = torch.zeros(n, dtype=torch.float32).pin_memory() if torch.device(device).type == 'cuda' \
-            else torch.zeros(n, dtype=torch.float32)
+        cuda = torch.device(device).type == 'cuda'
+        self._ring = [torch.zeros(n, dtype=torch.float32).pin_memory() if cuda else torch.zeros(n, dtype=torch.float32)
+                      for _ in range(self.RING if cuda else 1)]
+        self._events = [None] * len(self._ring)
+        self._cur = 0
+        self.host = self._ring[0]
         self.dev = torch.zeros(n, dtype=torch.float32, device=device)
+        self.waits = 0            # times the host had to wait for a slot (tests)
 
     def set(self, idx, value):
         self.host[idx] = float(value)
@@ -1456,6 +1477,18 @@ class DevScalars:
 
     def flush(self):
         self.dev.copy_(self.host, non_blocking=True)
+        if len(self._ring) == 1:
+            return
+        ev = self._events[self._cur]
+        if ev is None:
+            ev = self._events[self._cur] = torch.cuda.Event()
+        ev.record()
+        nxt = (self._cur + 1) % len(self._ring)
+        if self._events[nxt] is not None and not self._events[nxt].query():
+            self._events[nxt].synchronize()
+            self.waits += 1
+        self._ring[nxt].copy_(self.host)      # values not set again keep theirs
+        self._cur, self.host = nxt, self._ring[nxt]
 
 
 class _Axpby(torch.autograd.Function):

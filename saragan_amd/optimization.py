@@ -474,6 +474,9 @@ class StepGraph:
                 ent['decided'] = 'eager'
                 for k_ in ('real', 'rnd', 'scalars', 'opt', 'out', 'pend'):
                     ent.pop(k_, None)
+                # a kept filter-gradient workspace first made inside the failed capture had its zero-fill only RECORDED: it
+                # (and any other) goes, the next eager step makes clean ones
+                F.clear_kept_workspaces()
                 raise
             finally:
                 L.set_random_source(base)
@@ -563,6 +566,10 @@ class StepGraph:
         if g is None:
             F.GRAD_DEST_STATS['unreached'] += 1
         elif g.data_ptr() != slot.data_ptr() or g.dtype != slot.dtype:
+            if p.data_ptr() in F.ACCUMULATED_IN_PLACE:
+                raise RuntimeError('a gradient contribution was added in place to the flat-buffer slot of a parameter whose .grad '
+                                   'autograd then assembled elsewhere: copying it in would drop that contribution '
+                                   '(functional._grad_acc; SARAGAN_NO_GRAD_DEST=1 avoids the in-place path)')
             F.GRAD_DEST_STATS['copied'] += 1
             slot.copy_(g)
         elif g is not slot:

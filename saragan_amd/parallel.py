@@ -361,3 +361,5 @@ def broadcast_global_variables(store, root_rank=0, group=None):
     for k, v in store.vars.items():
         if k not in done:
             dist.broadcast(v.data, src=root_rank, group=group)
+    from . import functional as F
+    F.mark_packs_stale()      # the flat buffers were rewritten behind the version counters the packed weight images are keyed by

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 NAME = 'oracle_step_p3_wgan_a000.npz'
 
 
-def _run(golden_dir, steps, dtype, captured, mixing=False, clipping=False, keep=False, reload_at=None):
+def _run(golden_dir, steps, dtype, captured, mixing=False, clipping=False, keep=False, reload_at=None, run_ahead=False, alpha_step=0.11):
     import saragan_amd.optimization as opt
     from saragan_amd.ExtendedEMA import ExtendedEMA
     from saragan_amd.networks import loss as L
@@ -55,10 +55,15 @@ def _run(golden_dir, steps, dtype, captured, mixing=False, clipping=False, keep=
         losses, kept = [], []
         tg, td = (tup[12], tup[16]) if mixing else (tup[0], tup[1])
         fetch = [tg, td, tup[2], tup[3]] + ([tup[10], tup[11]] if clipping and not mixing else [])
+        reals = [(fx['real'].float() + 0.1 * torch.randn(fx['real'].shape, generator=g)).cuda() for _ in range(steps)]
+        if run_ahead:      # nothing in the loop below waits for the device; a long launch up front lets the host get steps ahead
+            big = torch.randn(8192, 8192, device='cuda')
+            for _ in range(12):
+                big = (big @ big).clamp_(-1, 1)
         for i in range(steps):
             g_lr.assign(1e-3 * (1.0 + 0.1 * i))       # a schedule: the step size moves every step
-            d_lr.assign(1e-3 * (1.0 - 0.05 * i))
-            real = (fx['real'].float() + 0.1 * torch.randn(fx['real'].shape, generator=g)).cuda()
+            d_lr.assign(1e-3 * (1.0 - 0.05 * i) if not run_ahead else 1e-3 / (1.0 + 0.05 * i))
+            real = reals[i]
             if i == reload_at:      # the weights change under the graph (a checkpoint restored mid-run): torch copies, new versions
                 store.load_state_dict({k: v * 0.5 for k, v in fx['p0'].items()}, strict=True)
             res = sess.run(fetch, feed_dict={ph: real})
@@ -69,7 +74,7 @@ def _run(golden_dir, steps, dtype, captured, mixing=False, clipping=False, keep=
             else:
                 losses.append((float(gl), float(dl)) + tuple(float(v) for v in res[4:]))
             if mixing:
-                alpha.assign(max(float(alpha.eval()) - 0.11, 0.0))
+                alpha.assign(max(float(alpha.eval()) - alpha_step, 0.0))
         if keep:
             losses = [(float(a), float(b)) for a, b in kept]
         graph = tup[0].graph
@@ -113,6 +118,24 @@ def test_captured_mixing_phase_replays_one_graph(golden_dir, dtype):
     assert n0 == 0 and n1 == 1, (n0, n1)
     assert l0 == l1, (l0, l1)
     assert len({a for a, _ in l0}) == len(l0)   # the losses do move with alpha: the replays did not reuse a stale weight
+    bad = [k for k in w0 if not torch.equal(w0[k], w1[k])]
+    assert not bad, bad
+
+
+def test_replays_that_run_ahead_of_the_device_read_their_own_scalars(golden_dir):
+    """a replayed step costs the host almost nothing, so without a synchronisation in the loop (train.py only
+    synchronises when it logs, on rank 0) the host is many steps ahead of the device.  The fade-in weights and step sizes travel
+    through a pinned mirror and an asynchronous copy: rewriting the mirror before that copy has executed hands a replay the
+    scalars of a LATER step.  30 mixing steps queued behind a long launch, no fetch read before the end: bit-identical to eager."""
+    import saragan_amd
+    saragan_amd.set_deterministic(True)
+    try:
+        w0, l0, n0 = _run(golden_dir, 30, torch.float32, captured=False, mixing=True, keep=True, run_ahead=True, alpha_step=0.03)
+        w1, l1, n1 = _run(golden_dir, 30, torch.float32, captured=True, mixing=True, keep=True, run_ahead=True, alpha_step=0.03)
+    finally:
+        saragan_amd.set_deterministic(False)
+    assert n0 == 0 and n1 == 1, (n0, n1)
+    assert l0 == l1, [(i, a, b) for i, (a, b) in enumerate(zip(l0, l1)) if a != b][:4]
     bad = [k for k in w0 if not torch.equal(w0[k], w1[k])]
     assert not bad, bad
 

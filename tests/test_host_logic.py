@@ -322,6 +322,37 @@ def test_autograd_adopts_a_slot_alias_as_grad():
     assert w.grad.data_ptr() != slot.data_ptr() and torch.equal(w.grad, x + 2)     # what StepGraph._land copies back
 
 
+def test_mixed_in_place_and_out_of_place_contributions_are_refused():
+    """a slot that took a contribution IN PLACE (functional._grad_acc) while autograd assembled the parameter's
+    .grad elsewhere (a contribution in between arrived as a tensor of its own) must not be overwritten by that sum: _land raises
+    instead of dropping the in-place part silently."""
+    import pytest
+    import torch
+    from saragan_amd import functional as F
+    from saragan_amd.optimization import StepGraph
+    flat = torch.zeros(32)
+    w = torch.nn.Parameter(torch.ones(2, 3))
+    slot = flat[8:14].view(2, 3)
+    slots = {id(w): slot}
+    with F.grads_into({w.data_ptr(): slot}):
+        with torch.no_grad():
+            first = F._grad_out(w.data_ptr(), (2, 3))            # V1: written by a kernel into the slot, handed to autograd
+            first.fill_(1.0)
+            w.grad = first + 2.0                                  # the engine summed V1 + T2 out of place: .grad is elsewhere
+            acc = F._grad_acc(w.data_ptr(), (2, 3))               # a third contribution goes into the slot in place
+            acc.add_(4.0)
+            F._note_accumulated(w.data_ptr())                     # (what the accumulating kernel's caller records)
+            with pytest.raises(RuntimeError, match='in place'):
+                StepGraph._land(w, slots)
+    w.grad = None
+    with F.grads_into({w.data_ptr(): slot}):                      # without the in-place part the sum is simply copied in
+        with torch.no_grad():
+            F._grad_out(w.data_ptr(), (2, 3)).fill_(1.0)
+            w.grad = slot + 2.0
+            StepGraph._land(w, slots)
+    assert w.grad is slot and torch.equal(slot, torch.full((2, 3), 3.0))
+
+
 def test_packed_image_cache_states():
     """functional.mark_packs_stale / clear_pack_cache (host logic only)."""
     from saragan_amd import functional as F

@@ -366,3 +366,34 @@ def test_a_step_leaves_no_device_memory_in_reference_cycles(golden_dir, dtype):
             gc.enable()
     assert not held, [tuple(t.shape) for t in held]
     assert after == base, (base, after)
+
+
+def test_ema_swap_is_seen_by_the_packed_weight_images(golden_dir):
+    """assign_ema_weights / restore_original_weights / ema_update_weights (ExtendedEMA.py:24-59 of the reference)
+    write the flat parameter buffer in place; the parameters alias it, so neither data_ptr nor the version counter the packed
+    weight images are keyed by moves.  Every such writer marks the images stale itself: the generator evaluated under the EMA
+    weights with FIXED latents equals an evaluation with freshly packed images, differs from the one under the training weights,
+    and the restore brings that one back bit for bit."""
+    from saragan_amd import functional as F
+    fx = load_step_fixture(os.path.join(golden_dir, 'oracle_step_p3_wgan_a000.npz'), torch.float64)
+    for dtype in (torch.float32, torch.bfloat16):
+        store, tup, ph, ema, sess = _build(fx, dtype)
+        train_gen, train_disc, gen_sample = tup[0], tup[1], tup[5]
+        ema_op = ema.apply()
+        feed = {ph: fx['real'].float()}
+        for _ in range(3):      # the weights leave their shadows behind
+            sess.run([train_gen, train_disc], feed_dict=feed)
+            sess.run(ema_op)
+        a = sess.run(gen_sample, feed_dict=feed).float().clone()            # (refreshes the images from the training weights)
+        sess.run(ema.assign_ema_weights())
+        b = sess.run(gen_sample, feed_dict=feed).float().clone()
+        F.clear_pack_cache()
+        b_ref = sess.run(gen_sample, feed_dict=feed).float().clone()
+        assert torch.equal(b, b_ref), f'{dtype}: the generator under EMA weights ran on stale weight images'
+        assert not torch.equal(a, b)
+        sess.run(ema.restore_original_weights())
+        c = sess.run(gen_sample, feed_dict=feed).float().clone()
+        assert torch.equal(c, a), f'{dtype}: restore_original_weights not seen'
+        sess.run(ema.ema_update_weights())
+        d = sess.run(gen_sample, feed_dict=feed).float().clone()
+        assert torch.equal(d, b), f'{dtype}: ema_update_weights not seen'

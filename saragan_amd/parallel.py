@@ -173,15 +173,28 @@ class GradientAllReducer:
             else:
                 self._handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    @staticmethod
+    def rs_ag_plan(numel, world, rank):
+        """Chunk arithmetic of the in-place reduce-scatter + all-gather of a bucket of `numel` elements: (chunk, body, lo, hi):
+        the first `body` = chunk * world elements are split into `world` equal chunks, rank r owns [lo, hi) = [r * chunk,
+        (r + 1) * chunk); the tail [body, numel) (fewer than `world` elements) goes through a plain all_reduce."""
+        chunk = numel // world
+        return chunk, chunk * world, rank * chunk, (rank + 1) * chunk
+
     def _launch_rs_ag(self, view):
-        """The same sum as all_reduce(view), as reduce-scatter + all-gather in place: rank r reduces the r-th of `world`
+        """The same sum as all_reduce(view), as reduce-scatter + all-gather IN PLACE: rank r reduces the r-th of `world`
         equal chunks into its own slot of the bucket, then every rank gathers all slots.  A tail that does not divide by
-        the world size (< world elements) goes through a plain all_reduce."""
+        the world size (< world elements) goes through a plain all_reduce.
+        The output of the reduce-scatter aliases its input at exactly the offset NCCL / RCCL document as their in-place form
+        (ncclReduceScatter: "in-place operation will happen if recvbuff == sendbuff + rank * recvcount"; ncclAllGather:
+        "sendbuff == recvbuff + rank * sendcount"): asserted below, so a change of the chunk arithmetic cannot turn it into an
+        undefined overlap."""
         w = self.world_size
-        chunk = view.numel() // w
+        chunk, nbody, lo, hi = self.rs_ag_plan(view.numel(), w, self.rank)
         if chunk:
-            body = view[:chunk * w]
-            mine = body[self.rank * chunk:(self.rank + 1) * chunk]
+            body = view[:nbody]
+            mine = body[lo:hi]
+            assert mine.data_ptr() == body.data_ptr() + self.rank * chunk * body.element_size() and mine.numel() * w == body.numel()
             h = dist.reduce_scatter_tensor(mine, body, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             if not self._ordered:
                 h.wait()
@@ -201,6 +214,16 @@ class GradientAllReducer:
             b['left'] -= 1
             if b['left'] == 0 and not b['launched']:
                 self._launch(b)
+
+    def launch_all(self):
+        """Launches every bucket that has not gone out yet WITHOUT waiting (the captured step: a replayed segment has completed
+        this network's gradients; the next segment is replayed while these run).  Returns the number launched."""
+        n = 0
+        for b in self._buckets:
+            if not b['launched']:
+                self._launch(b)
+                n += 1
+        return n
 
     def finish(self):
         self._armed = False

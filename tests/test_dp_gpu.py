@@ -158,6 +158,7 @@ def _worker_captured(rank, world, port, golden, q):
         sess = opt.Session('cuda')
         g = torch.Generator().manual_seed(9 + rank)
         losses = []
+        graph._issue_log = []          # host-side issue order of the replayed segments and their bucket collectives
         for i in range(5):
             real = (fx['real'][rank * n:(rank + 1) * n].float() + 0.1 * torch.randn((n, *fx['real'].shape[1:]), generator=g)).cuda()
             _, _, dl = sess.run([tup[0], tup[1], tup[3]], feed_dict={ph: real})
@@ -165,7 +166,7 @@ def _worker_captured(rank, world, port, golden, q):
             losses.append(float(dl))
         torch.cuda.synchronize()
         ncap = sum(1 for e in graph.__dict__.get('_captures', {}).values() if 'graph' in e)
-        out[mode] = (ncap, losses, {k: v.detach().cpu().numpy() for k, v in store.vars.items()})
+        out[mode] = (ncap, losses, {k: v.detach().cpu().numpy() for k, v in store.vars.items()}, list(graph._issue_log))
     q.put((rank, out))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
@@ -187,10 +188,17 @@ def test_captured_step_with_a_gradient_reducer_attached(golden_dir):
         p.join(timeout=120)
         assert p.exitcode == 0
     for r in range(world):
-        (n0, l0, w0), (n1, l1, w1) = res[r]['0'], res[r]['1']
+        (n0, l0, w0, log0), (n1, l1, w1, log1) = res[r]['0'], res[r]['1']
         assert n0 == 0 and n1 == 1, (n0, n1)
         assert l0 == l1, (l0, l1)
         for k in w0:
             np.testing.assert_array_equal(w0[k], w1[k], err_msg=f'rank {r} {k}')
+        # round 5: the step is captured as two segments ([forward + discriminator backward] [generator backward]); every replay
+        # issues segment 0, the discriminator's bucket collectives, segment 1 (which overlaps them), the generator's collectives
+        assert log0 == [] and len(log1) == 3 * 4, log1
+        for i in range(0, len(log1), 4):
+            a, b, c, d = log1[i:i + 4]
+            assert a == ('segment', 0) and c == ('segment', 1), log1[i:i + 4]
+            assert b[:2] == ('buckets', 0) and d[:2] == ('buckets', 1) and b[3] >= 1 and d[3] >= 1 and b[2] != d[2], log1[i:i + 4]
     for k in res[0]['1'][2]:
         np.testing.assert_array_equal(res[0]['1'][2][k], res[1]['1'][2][k])

@@ -365,3 +365,57 @@ def test_packed_image_cache_states():
     assert F._PACK_STATE['stale'] is True and ('rgbmat', 1) not in F._PACK_CACHE and len(F._PACK_CACHE) == 1
     F.clear_pack_cache()
     assert not F._PACK_CACHE and F._PACK_STATE['stale'] is False
+
+
+def test_rs_ag_chunk_arithmetic_with_a_fake_collective(monkeypatch):
+    """parallel.GradientAllReducer._launch_rs_ag at world 2 / 4 / 8 with the three collectives replaced by recorders (no process
+    group): every rank's reduce-scatter output is the slice of its OWN bucket at offset rank * chunk (NCCL's documented in-place
+    form), the all-gather writes the whole body from that slice, the tail (< world elements) goes through all_reduce -- and
+    executing the recorded calls with their collective semantics leaves the plain sum in every rank's bucket."""
+    import torch
+    from saragan_amd import parallel
+    calls = []
+
+    class H:
+        def wait(self):
+            pass
+    monkeypatch.setattr(parallel.dist, 'reduce_scatter_tensor', lambda out, inp, op=None, group=None, async_op=False: calls.append(('rs', out, inp)) or H())
+    monkeypatch.setattr(parallel.dist, 'all_gather_into_tensor', lambda out, inp, group=None, async_op=False: calls.append(('ag', out, inp)) or H())
+    monkeypatch.setattr(parallel.dist, 'all_reduce', lambda t, op=None, group=None, async_op=False: calls.append(('ar', t, t)) or H())
+    for world in (2, 4, 8):
+        for numel in (world * 5, world * 5 + 3, world - 1, 1000):
+            torch.manual_seed(world * 1000 + numel)
+            bufs = [torch.randn(numel) for _ in range(world)]
+            want = torch.stack(bufs).sum(0)
+            per_rank = []
+            for r in range(world):
+                red = object.__new__(parallel.GradientAllReducer)
+                red.world_size, red.rank, red.group, red._ordered, red._handles = world, r, None, True, []
+                chunk, body, lo, hi = red.rs_ag_plan(numel, world, r)
+                assert body + (numel - body) == numel and 0 <= numel - body < world and hi - lo == chunk and hi <= body
+                calls.clear()
+                red._launch_rs_ag(bufs[r])
+                per_rank.append(list(calls))
+                kinds = [c[0] for c in calls]
+                assert kinds == (['rs', 'ag'] if chunk else []) + (['ar'] if numel > body else []), (world, numel, kinds)
+                if chunk:
+                    _, out, inp = calls[0]
+                    assert inp.data_ptr() == bufs[r].data_ptr() and inp.numel() == body
+                    assert out.data_ptr() == inp.data_ptr() + r * chunk * 4 and out.numel() == chunk          # in place, NCCL's offset
+                    _, gout, ginp = calls[1]
+                    assert gout.data_ptr() == inp.data_ptr() and gout.numel() == body and ginp.data_ptr() == out.data_ptr()
+            # execute the recorded collectives: reduce-scatter on all ranks, then the all-gathers, then the tails
+            chunk = numel // world
+            if chunk:
+                snap = [c[0][2].clone() for c in per_rank]
+                for r in range(world):
+                    per_rank[r][0][1].copy_(sum(sn[r * chunk:(r + 1) * chunk] for sn in snap))
+                mine = [per_rank[r][0][1].clone() for r in range(world)]
+                for r in range(world):
+                    per_rank[r][1][1].copy_(torch.cat(mine))
+            if numel > chunk * world:
+                tails = [c[-1][1].clone() for c in per_rank]
+                for r in range(world):
+                    per_rank[r][-1][1].copy_(sum(tails))
+            for r in range(world):
+                assert torch.allclose(bufs[r], want, atol=1e-5), (world, numel, r)

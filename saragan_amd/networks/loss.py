@@ -65,18 +65,30 @@ class StaticRandom:
     counter that the captured launches advance themselves.  `after_replay()` keeps `base.calls` in step, so that an eager
     step that follows continues the same sequence."""
 
-    def __init__(self, base, n, latent_dim, device):
+    def __init__(self, base, n, latent_dim, device, pattern=('z', 'g')):
+        # pattern: the step's draws in the order the eager step makes them ('z': latents, 'g': mixing weights) -- ('z', 'g') for a
+        # `simultaneous` step, ('z', 'g', 'z') for `alternate` (forward_discriminator, then forward_generator draws its own latents)
         self.base, self.n, self.latent_dim = base, int(n), int(latent_dim)
-        self.z = torch.empty(self.n, self.latent_dim, device=device)
-        self.g = torch.empty(self.n, 1, 1, 1, 1, device=device)
+        self.pattern = tuple(pattern)
+        self.zs = [torch.empty(self.n, self.latent_dim, device=device) for k in self.pattern if k == 'z']
+        self.gs = [torch.empty(self.n, 1, 1, 1, 1, device=device) for k in self.pattern if k == 'g']
+        self.z, self.g = self.zs[0], self.gs[0]
+        self._iz = self._ig = 0
         self.counter = torch.zeros(1, dtype=torch.int64, device=device)
         self.noise_calls = 0         # add_noise calls of one step (counted while capturing)
         self.counting = False
 
     def draw(self):
         # (straight into the fixed buffers: the same draws from the same generator as RandomSource.latent / .gamma)
-        torch.randn(self.n, self.latent_dim, generator=self.base.gen, out=self.z)
-        torch.rand(self.n, 1, 1, 1, 1, generator=self.base.gen, out=self.g)
+        iz = ig = 0
+        for k in self.pattern:
+            if k == 'z':
+                torch.randn(self.n, self.latent_dim, generator=self.base.gen, out=self.zs[iz])
+                iz += 1
+            else:
+                torch.rand(self.n, 1, 1, 1, 1, generator=self.base.gen, out=self.gs[ig])
+                ig += 1
+        self._iz = self._ig = 0
 
     def sync_counter(self):
         if getattr(self, '_synced_calls', None) != self.base.calls:      # (only after eager steps moved the host count on)
@@ -84,11 +96,15 @@ class StaticRandom:
 
     def latent(self, n, latent_dim, device):
         assert (int(n), int(latent_dim)) == (self.n, self.latent_dim)
-        return self.z
+        z = self.zs[min(self._iz, len(self.zs) - 1)]
+        self._iz += 1
+        return z
 
     def gamma(self, n, device):
         assert int(n) == self.n
-        return self.g
+        g = self.gs[min(self._ig, len(self.gs) - 1)]
+        self._ig += 1
+        return g
 
     def add_noise(self, x, stddev, tag):
         if self.counting:

@@ -214,15 +214,21 @@ def get_weight(shape, activation, lrmul=1, use_eq_lr=True, use_spectral_norm=Fal
     runtime_coef = he_std * lrmul
     if use_spectral_norm:
         raise NotImplementedError('spectral_norm is not used by the pgan path')
-    w = get_variable('weight', shape, 'normal')   # init_std = 1/lrmul with lrmul = 1 (ops.py:115,118-119)
-    if lrmul != 1:
-        raise NotImplementedError('lrmul != 1 is not used by the pgan path')
+    from ..varstore import current_store, scope_name
+    full = (scope_name() + '/weight') if scope_name() else 'weight'
+    fresh = full not in current_store().vars
+    w = get_variable('weight', shape, 'normal')
+    if fresh and lrmul != 1:      # init_std = 1 / lrmul (ops.py:115,118-119); the coefficient below carries lrmul back in
+        with torch.no_grad():
+            w.mul_(1.0 / lrmul)
     return ScaledWeight(w, runtime_coef if use_eq_lr else 1.0)
 
 
 def apply_bias(x, lrmul=1):
     """networks/ops.py:130-136."""
     b = get_variable('bias', [x.shape[1]], 'zeros')
+    if lrmul != 1:                # ops.py:131: the variable times lrmul (a [C]-sized torch op; pgan never passes it)
+        b = b * float(lrmul)
     if isinstance(x, _LazyConv) and x.stage == 0 and x._v is None:
         x.bias, x.stage = b, 1
         return x

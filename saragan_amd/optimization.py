@@ -265,18 +265,11 @@ class StepGraph:
                     for tid, info in pend:
                         self._finish(tid, info, out, apply=tid in want_train)
             else:                               # alternate: D step, then G forward on the updated D
-                d_ids = [t for t in train_ids if self.trains[t]['net'] == 'discriminator']
-                g_ids = [t for t in train_ids if self.trains[t]['net'] == 'generator']
-                disc_loss, gp_loss = forward_discriminator(c['generator'], c['discriminator'], real, *net_args,
-                                                           c['gp_weight'], c['noise_stddev'])
-                out.update(disc_loss=disc_loss, gp_loss=gp_loss)
-                for tid in d_ids:
-                    self._finish(tid, self._backward(tid, out), out, apply=tid in want_train)
-                gen_sample, gen_loss = forward_generator(c['generator'], c['discriminator'], real, *net_args,
-                                                         c['noise_stddev'], is_reuse=True)
-                out.update(gen_sample=gen_sample, gen_loss=gen_loss)
-                for tid in g_ids:
-                    self._finish(tid, self._backward(tid, out), out, apply=tid in want_train)
+                no_dist = all(self.trains[t]['optimizer'].distributed is None for t in train_ids)
+                if no_dist and self._capturable(train_ids, real):
+                    out = self._replay_or_capture(real, train_ids, want_train, net_args, alpha, strategy='alternate')
+                else:
+                    self._compute_alternate(real, train_ids, want_train, net_args, out)
         static = out.pop('__static__', False)     # a replayed graph's outputs live in buffers the next replay overwrites
         self.last = None if static else out
 
@@ -294,6 +287,24 @@ class StepGraph:
                 v = out[f.key]
                 res.append(own(v.detach()) if torch.is_tensor(v) else v)
         return res
+
+    def _compute_alternate(self, real, train_ids, want_train, net_args, out, lr_dev=None, marks=None):
+        """One 'alternate' step (optimization.py:166-216 of the reference): the discriminator is updated from forward_discriminator's
+        loss; the generator loss is then built on the UPDATED discriminator and the generator is updated."""
+        c = self.cfg
+        lr_dev = lr_dev or {}
+        d_ids = [t for t in train_ids if self.trains[t]['net'] == 'discriminator']
+        g_ids = [t for t in train_ids if self.trains[t]['net'] == 'generator']
+        disc_loss, gp_loss = forward_discriminator(c['generator'], c['discriminator'], real, *net_args,
+                                                   c['gp_weight'], c['noise_stddev'])
+        out.update(disc_loss=disc_loss, gp_loss=gp_loss)
+        for tid in d_ids:
+            self._finish(tid, self._backward(tid, out), out, apply=tid in want_train, lr_dev=lr_dev.get(tid), marks=marks)
+        gen_sample, gen_loss = forward_generator(c['generator'], c['discriminator'], real, *net_args,
+                                                 c['noise_stddev'], is_reuse=True)
+        out.update(gen_sample=gen_sample, gen_loss=gen_loss)
+        for tid in g_ids:
+            self._finish(tid, self._backward(tid, out), out, apply=tid in want_train, lr_dev=lr_dev.get(tid), marks=marks)
 
     def _compute_simultaneous(self, real, train_ids, net_args, out, arm_dist=True, between=None):
         """Forward pass and both backward passes of a 'simultaneous' step (no optimizer): fills `out`, returns the per-net
@@ -371,12 +382,12 @@ class StepGraph:
             raise RuntimeError(f'{len(held)} parameter(s) still have an AccumulateGrad node owned by a live autograd graph '
                                f'(first: #{held[0]}): drop the previous step\'s outputs before a step is captured')
 
-    def _replay_or_capture(self, real, train_ids, want_train, net_args, alpha):
+    def _replay_or_capture(self, real, train_ids, want_train, net_args, alpha, strategy='simultaneous'):
         from .networks import loss as L
         alpha_class = 'mix' if 0.0 < alpha < 1.0 else float(alpha)
         norms = tuple(sorted(t for t in train_ids if ('max_norm', t) in self._wanted))
         dist_ids = tuple(t for t in train_ids if self.trains[t]['optimizer'].distributed is not None)
-        key = (tuple(train_ids), tuple(sorted(want_train)), norms, alpha_class, tuple(real.shape), str(compute_dtype()))
+        key = (tuple(train_ids), tuple(sorted(want_train)), norms, alpha_class, tuple(real.shape), str(compute_dtype()), strategy)
         caps = self.__dict__.setdefault('_captures', {})
         ent = caps.get(key)
         if ent is None:
@@ -387,6 +398,9 @@ class StepGraph:
 
         def eager():
             out = {}
+            if strategy == 'alternate':
+                self._compute_alternate(real, train_ids, want_train, net_args, out)
+                return out
             pend = self._compute_simultaneous(real, train_ids, net_args, out)
             for tid, info in pend:
                 self._finish(tid, info, out, apply=tid in want_train)
@@ -429,7 +443,8 @@ class StepGraph:
                 old = min((k for k, e in caps.items() if 'graph' in e), key=lambda k: caps[k]['used'])
                 del caps[old]
             ent['real'] = real.clone()
-            ent['rnd'] = L.StaticRandom(base, real.shape[0], self.cfg['latent_dim'], real.device)
+            ent['rnd'] = L.StaticRandom(base, real.shape[0], self.cfg['latent_dim'], real.device,
+                                        pattern=('z', 'g', 'z') if strategy == 'alternate' else ('z', 'g'))
             ent['rnd'].draw()
             ent['rnd'].sync_counter()
             sc = ent['scalars'] = F.DevScalars(real.device, 8)
@@ -463,7 +478,11 @@ class StepGraph:
                 pool = self.__dict__.get('_cap_pool')
                 if pool is None:
                     pool = self.__dict__['_cap_pool'] = torch.cuda.graph_pool_handle()
-                if not dist_ids:
+                if strategy == 'alternate':      # (no reducer attached: run() checked) the two half-steps in one graph: the second one's
+                    with torch.cuda.graph(g, pool=pool):      # first convolution refreshes the weight images from the updated D
+                        self._compute_alternate(ent['real'], train_ids, want_train, tuple(args), ent['out'], lr_dev=lr_dev, marks=marks)
+                    ent['pend'] = []
+                elif not dist_ids:
                     with torch.cuda.graph(g, pool=pool):
                         ent['pend'] = self._compute_simultaneous(ent['real'], train_ids, tuple(args), ent['out'], arm_dist=False)
                         for tid, info in ent['pend']:

@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 NAME = 'oracle_step_p3_wgan_a000.npz'
 
 
-def _run(golden_dir, steps, dtype, captured, mixing=False, clipping=False, keep=False, reload_at=None, run_ahead=False, alpha_step=0.11):
+def _run(golden_dir, steps, dtype, captured, mixing=False, clipping=False, keep=False, reload_at=None, run_ahead=False, alpha_step=0.11, strategy='simultaneous'):
     import saragan_amd.optimization as opt
     from saragan_amd.ExtendedEMA import ExtendedEMA
     from saragan_amd.networks import loss as L
@@ -46,7 +46,7 @@ def _run(golden_dir, steps, dtype, captured, mixing=False, clipping=False, keep=
         with use_store(store):
             tup = opt.optimize_step(og, od, generator, discriminator, ph, LATENT, alpha, fx['phase'],
                                     BASE_SHAPE, KERNEL_SPEC, FILTER_SPEC, 'leaky_relu', 0.2, 'wgan', fx['cfg']['gp_weight'],
-                                    'simultaneous', clipping, clipping, 0.01, freeze)
+                                    strategy, clipping, clipping, 0.01, freeze)
         store.load_state_dict(dict(fx['p0']), strict=True)
         ema = ExtendedEMA(list(store.vars.keys()), 0.99, graph=tup[0].graph)
         ema_op = ema.apply()
@@ -136,6 +136,25 @@ def test_replays_that_run_ahead_of_the_device_read_their_own_scalars(golden_dir)
         saragan_amd.set_deterministic(False)
     assert n0 == 0 and n1 == 1, (n0, n1)
     assert l0 == l1, [(i, a, b) for i, (a, b) in enumerate(zip(l0, l1)) if a != b][:4]
+    bad = [k for k in w0 if not torch.equal(w0[k], w1[k])]
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('mixing', [False, True])
+def test_captured_alternate_step_equals_eager(golden_dir, mixing):
+    """--optim_strategy alternate (optimization.py:166-216 of the reference: D step, then the generator loss on the UPDATED
+    discriminator) captured as one graph: the second half-step's first convolution refreshes the weight images from the weights the
+    first half-step's optimiser launch wrote, the two forward passes draw their own latents (StaticRandom's pattern z, g, z).
+    Bit-identical to the eager run, stabilising and mixing (freeze train ops, alpha and the step sizes moving every step)."""
+    import saragan_amd
+    saragan_amd.set_deterministic(True)
+    try:
+        w0, l0, n0 = _run(golden_dir, 6, torch.float32, captured=False, mixing=mixing, strategy='alternate')
+        w1, l1, n1 = _run(golden_dir, 6, torch.float32, captured=True, mixing=mixing, strategy='alternate')
+    finally:
+        saragan_amd.set_deterministic(False)
+    assert n0 == 0 and n1 == 1, (n0, n1)
+    assert l0 == l1, (l0, l1)
     bad = [k for k in w0 if not torch.equal(w0[k], w1[k])]
     assert not bad, bad
 

@@ -397,3 +397,35 @@ def test_ema_swap_is_seen_by_the_packed_weight_images(golden_dir):
         sess.run(ema.ema_update_weights())
         d = sess.run(gen_sample, feed_dict=feed).float().clone()
         assert torch.equal(d, b), f'{dtype}: ema_update_weights not seen'
+
+
+def test_lrmul_enters_the_packed_coefficient():
+    """networks/ops.py:111-136 of the reference: a layer built with lrmul = m draws its weight with std 1 / m and multiplies it
+    (and the bias) with m at run time.  Here m rides in the coefficient the weight-pack kernel applies: a layer with lrmul 2 equals the
+    lrmul-1 layer whose variables hold twice the values -- output and variable gradients (which carry the factor m)."""
+    from saragan_amd.networks import ops
+    from saragan_amd.varstore import VariableStore, set_compute_dtype, use_store
+    set_compute_dtype(torch.float32)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 8, 4, 8, 8, generator=g).cuda().contiguous(memory_format=torch.channels_last_3d)
+    outs, grads = [], []
+    sa, sb = VariableStore('cuda', seed=5), VariableStore('cuda', seed=5)
+    for store, m in ((sa, 2), (sb, 1)):
+        with use_store(store), ops.variable_scope('layer'):
+            y = ops.act(ops.apply_bias(ops.conv3d(x, 16, (3, 3, 3), 'leaky_relu', param=0.2, lrmul=m), lrmul=m), 'leaky_relu', 0.2)
+            if m == 2:
+                with torch.no_grad():
+                    assert abs(float(store.vars['layer/weight'].std()) - 0.5) < 0.05      # init_std = 1 / lrmul
+                    store.vars['layer/bias'].copy_(torch.randn(16, generator=g).cuda())
+            else:
+                with torch.no_grad():      # the same function with lrmul = 1: variables twice as large
+                    store.vars['layer/weight'].copy_(2.0 * sa.vars['layer/weight'])
+                    store.vars['layer/bias'].copy_(2.0 * sa.vars['layer/bias'])
+        with use_store(store), ops.variable_scope('layer'):
+            y = ops._val(ops.act(ops.apply_bias(ops.conv3d(x, 16, (3, 3, 3), 'leaky_relu', param=0.2, lrmul=m), lrmul=m), 'leaky_relu', 0.2))
+        gw, gb = torch.autograd.grad(y.float().square().sum(), [store.vars['layer/weight'], store.vars['layer/bias']])
+        outs.append(y.detach().float().cpu())
+        grads.append((gw.detach().cpu(), gb.detach().cpu()))
+    np.testing.assert_allclose(outs[0].numpy(), outs[1].numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(grads[0][0].numpy(), 2.0 * grads[1][0].numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(grads[0][1].numpy(), 2.0 * grads[1][1].numpy(), rtol=1e-4, atol=1e-4)

@@ -121,6 +121,28 @@ typedef struct {
   const void* in_mask_bits;
   float in_mask_slope;
   float in_gain;
+  /* to_rgb (networks/ops.py:239-240, pgan/generator.py:96-97: a 1x1x1 convolution to ONE image channel) of this convolution's
+   * output inside its epilogue: rgb_out[n,d,h,w,1] = sum_c y[..,c] * rgb_w[c] + rgb_bias[0] with y as it is stored (rounded to dt)
+   * and rgb_w the [cout] f32 values to_rgb's forward multiplies with -- the full-resolution stage output is not read again for the
+   * image.  With pixel_norm + act + sign_out, cout == 32, the 32-input-channel 3x3x3 kernel's shapes (bf16, w % 32 == 0);
+   * otherwise SG_EUNSUPPORTED (run sg_conv3d_fwd on y).  rgb_out NULL: off. */
+  const float* rgb_w;
+  const float* rgb_bias;
+  void* rgb_out;
+  /* from_rgb's WHOLE backward (networks/ops.py:243-247, pgan/discriminator.py:9-12: 1x1x1 from ONE image channel, bias, LeakyReLU)
+   * in the epilogue of the data-gradient convolution that produces the gradient g of its output (mask_bits = from_rgb's sign
+   * words): pw_dx[n,d,h,w,1] = sum_c g_c * pw_wmat[c] (optional), pw_dw[c] = pw_coef * sum_v pw_x[v] * g[v][c], pw_dbias[c] =
+   * sum_v g[v][c] (each optional), g as it would have been stored (rounded to dt) -- and y is NOT written (y may be NULL): the
+   * 32-channel gradient, the largest tensor of the discriminator's backward, is needed by nobody else.  workspace must hold
+   * sg_conv3d_pw_epilogue_workspace() bytes (per-wave partial sums, added in a fixed order).  Same kernel and shapes as rgb_*
+   * (cout == 32, no bias / activation / pooling); otherwise SG_EUNSUPPORTED (run the convolution, then sg_conv3d_pw_bwd).
+   * pw_x NULL: off. */
+  const void* pw_x;
+  const float* pw_wmat;
+  void* pw_dx;
+  float* pw_dw;
+  float* pw_dbias;
+  float pw_coef;
 } sg_conv_epilogue;
 
 /* Sign words of an NDHWC tensor t[nvox][c]: uint32 words[nvox][ceil(c/32)], bit j of word (v, k) = (t[v][32k+j] < 0),
@@ -146,6 +168,7 @@ int sg_conv3d_pack_weights_batch(int n, const float* const* w_dhwio, const float
                                  void* const* wp, const sg_conv_shape* shapes, sg_dtype dt, sg_stream_t st);
 /* Bytes of sg_conv_epilogue.workspace that let this shape take its fastest path (0: none needed). */
 size_t sg_conv3d_fwd_workspace(const sg_conv_shape* s, sg_dtype dt);
+size_t sg_conv3d_pw_epilogue_workspace(void);     /* bytes of sg_conv_epilogue.workspace for the pw_* epilogue */
 /* y = epilogue(conv3d(x, wp)).  x: [n,d,h,w,cin] (or half-res if upsample_in), y: [n,d,h,w,cout]. */
 int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_conv_shape* s,
                   const sg_conv_epilogue* ep, sg_dtype dt, sg_stream_t st);

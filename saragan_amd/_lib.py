@@ -28,7 +28,9 @@ class ConvEpilogue(C.Structure):
                 ('tap_off', C.c_int32 * 3), ('pool', C.c_int32), ('workspace', C.c_void_p),
                 ('workspace_bytes', C.c_size_t), ('x_plane_channels', C.c_int32), ('pn_bwd_y', C.c_void_p),
                 ('pn_bwd_scale', C.c_void_p), ('in_mask_bits', C.c_void_p), ('in_mask_slope', C.c_float),
-                ('in_gain', C.c_float)]
+                ('in_gain', C.c_float), ('rgb_w', C.c_void_p), ('rgb_bias', C.c_void_p), ('rgb_out', C.c_void_p),
+                ('pw_x', C.c_void_p), ('pw_wmat', C.c_void_p), ('pw_dx', C.c_void_p), ('pw_dw', C.c_void_p),
+                ('pw_dbias', C.c_void_p), ('pw_coef', C.c_float)]
 
     def __init__(self, *args, **kw):
         super().__init__(C.sizeof(type(self)), *args, **kw)
@@ -50,6 +52,7 @@ SIGNATURES = {
     'sg_conv3d_pack_weights': (C.c_int, [_p, _f, C.c_int, _p, _SHP, C.c_int, _p]),
     'sg_conv3d_pack_weights_batch': (C.c_int, [C.c_int, _p, _p, _p, _p, _p, C.c_int, _p]),
     'sg_conv3d_fwd_workspace': (_sz, [_SHP, C.c_int]),
+    'sg_conv3d_pw_epilogue_workspace': (_sz, []),
     'sg_conv3d_fwd': (C.c_int, [_p, _p, _p, _SHP, C.POINTER(ConvEpilogue), C.c_int, _p]),
     'sg_upconv3d_subpixel_supported': (C.c_int, [_SHP, C.c_int]),
     'sg_upconv3d_subpixel_packed_bytes': (_sz, [_SHP, C.c_int]),

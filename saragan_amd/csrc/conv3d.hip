@@ -2889,6 +2889,8 @@ static int launch_pw_fwd(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st,
 unsigned long long* g_dbg_ts = nullptr;   // in-kernel phase stamps (tools/ts_conv.py, tools/ts_wgrad.py); also read by wgrad.hip
 extern "C" __attribute__((visibility("default"))) void sg_debug_set_ts_buffer(void* p) { g_dbg_ts = (unsigned long long*)p; }
 
+extern "C" size_t sg_conv3d_pw_epilogue_workspace(void) { return (size_t)SG_PW_PART_ROWS * 64 * sizeof(float); }
+
 extern "C" size_t sg_conv3d_fwd_workspace(const sg_conv_shape* s, sg_dtype dt) {
   if (!conv_shape_ok(s) || dt != SG_BF16) return 0;
   if (!sg_cfg().no_gemm && sg_gemm_conv_eligible(s, dt)) return sg_gemm_conv_workspace(s, dt);   // K-split partial tiles
@@ -2900,7 +2902,7 @@ extern "C" size_t sg_conv3d_fwd_workspace(const sg_conv_shape* s, sg_dtype dt) {
 
 extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_conv_shape* s,
                              const sg_conv_epilogue* ep, sg_dtype dt, sg_stream_t st) {
-  if (!conv_shape_ok(s) || !x || !wp || !y) return SG_EINVAL;
+  if (!conv_shape_ok(s) || !x || !wp || (!y && !(ep && ep->pw_x))) return SG_EINVAL;
   if (ep && ep->struct_size != (uint32_t)sizeof(sg_conv_epilogue)) return SG_EINVAL;   // caller built against another header
   if (!sg_aligned16(x) || !sg_aligned16(wp) || !sg_aligned16(y)) return SG_EALIGN;
   ConvFwdArgs a;
@@ -2929,6 +2931,15 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
                     !sg_aligned16(a.in_mask) || !sg_is_pow2f(a.in_gain)))
     return a.in_mask && !sg_aligned16(a.in_mask) ? SG_EALIGN : SG_EUNSUPPORTED;     // only the two-pass 64 -> 32 path masks its gather;
                                                                                    // the gain must be a power of two (sg_mask_piece_bf16)
+  a.rgb_w = ep ? ep->rgb_w : nullptr; a.rgb_bias = ep ? ep->rgb_bias : nullptr; a.rgb_out = ep ? ep->rgb_out : nullptr;
+  a.pw_x = ep ? ep->pw_x : nullptr; a.pw_wmat = ep ? ep->pw_wmat : nullptr; a.pw_dx = ep ? ep->pw_dx : nullptr;
+  a.pw_part = (ep && ep->pw_x) ? reinterpret_cast<float*>(ep->workspace) : nullptr;
+  if (a.rgb_out && (!a.rgb_w || !sg_aligned16(a.rgb_out))) return SG_EINVAL;
+  if (a.pw_x && (!a.pw_wmat || !ep->workspace || ep->workspace_bytes < sg_conv3d_pw_epilogue_workspace() || !sg_aligned16(ep->workspace)))
+    return SG_EINVAL;
+  if ((a.rgb_out || a.pw_x) && (dt != SG_BF16 || s->kd != 3 || s->kh != 3 || s->kw != 3 || s->cin != 32 || s->cout != 32 || s->upsample_in ||
+                                !sg_cfg().fwd3s_16 || sg_cfg().fwd_no_v3 || sg_cfg().fwd_no_v3s || sg_cfg().fwd_v1 || ep->x_plane_channels))
+    return SG_EUNSUPPORTED;      // these epilogues exist in conv_fwd3w only
   a.os = (ep && ep->out_scale == 2) ? 2 : 1;
   a.oa = ep ? ep->out_off[0] : 0; a.ob = ep ? ep->out_off[1] : 0; a.oc = ep ? ep->out_off[2] : 0;
   const bool subpixel = a.os == 2 || a.tap_d || a.tap_h || a.tap_w || s->kd == 2;
@@ -3044,9 +3055,13 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     if (xpl || a.in_mask) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }
     if (dt == SG_BF16 && k333 && !sg_cfg().fwd_no_v3s) {   // sliding-halo variant where its tile fits
       if (a.nchunk == 2 && sg_cfg().fwd3s_16) {              // ... as wave-private planes + sliding accumulators on 16x16x32 (conv3w.hip)
-        rc = sg_launch_fwd3w(a, s, hs, &used);
+        int pw_rows = 0;
+        rc = sg_launch_fwd3w(a, s, hs, &used, &pw_rows);
+        if (rc == SG_OK && used && a.pw_x)      // the per-wave rows of the fused from_rgb backward, added in order
+          rc = sg_pw_wgrad_finalize(a.pw_part, pw_rows, ep->pw_dw, ep->pw_dbias, ep->pw_coef, hs);
         if (rc != SG_OK || used) { prof.done(rc); return rc; }
       }
+      if (a.rgb_out || a.pw_x) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }      // (only that kernel has these epilogues)
       if (a.nchunk == 2) rc = launch_fwd3s<2>(a, s, hs, &used);
       else if (a.nchunk == 1) rc = launch_fwd3s<1>(a, s, hs, &used);
       if (rc != SG_OK || used) { prof.done(rc); return rc; }

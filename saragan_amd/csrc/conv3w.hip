@@ -39,7 +39,11 @@ constexpr int W3_HALO = W3_HROWS * 64;            // 8 704 B
 constexpr int W3_HOFF = W3_WBYTES;
 constexpr int W3_BOFF = W3_HOFF + 8 * W3_HALO;
 constexpr int W3_POFF = W3_BOFF + 128;             // progress words of the 8 waves
-constexpr int W3_LDS = W3_POFF + 64;
+constexpr int W3_MOFF = W3_POFF + 64;              // (RGB / PWB) the pointwise layer's 32 matrix values
+constexpr int W3_AOFF = W3_MOFF + 128;             // (PWB) per-wave running sums: [64 lanes][16] f32
+constexpr int W3_LDS = W3_MOFF + 128;
+constexpr int W3_LDS_PWB = W3_AOFF + 8 * 4096;
+static_assert(W3_LDS_PWB <= 160 * 1024, "LDS budget");
 constexpr int W3_NPIECE = 9;                      // 16-byte pieces per lane and plane: 136 rows x 4 / 64 = 8.5
 static_assert(W3_LDS <= 160 * 1024, "LDS budget");
 #ifndef W3_PFW
@@ -199,8 +203,9 @@ __global__ __launch_bounds__(512) void conv_fwd3w_kernel(Fwd3wArgs fa) {
   constexpr int ES = 2, CIN = 32;
   constexpr uint32_t DEAD = 0x80000000u;             // byte offset beyond every buffer: loads return 0, stores drop
   constexpr bool SIGN = (EPI & SG_EP_SIGN) != 0, MASK = (EPI & SG_EP_MASK) != 0, PN = (EPI & SG_EP_PN) != 0,
-                 POOL = (EPI & SG_EP_POOL) != 0, PNB = (EPI & SG_EP_PNB) != 0;
-  static_assert(!(PN && (POOL || MASK || PNB)) && !(PNB && (POOL || SIGN || !MASK)) && !(MASK && SIGN), "unsupported epilogue combination");
+                 POOL = (EPI & SG_EP_POOL) != 0, PNB = (EPI & SG_EP_PNB) != 0, RGB = (EPI & SG_EP_RGB) != 0, PWB = (EPI & SG_EP_PWB) != 0;
+  static_assert(!(PN && (POOL || MASK || PNB)) && !(PNB && (POOL || SIGN || !MASK)) && !(MASK && SIGN) &&
+                !(RGB && (POOL || MASK || PNB)) && !(PWB && (!MASK || POOL || PNB || RGB)), "unsupported epilogue combination");
   const int tid = threadIdx.x, lane = tid & 63;
   const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int v16 = lane & 15, q4 = lane >> 4;         // MFMA 16x16x32: voxel column / K group (inputs), row group (outputs)
@@ -222,6 +227,9 @@ __global__ __launch_bounds__(512) void conv_fwd3w_kernel(Fwd3wArgs fa) {
   float* bias_lds = reinterpret_cast<float*>(smem + W3_BOFF);
   if (tid < 32) bias_lds[tid] = a.bias != nullptr ? a.bias[nt0 * 32 + tid] : 0.f;
   if (tid < 8) reinterpret_cast<int*>(smem + W3_POFF)[tid] = 0;
+  if constexpr ((EPI & (SG_EP_RGB | SG_EP_PWB)) != 0) {
+    if (tid < 32) reinterpret_cast<float*>(smem + W3_MOFF)[tid] = ((EPI & SG_EP_RGB) ? a.rgb_w : a.pw_wmat)[tid];
+  }
   __syncthreads();      // the only barrier: from here on a wave reads what it wrote itself (and the weights)
 
   // item schedule: XCD group xg owns a contiguous chunk of the item list (neighbouring columns share halo rows in its L2)
@@ -232,7 +240,15 @@ __global__ __launch_bounds__(512) void conv_fwd3w_kernel(Fwd3wArgs fa) {
   const int i_begin = xg * ipx, i_end = min(nitems_all, i_begin + ipx);
   const int ifirst = i_begin + bslot;
   const int nitems = ifirst < i_end ? (i_end - ifirst + per_x - 1) / per_x : 0;
-  if (nitems == 0) return;
+  if (nitems == 0) {
+    if constexpr (PWB) {      // every wave owns a row of partial sums: mine are zero
+      if (lane < 32) {
+        a.pw_part[((size_t)(blockIdx.x * 8 + w8) * 2 + 0) * 32 + lane] = 0.f;
+        a.pw_part[((size_t)(blockIdx.x * 8 + w8) * 2 + 1) * 32 + lane] = 0.f;
+      }
+    }
+    return;
+  }
   if ((a.dbg_flags & 8192) && w8 >= 4) return;      // diagnostic: one wave per SIMD (half the output is not computed)
   const bool no_stage = (a.dbg_flags & 1) != 0, no_epi = (a.dbg_flags & 2) != 0;      // diagnostic ablations (0 in production)
 
@@ -308,7 +324,7 @@ __global__ __launch_bounds__(512) void conv_fwd3w_kernel(Fwd3wArgs fa) {
   };
   // ---- output side
   Cur E{0, 0, 0, 0, 0, 0, 0, 0};
-  __amdgpu_buffer_rsrc_t ryE, rsE, rmE, rpE, rbE, rqE;
+  __amdgpu_buffer_rsrc_t ryE, rsE, rmE, rpE, rbE, rqE, rgE, rxiE, rdxE;
   int colvoxE = 0;
   bool row_ok[2] = {false, false};
   auto enter_item_E = [&]() {
@@ -323,6 +339,11 @@ __global__ __launch_bounds__(512) void conv_fwd3w_kernel(Fwd3wArgs fa) {
     if (PNB) {
       rbE = rsrc_of(a.pnb_y, ysb, E.n0);
       rqE = rsrc_of(a.pnb_scale, psb, E.n0);
+    }
+    if (RGB) rgE = rsrc_of(a.rgb_out, svox * ES, E.n0);
+    if (PWB) {
+      rxiE = rsrc_of(a.pw_x, svox * ES, E.n0);
+      rdxE = rsrc_of(a.pw_dx, svox * ES, E.n0);
     }
   };
   auto advance_E = [&]() {
@@ -388,6 +409,17 @@ __global__ __launch_bounds__(512) void conv_fwd3w_kernel(Fwd3wArgs fa) {
     asm volatile("" : "+v"(c[0][0][0]), "+v"(c[0][0][1]), "+v"(c[0][1][0]), "+v"(c[0][1][1]),
                  "+v"(c[1][0][0]), "+v"(c[1][0][1]), "+v"(c[1][1][0]), "+v"(c[1][1][1]));      // eight separate tuples from here on
   };
+  // (RGB / PWB) the eight values of the pointwise layer's matrix for my channels; (PWB) running sums of x * g and g over my voxels
+  // (kept in LDS, not in registers that would live across the K loops: the matrix is re-read per plane, the sums are a
+  // wave-private read-add-write per plane)
+  const float* pwm_lds = reinterpret_cast<const float*>(smem + W3_MOFF);
+  f32x4* pwacc = reinterpret_cast<f32x4*>(smem + W3_AOFF + w8 * 4096 + lane * 64);
+  if constexpr (PWB) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pwacc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float rgb_b = (RGB && a.rgb_bias != nullptr) ? a.rgb_bias[0] : 0.f;
+  const bool want_pw_dx = PWB && a.pw_dx != nullptr;
   f32x4 hold[POOL ? 2 : 1][POOL ? 2 : 1];            // (POOL) W-pair sums of the even plane of a D pair: [row][channel half]
   // sum / OR over the four lanes (l, l ^ 16, l ^ 32, l ^ 48) that share a voxel: two swaps on the VALU (v_permlane16_swap /
   // v_permlane32_swap exchange the odd rows / upper half of one operand with the even rows / lower half of the other: with both
@@ -519,6 +551,26 @@ __global__ __launch_bounds__(512) void conv_fwd3w_kernel(Fwd3wArgs fa) {
         }
     }
     if constexpr (!POOL) {
+      float pwm[(RGB || PWB) ? 2 : 1][(RGB || PWB) ? 4 : 1];      // the eight matrix values of my channels
+      float gws[PWB ? 2 : 1][PWB ? 4 : 1], gbs[PWB ? 2 : 1][PWB ? 4 : 1];      // (PWB) this plane's sums of x * g and g over my voxels
+      if constexpr (RGB || PWB) {
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            pwm[ch][i] = pwm_lds[16 * ch + 4 * q4 + i];
+            if constexpr (PWB) gws[ch][i] = gbs[ch][i] = 0.f;
+          }
+      }
+      uint32_t ximg[PWB ? 2 : 1][PWB ? 2 : 1];      // (PWB) from_rgb's input at my four voxels
+      if constexpr (PWB) {
+#pragma unroll
+        for (int wr = 0; wr < 2; ++wr)
+#pragma unroll
+          for (int vh = 0; vh < 2; ++vh)
+            ximg[wr][vh] = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rxiE, row_ok[wr] ? (uint32_t)(v16 * ES) : DEAD,
+                                                                                    (tile_vox + vrel(wr, vh)) * (uint32_t)ES, 0);
+      }
 #pragma unroll
       for (int wr = 0; wr < 2; ++wr) {
         const uint32_t vo = row_ok[wr] ? yv0 : DEAD;
@@ -529,6 +581,37 @@ __global__ __launch_bounds__(512) void conv_fwd3w_kernel(Fwd3wArgs fa) {
           // registers (v_permlane16_swap), after which lane q4 holds channels [0, 16, 8, 24][q4] .. + 7
           const uint32_t a0 = sg_pack_bf16(t[0][0], t[0][1]), a1 = sg_pack_bf16(t[0][2], t[0][3]);
           const uint32_t b0 = sg_pack_bf16(t[1][0], t[1][1]), b1 = sg_pack_bf16(t[1][2], t[1][3]);
+          if constexpr (RGB || PWB) {
+            // the pointwise layer next to this one works on the STORED values (rounded to bf16): to_rgb of the stage's output
+            // (pgan/generator.py:96-97), or from_rgb's backward on the gradient of ITS output (pgan/discriminator.py:9-12:
+            // image gradient = sum_c g_c m_c; filter gradient = sum_v x_v g_vc; bias gradient = sum_v g_vc) -- sg_conv3d_pw_bwd's sums
+            const uint32_t pk[2][2] = {{a0, a1}, {b0, b1}};
+            float dot = 0.f;
+            const float xv = PWB ? __uint_as_float(ximg[wr][vh] << 16) : 0.f;
+#pragma unroll
+            for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+              for (int h2 = 0; h2 < 2; ++h2) {
+                const float lo = __uint_as_float(pk[ch][h2] << 16), hi = __uint_as_float(pk[ch][h2] & 0xFFFF0000u);
+                dot = fmaf(lo, pwm[ch][2 * h2], dot);
+                dot = fmaf(hi, pwm[ch][2 * h2 + 1], dot);
+                if constexpr (PWB) {      // (a row beyond H: x loads as 0; its accumulators are not zero -- the row above feeds them)
+                  gws[ch][2 * h2] = fmaf(xv, lo, gws[ch][2 * h2]);
+                  gws[ch][2 * h2 + 1] = fmaf(xv, hi, gws[ch][2 * h2 + 1]);
+                  gbs[ch][2 * h2] += row_ok[wr] ? lo : 0.f;
+                  gbs[ch][2 * h2 + 1] += row_ok[wr] ? hi : 0.f;
+                }
+              }
+            dot = quad_sum(dot) + rgb_b;
+            const uint32_t img = sg_pack_bf16(dot, 0.f);
+            if constexpr (RGB)
+              __builtin_amdgcn_raw_buffer_store_b16((short)img, rgE, (row_ok[wr] && q4 == 0) ? (uint32_t)(v16 * ES) : DEAD,
+                                                    (tile_vox + vrel(wr, vh)) * (uint32_t)ES, 0);
+            else
+              __builtin_amdgcn_raw_buffer_store_b16((short)img, rdxE, (row_ok[wr] && q4 == 0 && want_pw_dx) ? (uint32_t)(v16 * ES) : DEAD,
+                                                    (tile_vox + vrel(wr, vh)) * (uint32_t)ES, 0);
+          }
+          if constexpr (PWB) continue;      // the gradient of from_rgb's output itself is needed by nobody else: not written
           const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
           const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
           u32x4 out;
@@ -536,6 +619,14 @@ __global__ __launch_bounds__(512) void conv_fwd3w_kernel(Fwd3wArgs fa) {
           __builtin_amdgcn_raw_buffer_store_b128(out, ryE, vo, ysoff + vrel(wr, vh) * (uint32_t)(cout * ES), 0);
           SG_STORE16_GUARD(out);
         }
+      }
+      if constexpr (PWB) {      // this plane's sums into my running sums
+        f32x4 r0 = pwacc[0], r1 = pwacc[1], r2 = pwacc[2], r3 = pwacc[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          r0[i] += gws[0][i]; r1[i] += gws[1][i]; r2[i] += gbs[0][i]; r3[i] += gbs[1][i];
+        }
+        pwacc[0] = r0; pwacc[1] = r1; pwacc[2] = r2; pwacc[3] = r3;
       }
     } else {
       // fused downscale3d, first stage (pgan/discriminator.py:44 after conv_2 + bias + LeakyReLU): mean over the 2 x 1 x 2 (D x W)
@@ -659,6 +750,27 @@ __global__ __launch_bounds__(512) void conv_fwd3w_kernel(Fwd3wArgs fa) {
     if (E.j >= nitems) break;
   }
 #undef SG_W3_OFF
+  if constexpr (PWB) {
+    // my partial sums over the 16 voxel columns of each lane row (lanes with equal q4), then one row of [2][32] per wave:
+    // pw_wgrad_final_kernel (wgrad.hip) adds the rows in order -- reproducible, no atomics
+    const f32x4 fin[4] = {pwacc[0], pwacc[1], pwacc[2], pwacc[3]};
+#pragma unroll
+    for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float sw = fin[ch][i], sb = fin[2 + ch][i];
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) {
+          sw += __shfl_xor(sw, m);
+          sb += __shfl_xor(sb, m);
+        }
+        if (v16 == 0) {
+          float* row = a.pw_part + (size_t)(blockIdx.x * 8 + w8) * 64;
+          row[16 * ch + 4 * q4 + i] = sw;
+          row[32 + 16 * ch + 4 * q4 + i] = sb;
+        }
+      }
+  }
 }
 
 // weight image for the v_mfma_f32_16x16x32_bf16 kernels: 1-KiB fragments [32-channel output tile][tap][32-channel input chunk]
@@ -693,11 +805,27 @@ __global__ void pack_weights16_batch_kernel(Pack16Batch b) {
   }
 }
 
+// the per-wave rows of the fused from_rgb backward, added in a fixed order
+__global__ __launch_bounds__(256) void pw_part_final_kernel(const float* __restrict__ part, int rows, float* __restrict__ dw,
+                                                            float* __restrict__ dbias, float coef) {
+  __shared__ float red[4][64];
+  const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  float sum = 0.f;
+  for (int b = rg; b < rows; b += 4) sum += part[(size_t)b * 64 + col];
+  red[rg][col] = sum;
+  __syncthreads();
+  if (rg == 0) {
+    const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    if (col < 32) { if (dw) dw[col] = coef * t; }
+    else if (dbias) dbias[col - 32] = t;
+  }
+}
+
 template <int EPI>
 int launch_fwd3w_inst(const Fwd3wArgs& fa, unsigned gx, hipStream_t st) {
   auto kern = conv_fwd3w_kernel<EPI>;
   SG_ALLOW_160K_LDS(kern);
-  hipLaunchKernelGGL(kern, dim3(gx, (unsigned)fa.a.ntile), dim3(512), W3_LDS, st, fa);
+  hipLaunchKernelGGL(kern, dim3(gx, (unsigned)fa.a.ntile), dim3(512), (EPI & SG_EP_PWB) ? W3_LDS_PWB : W3_LDS, st, fa);
   return SG_OK;
 }
 
@@ -728,10 +856,18 @@ int sg_pack16_batch(int n, const float* const* w, const float* coef, const int* 
   return SG_OK;
 }
 
+int sg_pw_wgrad_finalize(const float* part, int rows, float* dw, float* dbias, float coef, hipStream_t st) {
+  if (!dw && !dbias) return SG_OK;
+  hipLaunchKernelGGL(pw_part_final_kernel, dim3(1), dim3(256), 0, st, part, rows, dw, dbias, coef);
+  SG_LAUNCH_CHECK();
+  return SG_OK;
+}
+
 // bf16, 3 x 3 x 3, 32 -> 32k channels, whole 32-wide rows.  Sets *used = false (and launches nothing) for anything else: the
 // caller falls back to the sliding-halo kernel.
-int sg_launch_fwd3w(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used) {
+int sg_launch_fwd3w(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used, int* pw_rows) {
   *used = false;
+  *pw_rows = 0;
   if (s->kd != 3 || s->kh != 3 || s->kw != 3 || s->cin != 32 || (s->cout & 31) || a.xcs != 32 || a.xco != 0) return SG_OK;
   if (s->upsample_in || a.in_mask || a.addend) return SG_OK;
   if (s->d < 2 || s->h < 8 || (s->w % 32) != 0) return SG_OK;
@@ -739,6 +875,9 @@ int sg_launch_fwd3w(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool
   if (a.pixel_norm && (a.mask_bits || a.ntile != 1 || a.pnb_y)) return SG_OK;
   if (a.mask_bits && a.sign_out) return SG_OK;
   if (a.pnb_y && (a.ntile != 1 || !a.mask_bits || a.sign_out || a.bias || a.act || !a.pnb_scale)) return SG_OK;
+  if (a.rgb_out && (a.ntile != 1 || !a.rgb_w || a.pool || a.mask_bits || a.pnb_y || !a.pixel_norm || !a.sign_out)) return SG_OK;
+  if (a.pw_x && (a.ntile != 1 || !a.pw_wmat || !a.pw_part || !a.mask_bits || a.pool || a.pnb_y || a.rgb_out || a.pixel_norm ||
+                 a.sign_out || a.bias || a.act)) return SG_OK;
   {   // buffer addressing (rebased per sample): one sample of every tensor this kernel touches stays below 2 GiB
     const int64_t svox = (int64_t)s->d * s->h * s->w;
     if (svox * 64 >= (1ll << 31) || svox * s->cout * 2 >= (1ll << 31) || svox * a.ntile * 4 >= (1ll << 31)) return SG_OK;
@@ -767,8 +906,9 @@ int sg_launch_fwd3w(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool
   fa.nseg = nseg;
   fa.nitems = (int)ncol * nseg;
   if (fa.nitems < gx) gx = (fa.nitems + 7) / 8 * 8;
+  if (a.pw_x && (size_t)gx * 8 > (size_t)SG_PW_PART_ROWS) return SG_OK;
   const int epi = (a.sign_out ? SG_EP_SIGN : 0) | (a.mask_bits ? SG_EP_MASK : 0) | (a.pixel_norm ? SG_EP_PN : 0) |
-                  (a.pool ? SG_EP_POOL : 0) | (a.pnb_y ? SG_EP_PNB : 0);
+                  (a.pool ? SG_EP_POOL : 0) | (a.pnb_y ? SG_EP_PNB : 0) | (a.rgb_out ? SG_EP_RGB : 0) | (a.pw_x ? SG_EP_PWB : 0);
   int rc = SG_OK;
   switch (epi) {
     case 0: rc = launch_fwd3w_inst<0>(fa, (unsigned)gx, st); break;
@@ -780,11 +920,14 @@ int sg_launch_fwd3w(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool
     case SG_EP_SIGN | SG_EP_POOL: rc = launch_fwd3w_inst<SG_EP_SIGN | SG_EP_POOL>(fa, (unsigned)gx, st); break;
     case SG_EP_MASK | SG_EP_POOL: rc = launch_fwd3w_inst<SG_EP_MASK | SG_EP_POOL>(fa, (unsigned)gx, st); break;
     case SG_EP_MASK | SG_EP_PNB: rc = launch_fwd3w_inst<SG_EP_MASK | SG_EP_PNB>(fa, (unsigned)gx, st); break;
+    case SG_EP_PN | SG_EP_SIGN | SG_EP_RGB: rc = launch_fwd3w_inst<SG_EP_PN | SG_EP_SIGN | SG_EP_RGB>(fa, (unsigned)gx, st); break;
+    case SG_EP_MASK | SG_EP_PWB: rc = launch_fwd3w_inst<SG_EP_MASK | SG_EP_PWB>(fa, (unsigned)gx, st); break;
     default: return SG_OK;
   }
   if (rc != SG_OK) return rc;
   SG_KNAME("conv_fwd3w<bf16,32->%d>", 32);
   SG_LAUNCH_CHECK();
+  *pw_rows = a.pw_x ? gx * 8 : 0;
   *used = true;
   return SG_OK;
 }

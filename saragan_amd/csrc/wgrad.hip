@@ -1492,8 +1492,9 @@ static int launch_wgrad3(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   const int pairs = a.ciT * a.coT;
   int gx = (256 / pairs) / 8 * 8;
   if (gx < 8) gx = 8;
-  if (w16)      // few columns at these levels: rather fewer blocks (>= 128) than the tap-per-wave kernel
-    while (gx > 8 && ncol < 2 * gx && (gx - 8) * pairs >= 128) gx -= 8;
+  // few columns (the 16-wide levels; small batches at the wide ones): rather fewer blocks (>= 64) than the tap-per-wave kernel,
+  // which runs these shapes at 0.2-0.4 of this kernel's rate
+  while (gx > 8 && ncol < 2 * gx && (gx - 8) * pairs >= (w16 ? 128 : 64)) gx -= 8;
   if (ncol < 2 * gx || g.nTd < 2) return SG_OK;      // needs >= 2 columns per block and something to slide over
   a.gy = a.g;
   a.ntiles = ncol * g.nTd;

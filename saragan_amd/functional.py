@@ -231,13 +231,18 @@ def _raw_upconv_subpixel(x, w, coef, bias, act, slope, pixel_norm, eps, want_sca
 
 
 def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel_norm=False, eps=1e-8,
-             want_scale=False, mask_bits=None, mask_slope=0.0, want_signs=False, pool=False, pn_bwd=None):
+             want_scale=False, mask_bits=None, mask_slope=0.0, want_signs=False, pool=False, pn_bwd=None, rgb=None, pw_bwd=None):
     """y = epilogue(conv3d(x, coef*w)) with w in DHWIO; `flip` selects the data-gradient weights.
     Returns (y, pixel-norm scale or None, sign words of y or None).  pool (sg_conv_epilogue.pool): 1 -- y is the
     2 x 1 x 2 (D x H x W) block mean of the output, [n,cout,d/2,h,w/2]; 2 -- the 1 x 2 x 2 block mean, [n,cout,d,h/2,w/2];
     returns None if no kernel of the build fuses it here.  pn_bwd = (y, scale) of a pixel-norm stage: the result is
     pushed through that stage's backward in the epilogue (sg_conv_epilogue.pn_bwd_y; mask_bits = the stage's sign words);
-    None if no kernel does that for this layer."""
+    None if no kernel does that for this layer.
+    rgb = (matrix [cout] f32, bias tensor or None): to_rgb (one image channel) of the stored output in the epilogue
+    (sg_conv_epilogue.rgb_*); returns (y, scale, signs, img), or None if the library has no such epilogue for this layer.
+    pw_bwd = dict(x=image, wmat=[cout] f32, want_dx, dw, db, coef): from_rgb's whole backward in the epilogue of this data
+    gradient (sg_conv_epilogue.pw_*; y is not written); returns the image gradient (or True when none was asked for), or None
+    if the library declines."""
     lib = _lib.load()
     _req_cuda(x, w, bias)
     x = ndhwc(x)
@@ -262,7 +267,8 @@ def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel
     pool = int(pool)
     if pool and (((d | wd) if pool == 1 else (h | wd)) & 1 or x.dim() != 5):
         return None
-    y = _empty_like_shape(x, cout, {0: (d, h, wd), 1: (d // 2, h, wd // 2), 2: (d, h // 2, wd // 2)}[pool])
+    y = None if pw_bwd is not None else \
+        _empty_like_shape(x, cout, {0: (d, h, wd), 1: (d // 2, h, wd // 2), 2: (d, h // 2, wd // 2)}[pool])
     _check_signs(mask_bits, n * d * h * wd, cout)
     signs = _empty_signs(x.device, n, d, h, wd, cout) if want_signs else None
     scale = None
@@ -281,10 +287,27 @@ def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel
     if ws_bytes and not pool:      # scratch for the library's two-pass (K-split) path of this layer
         ws = torch.empty(ws_bytes, device=x.device, dtype=torch.uint8)
         ep.workspace, ep.workspace_bytes = ws.data_ptr(), ws_bytes
+    img = dimg = None
+    if rgb is not None:
+        img = _empty_like_shape(x, 1, (d, h, wd))
+        ep.rgb_w, ep.rgb_bias, ep.rgb_out = rgb[0].data_ptr(), (rgb[1].data_ptr() if rgb[1] is not None else None), img.data_ptr()
+    if pw_bwd is not None:
+        pws = lib.sg_conv3d_pw_epilogue_workspace()
+        ws = torch.empty(pws, device=x.device, dtype=torch.uint8)
+        ep.workspace, ep.workspace_bytes = ws.data_ptr(), pws
+        dimg = _empty_like_shape(x, 1, (d, h, wd)) if pw_bwd['want_dx'] else None
+        ep.pw_x, ep.pw_wmat, ep.pw_dx = pw_bwd['x'].data_ptr(), pw_bwd['wmat'].data_ptr(), (dimg.data_ptr() if dimg is not None else None)
+        ep.pw_dw = pw_bwd['dw'].data_ptr() if pw_bwd['dw'] is not None else None
+        ep.pw_dbias = pw_bwd['db'].data_ptr() if pw_bwd['db'] is not None else None
+        ep.pw_coef = float(pw_bwd['coef'])
     rc = lib.sg_conv3d_fwd(_ptr(x), _ptr(wp), _ptr(y), C.byref(shp), C.byref(ep), dt, st)
-    if (pool or pn_bwd is not None) and rc == _lib.SG_EUNSUPPORTED:
+    if (pool or pn_bwd is not None or rgb is not None or pw_bwd is not None) and rc == _lib.SG_EUNSUPPORTED:
         return None
     check(rc, 'sg_conv3d_fwd')
+    if pw_bwd is not None:
+        return dimg if dimg is not None else True
+    if rgb is not None:
+        return y, scale, signs, img
     return y, scale, signs
 
 
@@ -507,6 +530,9 @@ class ActInfo:
         self.bits = None          # sign words of `a`, written by the producing conv's epilogue
         self.pn = None            # (y, scale) when the stage goes on through pixel_norm: y = pixel_norm(a); consumers that
         #                           registered as premask then apply the pixel-norm backward as well (_dgrad_into)
+        self.pw = None            # from_rgb (1x1x1 from one image channel): dict(x, w, coef, w_ptr, b_ptr, has_b, x_req) -- a consumer
+        #                           whose data-gradient kernel has the pw_* epilogue runs this layer's whole backward there ...
+        self.pw_result = None     # ... and leaves (gx, gw, gb) here for the layer's own backward to return (_dgrad_into)
         self.n_consumers = 0
         self.n_premask = 0
 
@@ -534,7 +560,9 @@ def pn_bwd_epilogue_available(prod_shape, kernel, fmaps, dtype):
     if _NO_PN_EPILOGUE or dtype != torch.bfloat16 or len(prod_shape) != 5 or tuple(kernel) != (3, 3, 3):
         return False
     n, c, d, h, w = prod_shape
-    return c == 32 and fmaps == 32 and w % 32 == 0 and d >= 4 and n * ((h + 3) // 4 + 1) // 2 * (w // 32) >= 256
+    # (round 5: conv_fwd3w takes this epilogue at any batch -- few columns are cut into D segments; the sliding-halo kernel
+    # behind it needed >= 256 column pairs)
+    return c == 32 and fmaps == 32 and w % 32 == 0 and d >= 2 and h >= 8
 
 
 def _dgrad_into(info, g, w, coef, flip):
@@ -542,6 +570,10 @@ def _dgrad_into(info, g, w, coef, flip):
     registered to apply (ActInfo.all_premask): the LeakyReLU mask in the epilogue, and for a pixel-norm stage its whole
     backward (sg_conv_epilogue.pn_bwd_y) -- the producer then skips its own pass."""
     if info.pn is None:
+        if info.pw is not None and not torch.is_grad_enabled() and not _NO_PW_EPILOGUE and g.dtype == torch.bfloat16:
+            res = _pw_fused_backward(info, g, w, coef, flip)
+            if res is not None:
+                return res
         return _Conv.apply(g, w, coef, flip, False, None, info.bits, info.slope)
     if torch.is_grad_enabled():
         raise NotImplementedError('second-order gradient through pixel_norm is not part of the pgan step')
@@ -550,6 +582,40 @@ def _dgrad_into(info, g, w, coef, flip):
         return res[0]
     gy = raw_conv(g, w, coef, flip)[0]          # the library declined (shape): the two passes, here
     return _PnActBwd.apply(gy, info.pn[0], info.pn[1], info.bits, info.slope, False)[0]
+
+
+_NO_PW_EPILOGUE = bool(int(os.environ.get('SARAGAN_NO_PW_EPILOGUE', '0')))   # diagnostic: from_rgb's backward as its own pass over the gradient
+
+
+def _pw_fused_backward(info, g, w, coef, flip):
+    """conv_1's data gradient with from_rgb's whole backward in its epilogue (sg_conv_epilogue.pw_*): the gradient of from_rgb's
+    output -- 32 channels at full resolution, the largest tensor of the discriminator's backward, read once more by
+    sg_conv3d_pw_bwd only to be reduced to 32 + 32 numbers and a one-channel image -- is never written.  from_rgb's own
+    backward (which autograd runs next) finds (gx, gw, gb) in info.pw_result; what it is handed as `gy` is a stride-0 placeholder.
+    None: the library has no such epilogue for this layer."""
+    pw = info.pw
+    wr = pw['w']
+    want_w = wr.data_ptr() not in _SKIP['ptrs']
+    want_b = pw['has_b'] and pw['b_ptr'] not in _SKIP['ptrs']
+    want_dx = bool(pw['x_req'])
+    if not (want_w or want_b or want_dx):
+        return None
+    x_img = ndhwc(pw['x'])
+    if x_img.dtype != g.dtype or x_img.shape[1] != 1:
+        return None
+    cout = wr.shape[-1]
+    dw = _f32_out(wr.data_ptr(), tuple(wr.shape), g.device) if want_w else None
+    db = _f32_out(pw['b_ptr'], (cout,), g.device) if want_b else None
+    res = raw_conv(g, w, coef, flip, mask_bits=info.bits, mask_slope=info.slope,
+                   pw_bwd=dict(x=x_img, wmat=_rgb_matrix(wr, pw['coef'], g.dtype, small_is_cin=True), want_dx=want_dx, dw=dw, db=db,
+                               coef=pw['coef']))
+    if res is None:
+        _unclaim(wr.data_ptr(), dw)
+        _unclaim(pw['b_ptr'], db)
+        return None
+    info.pw_result = (res if want_dx else None, dw, db)
+    n, c, d, h, wd = _dims(ndhwc(g))
+    return torch.zeros((), device=g.device, dtype=g.dtype).expand(n, w.shape[3] if flip else w.shape[4], d, h, wd)
 
 
 class BackInfo:
@@ -678,6 +744,10 @@ class _ConvBiasAct(torch.autograd.Function):
             # (an alias without autograd history: `y` itself will point at this node, which holds out_info -- a reference
             # cycle that kept the stage's output alive until the cyclic collector ran, 1.7 GiB per step at batch 32)
             out_info.pn = (y.detach(), scale) if pixel_norm else None
+            if (act and not pixel_norm and not ups and signs is not None and w.dim() == 5 and tuple(w.shape[:4]) == (1, 1, 1, 1) and
+                    x.dim() == 5 and not _NO_RGB_FUSION):      # from_rgb on one image channel (pgan/discriminator.py:9-12)
+                out_info.pw = dict(x=x.detach(), w=w, coef=coef, b_ptr=b.data_ptr() if b is not None else 0, has_b=b is not None,
+                                   x_req=x.requires_grad)
         ctx.save_for_backward(x, w, y if (pixel_norm or (act and signs is None)) else None, scale, signs)
         ctx.cfg = (coef, ups, act, slope, pixel_norm)
         ctx.has_b = b is not None
@@ -689,6 +759,11 @@ class _ConvBiasAct(torch.autograd.Function):
     def backward(ctx, gy):
         x, w, y, scale, signs = ctx.saved_tensors
         coef, ups, act, slope, pixel_norm = ctx.cfg
+        if ctx.out_info is not None and ctx.out_info.pw_result is not None:
+            # from_rgb: the consumer's data-gradient kernel ran this whole backward in its epilogue (_pw_fused_backward); `gy` is a placeholder
+            gx, gw, gb = ctx.out_info.pw_result
+            ctx.out_info.pw_result = None
+            return (gx if ctx.needs_input_grad[0] else None), gw, gb, None, None, None, None, None, None, None, None
         g = gy
         want_db = ctx.has_b and _wants(ctx, 2, ctx.b_ptr)
         gb = None
@@ -731,6 +806,7 @@ class _ConvBiasAct(torch.autograd.Function):
         return gx, gw, (gb if want_db else None), None, None, None, None, None, None, None, None
 
 
+_NO_RGB_FWD_EPILOGUE = bool(int(os.environ.get('SARAGAN_NO_RGB_FWD_EPILOGUE', '0')))   # diagnostic: to_rgb's forward as its own pass over y
 _NO_RGB_FUSION = bool(int(os.environ.get('SARAGAN_NO_RGB_FUSION', '0')))   # diagnostic: to_rgb's data gradient as a tensor
 _NO_RGB_WG_FUSION = bool(int(os.environ.get('SARAGAN_NO_RGB_WG_FUSION', '0')))   # diagnostic: to_rgb's filter gradient as its own pass over y
 
@@ -786,9 +862,18 @@ class _ConvPnActToRgb(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, coef, ups, slope, eps, in_info, w_rgb, b_rgb, coef_rgb):
         _note_all(x, w, b, w_rgb, b_rgb)
-        y, scale, signs = raw_conv(x, w, coef, False, ups, bias=b, act=True, slope=slope, pixel_norm=True, eps=eps,
-                                   want_scale=True, want_signs=True)
-        img, _, _ = raw_conv(y, w_rgb, coef_rgb, False, False, bias=b_rgb)
+        res = None
+        if (w_rgb.shape[-1] == 1 and not ups and x.dtype == torch.bfloat16 and not _NO_RGB_FWD_EPILOGUE and
+                (b_rgb is None or b_rgb.dtype == torch.float32)):
+            # to_rgb inside the stage's own epilogue (sg_conv_epilogue.rgb_*): the stage's output is not read again for the image
+            res = raw_conv(x, w, coef, False, ups, bias=b, act=True, slope=slope, pixel_norm=True, eps=eps, want_scale=True,
+                           want_signs=True, rgb=(_rgb_matrix(w_rgb, coef_rgb, x.dtype), b_rgb))
+        if res is not None:
+            y, scale, signs, img = res
+        else:
+            y, scale, signs = raw_conv(x, w, coef, False, ups, bias=b, act=True, slope=slope, pixel_norm=True, eps=eps,
+                                       want_scale=True, want_signs=True)
+            img, _, _ = raw_conv(y, w_rgb, coef_rgb, False, False, bias=b_rgb)
         ctx.save_for_backward(x, w, y, scale, signs, w_rgb)
         ctx.cfg = (coef, ups, slope, coef_rgb)
         ctx.in_info = in_info

@@ -40,7 +40,7 @@ def test_struct_declarations_agree():
     lib_py = open(os.path.join(ROOT, 'saragan_amd', '_lib.py')).read()
     integ = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
     ep = _c_struct_fields(hdr, 'sg_conv_epilogue')
-    assert ep[0] == 'struct_size' and len(ep) == 22, ep
+    assert ep[0] == 'struct_size' and len(ep) == 31, ep
     assert _py_struct_fields(lib_py, 'ConvEpilogue') == ep
     assert _py_struct_fields(integ, 'SgConvEpilogue') == ep, 'INTEGRATION.md stub is out of sync with the header'
     shp = _c_struct_fields(hdr, 'sg_conv_shape')
@@ -48,8 +48,8 @@ def test_struct_declarations_agree():
     assert _py_struct_fields(integ, 'SgConvShape') == shp
     from saragan_amd import _lib
     # natural C layout: u32 +pad, ptr, i32, f32, i32, f32, ptr, ptr, f32 +pad, ptr, i32, i32[3], i32[3], i32, ptr, size_t, i32 +pad, ptr, ptr, ptr, f32, f32
-    assert C.sizeof(_lib.ConvEpilogue) == 152 and C.sizeof(_lib.ConvShape) == 40
-    assert _lib.ConvEpilogue(None, 1, 0.2).struct_size == 152
+    assert C.sizeof(_lib.ConvEpilogue) == 224 and C.sizeof(_lib.ConvShape) == 40
+    assert _lib.ConvEpilogue(None, 1, 0.2).struct_size == 224
     # every entry point INTEGRATION.md names is declared by the header
     named = set(re.findall(r'`(sg_[a-z0-9_]+)', integ))
     declared = set(re.findall(r'\b(sg_[a-z0-9_]+)\s*\(', hdr)) | {'sg_conv_epilogue', 'sg_conv_shape'}

@@ -128,6 +128,48 @@ def main():
                 print('   ** MISMATCH')
     os.environ['SG_FWD3S_16'] = '1'
     lib.sg_config_reload()
+    # ---- the pointwise layers next to the 32-channel convolution, in its epilogue (round 5): to_rgb of a generator stage's output
+    # (sg_conv_epilogue.rgb_*) and from_rgb's whole backward in the data gradient of its output (pw_*), against the separate passes
+    for (n, sp, flip) in [(2, (6, 128, 256), False), (3, (5, 72, 96), True), (1, (16, 64, 64), False), (5, (4, 10, 32), True)]:
+        cin = cout = 32
+        x = torch.randn(n, cin, *sp, device=dev).bfloat16().contiguous(memory_format=torch.channels_last_3d)
+        w = torch.randn(3, 3, 3, cout, cin, device=dev) if flip else torch.randn(3, 3, 3, cin, cout, device=dev)
+        b = torch.randn(cout, device=dev) * 0.3
+        coef = (2.0 / (27 * cin)) ** 0.5
+        nvox = n * sp[0] * sp[1] * sp[2]
+        w_rgb = torch.randn(1, 1, 1, cout, 1, device=dev)
+        b_rgb = torch.randn(1, device=dev)
+        mat = F._rgb_matrix(w_rgb, 0.25, torch.bfloat16)
+        res = F.raw_conv(x, w, coef, flip, False, bias=b, act=True, pixel_norm=True, want_scale=True, want_signs=True, rgb=(mat, b_rgb))
+        y0, sc0, sg0 = F.raw_conv(x, w, coef, flip, False, bias=b, act=True, pixel_norm=True, want_scale=True, want_signs=True)
+        img0 = F.raw_conv(y0, w_rgb, 0.25, False, False, bias=b_rgb)[0]
+        print(f'n{n} 32->32 {sp} flip{int(flip)} pn+signs+to_rgb epilogue:', 'declined' if res is None else 'ran', flush=True)
+        if res is None:
+            ok = False
+        else:
+            wst = cmp('stage + image', [res[0], res[1], res[2], res[3]], [y0, sc0, sg0, img0])
+            if wst > 2e-2:
+                ok = False
+                print('   ** MISMATCH')
+        # from_rgb's backward: image x_img, gradient g of conv_1's output (here: x), from_rgb's sign words
+        words = torch.randint(-2 ** 31, 2 ** 31 - 1, (nvox,), device=dev, dtype=torch.int64).to(torch.int32)
+        x_img = torch.randn(n, 1, *sp, device=dev).bfloat16().contiguous(memory_format=torch.channels_last_3d)
+        w_frgb = torch.randn(1, 1, 1, 1, cout, device=dev)
+        wmat = F._rgb_matrix(w_frgb, 0.5, torch.bfloat16, small_is_cin=True)
+        dw, db = torch.zeros(1, 1, 1, 1, cout, device=dev), torch.zeros(cout, device=dev)
+        dimg = F.raw_conv(x, w, coef, flip, False, mask_bits=words, mask_slope=0.2,
+                          pw_bwd=dict(x=x_img, wmat=wmat, want_dx=True, dw=dw, db=db, coef=0.5))
+        g0 = F.raw_conv(x, w, coef, flip, False, mask_bits=words, mask_slope=0.2)[0]
+        ref = F._pw_backward(x_img, g0, w_frgb, 0.5, True)
+        print(f'n{n} 32->32 {sp} flip{int(flip)} masked + from_rgb backward epilogue:', 'declined' if dimg is None else 'ran', flush=True)
+        if dimg is None or ref is None:
+            ok = False
+            print('   ** declined', dimg is None, ref is None)
+        else:
+            wst = cmp('image gradient / filter / bias gradient', [dimg, dw.reshape(-1), db], [ref[0], ref[1].reshape(-1), ref[2]], tol=5e-3)
+            if wst > 5e-3:
+                ok = False
+                print('   ** MISMATCH')
     print('OK' if ok else 'FAILED')
     return ok
 

@@ -91,7 +91,9 @@ typedef struct {
    * pool = 2: the mean over 1 (D) x 2 (H) x 2 (W) blocks instead, [n, d, h/2, w/2, cout], finished by
    * sg_downscale_sum(2,1,1, gain 1/2): the streamed ping-pong kernel's tile (bf16, 3x3x3, cin % 16 == 0, cout % 64 == 0,
    * even h and w, no pixel-norm / mask), for the layers with more than 32 input channels.  With act = 0 and no bias
-   * either mode is the block mean of a plain convolution (the gradient of conv3d(upscale3d(x)), 8 x the mean). */
+   * either mode is the block mean of a plain convolution (the gradient of conv3d(upscale3d(x)), 8 x the mean).
+   * pool = 3: the mean over whole 2 x 2 x 2 blocks, [n, d/2, h/2, w/2, cout] -- downscale3d finished inside the epilogue, no
+   * second pass (32 input channels, even d / h / w, otherwise as pool = 1; SG_EUNSUPPORTED elsewhere: use pool = 1). */
   int32_t pool;
   /* Optional scratch for layers the library computes in two passes over halves of the input channels (64 -> 32 at
    * 3x3x3, bf16: f32 partial sums of the first half, n*d*h*w*cout*4 bytes, 16-byte aligned, contents irrelevant on

@@ -2918,7 +2918,7 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
   a.eps = ep ? ep->eps : 0.f;
   a.tap_d = ep ? ep->tap_off[0] : 0; a.tap_h = ep ? ep->tap_off[1] : 0; a.tap_w = ep ? ep->tap_off[2] : 0;
   a.pool = ep ? ep->pool : 0;
-  if (a.pool < 0 || a.pool > 2) return SG_EINVAL;
+  if (a.pool < 0 || a.pool > 3) return SG_EINVAL;
   a.pnb_y = ep ? ep->pn_bwd_y : nullptr;
   a.pnb_scale = ep ? ep->pn_bwd_scale : nullptr;
   if ((a.pnb_y != nullptr) != (a.pnb_scale != nullptr) || (a.pnb_y && !sg_aligned16(a.pnb_y))) return SG_EINVAL;
@@ -2969,7 +2969,9 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
     return rc;
   }
   if (a.pool && (subpixel || dt != SG_BF16 || sg_cfg().fwd_v1 || (s->cin * 2) % 16 != 0 || a.pixel_norm ||
-                 (a.pool == 1 && (sg_cfg().fwd_no_v3 || sg_cfg().fwd_no_v3s)) || (a.pool == 2 && sg_cfg().fwd_no_v5)))
+                 (a.pool == 1 && (sg_cfg().fwd_no_v3 || sg_cfg().fwd_no_v3s)) || (a.pool == 2 && sg_cfg().fwd_no_v5) ||
+                 (a.pool == 3 && (s->cin != 32 || s->kd != 3 || s->kh != 3 || s->kw != 3 || s->upsample_in || !sg_cfg().fwd3s_16 ||
+                                  sg_cfg().fwd_no_v3 || sg_cfg().fwd_no_v3s || (ep && ep->x_plane_channels)))))
     return SG_EUNSUPPORTED;
   // the pixel-norm backward epilogue exists in the sliding-halo kernel only
   if (a.pnb_y && (subpixel || dt != SG_BF16 || sg_cfg().fwd_v1 || sg_cfg().fwd_no_v3 || sg_cfg().fwd_no_v3s || a.pool ||
@@ -3061,7 +3063,7 @@ extern "C" int sg_conv3d_fwd(const void* x, const void* wp, void* y, const sg_co
           rc = sg_pw_wgrad_finalize(a.pw_part, pw_rows, ep->pw_dw, ep->pw_dbias, ep->pw_coef, hs);
         if (rc != SG_OK || used) { prof.done(rc); return rc; }
       }
-      if (a.rgb_out || a.pw_x) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }      // (only that kernel has these epilogues)
+      if (a.rgb_out || a.pw_x || a.pool == 3) { prof.done(SG_EUNSUPPORTED); return SG_EUNSUPPORTED; }      // (only that kernel has these epilogues)
       if (a.nchunk == 2) rc = launch_fwd3s<2>(a, s, hs, &used);
       else if (a.nchunk == 1) rc = launch_fwd3s<1>(a, s, hs, &used);
       if (rc != SG_OK || used) { prof.done(rc); return rc; }

@@ -203,7 +203,8 @@ __global__ __launch_bounds__(512) void conv_fwd3w_kernel(Fwd3wArgs fa) {
   constexpr int ES = 2, CIN = 32;
   constexpr uint32_t DEAD = 0x80000000u;             // byte offset beyond every buffer: loads return 0, stores drop
   constexpr bool SIGN = (EPI & SG_EP_SIGN) != 0, MASK = (EPI & SG_EP_MASK) != 0, PN = (EPI & SG_EP_PN) != 0,
-                 POOL = (EPI & SG_EP_POOL) != 0, PNB = (EPI & SG_EP_PNB) != 0, RGB = (EPI & SG_EP_RGB) != 0, PWB = (EPI & SG_EP_PWB) != 0;
+                 POOL = (EPI & SG_EP_POOL) != 0, PNB = (EPI & SG_EP_PNB) != 0, RGB = (EPI & SG_EP_RGB) != 0, PWB = (EPI & SG_EP_PWB) != 0,
+                 POOL3 = (EPI & SG_EP_POOL3) != 0;
   static_assert(!(PN && (POOL || MASK || PNB)) && !(PNB && (POOL || SIGN || !MASK)) && !(MASK && SIGN) &&
                 !(RGB && (POOL || MASK || PNB)) && !(PWB && (!MASK || POOL || PNB || RGB)), "unsupported epilogue combination");
   const int tid = threadIdx.x, lane = tid & 63;
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(512) void conv_fwd3w_kernel(Fwd3wArgs fa) {
     row_ok[0] = E.h0 < H;
     row_ok[1] = E.h0 + 1 < H;
     colvoxE = E.h0 * W + E.w0;
-    ryE = rsrc_of(a.y, POOL ? ysb / 4 : ysb, E.n0);
+    ryE = rsrc_of(a.y, POOL3 ? ysb / 8 : POOL ? ysb / 4 : ysb, E.n0);
     if (SIGN) rsE = rsrc_of(a.sign_out, wsb, E.n0);
     if (MASK) rmE = rsrc_of(a.mask_bits, wsb, E.n0);
     if (PN) rpE = rsrc_of(a.pn_scale, psb, E.n0);
@@ -629,10 +630,12 @@ __global__ __launch_bounds__(512) void conv_fwd3w_kernel(Fwd3wArgs fa) {
         pwacc[0] = r0; pwacc[1] = r1; pwacc[2] = r2; pwacc[3] = r3;
       }
     } else {
-      // fused downscale3d, first stage (pgan/discriminator.py:44 after conv_2 + bias + LeakyReLU): mean over the 2 x 1 x 2 (D x W)
-      // block; the H pairs are pooled by sg_downscale_sum(1, 2, 1).  W neighbours are adjacent lanes (DPP quad_perm [1,0,3,2]);
-      // even lanes keep the pairs of voxel half 0, odd lanes those of voxel half 1; the even plane of a D pair waits one phase
-      // in `hold`.  Output [n, D/2, H, W/2, cout].
+      // fused downscale3d (pgan/discriminator.py:44 after conv_2 + bias + LeakyReLU).  POOL: the mean over the 2 x 1 x 2 (D x W)
+      // block, the H pairs are left to sg_downscale_sum(1, 2, 1), output [n, D/2, H, W/2, cout]; POOL3: the wave owns both rows of
+      // an H pair, so the whole 2 x 2 x 2 mean leaves the kernel, output [n, D/2, H/2, W/2, cout] -- no second pass over the pooled
+      // tensor.  W neighbours are adjacent lanes (DPP quad_perm [1,0,3,2]); even lanes keep the pairs of voxel half 0, odd lanes
+      // those of voxel half 1; the even plane of a D pair waits one phase in `hold`.
+      f32x4 sall[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int wr = 0; wr < 2; ++wr) {
         f32x4 s[2];
@@ -643,26 +646,34 @@ __global__ __launch_bounds__(512) void conv_fwd3w_kernel(Fwd3wArgs fa) {
             const float u0 = c[wr][0][ch][i] + __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(c[wr][0][ch][i]), 0xB1, 0xF, 0xF, true));
             const float u1 = c[wr][1][ch][i] + __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(c[wr][1][ch][i]), 0xB1, 0xF, 0xF, true));
             s[ch][i] = (v16 & 1) ? u1 : u0;
+            sall[ch][i] += s[ch][i];
           }
+        if constexpr (POOL3) {
+          if (wr == 0) continue;      // (both rows first)
+          s[0] = sall[0];
+          s[1] = sall[1];
+        }
+        f32x4(&hd)[2] = hold[POOL3 ? 0 : wr];
         if ((o & 1) == 0) {   // uniform
-          hold[wr][0] = s[0];
-          hold[wr][1] = s[1];
+          hd[0] = s[0];
+          hd[1] = s[1];
         } else {
           float m[2][4];
 #pragma unroll
           for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) m[ch][i] = (hold[wr][ch][i] + s[ch][i]) * 0.25f;
+            for (int i = 0; i < 4; ++i) m[ch][i] = (hd[ch][i] + s[ch][i]) * (POOL3 ? 0.125f : 0.25f);
           const uint32_t a0 = sg_pack_bf16(m[0][0], m[0][1]), a1 = sg_pack_bf16(m[0][2], m[0][3]);
           const uint32_t b0 = sg_pack_bf16(m[1][0], m[1][1]), b1 = sg_pack_bf16(m[1][2], m[1][3]);
           const auto s0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
           const auto s1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
           u32x4 out;
           out[0] = s0[0]; out[1] = s1[0]; out[2] = s0[1]; out[3] = s1[1];
-          // pooled voxel (o / 2, h0 + wr, w0 / 2 + wq), wq = (v16 >> 1) + 8 * (v16 & 1)
-          const uint32_t psoff = (uint32_t)((((o >> 1) * H + E.h0 + wr) * (W >> 1) + (E.w0 >> 1)) * cout * ES);
+          // pooled voxel (o / 2, h0 + wr [POOL3: h0 / 2], w0 / 2 + wq), wq = (v16 >> 1) + 8 * (v16 & 1)
+          const uint32_t psoff = POOL3 ? (uint32_t)((((o >> 1) * (H >> 1) + (E.h0 >> 1)) * (W >> 1) + (E.w0 >> 1)) * cout * ES)
+                                       : (uint32_t)((((o >> 1) * H + E.h0 + wr) * (W >> 1) + (E.w0 >> 1)) * cout * ES);
           const uint32_t pvo = (uint32_t)((((v16 >> 1) + 8 * (v16 & 1)) * cout + nt0 * 32) * ES) + cb * ES;
-          __builtin_amdgcn_raw_buffer_store_b128(out, ryE, row_ok[wr] ? pvo : DEAD, psoff, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(out, ryE, row_ok[POOL3 ? 0 : wr] ? pvo : DEAD, psoff, 0);
           SG_STORE16_GUARD(out);
         }
       }
@@ -871,7 +882,7 @@ int sg_launch_fwd3w(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool
   if (s->kd != 3 || s->kh != 3 || s->kw != 3 || s->cin != 32 || (s->cout & 31) || a.xcs != 32 || a.xco != 0) return SG_OK;
   if (s->upsample_in || a.in_mask || a.addend) return SG_OK;
   if (s->d < 2 || s->h < 8 || (s->w % 32) != 0) return SG_OK;
-  if (a.pool && (a.pool != 1 || (s->d & 1) || a.pixel_norm || a.pnb_y || (a.mask_bits && (a.sign_out || a.bias || a.act)))) return SG_OK;
+  if (a.pool && ((a.pool != 1 && a.pool != 3) || (s->d & 1) || (a.pool == 3 && ((s->h | s->w) & 1)) || a.pixel_norm || a.pnb_y || (a.mask_bits && (a.sign_out || a.bias || a.act)))) return SG_OK;
   if (a.pixel_norm && (a.mask_bits || a.ntile != 1 || a.pnb_y)) return SG_OK;
   if (a.mask_bits && a.sign_out) return SG_OK;
   if (a.pnb_y && (a.ntile != 1 || !a.mask_bits || a.sign_out || a.bias || a.act || !a.pnb_scale)) return SG_OK;
@@ -908,7 +919,8 @@ int sg_launch_fwd3w(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool
   if (fa.nitems < gx) gx = (fa.nitems + 7) / 8 * 8;
   if (a.pw_x && (size_t)gx * 8 > (size_t)SG_PW_PART_ROWS) return SG_OK;
   const int epi = (a.sign_out ? SG_EP_SIGN : 0) | (a.mask_bits ? SG_EP_MASK : 0) | (a.pixel_norm ? SG_EP_PN : 0) |
-                  (a.pool ? SG_EP_POOL : 0) | (a.pnb_y ? SG_EP_PNB : 0) | (a.rgb_out ? SG_EP_RGB : 0) | (a.pw_x ? SG_EP_PWB : 0);
+                  (a.pool ? SG_EP_POOL : 0) | (a.pool == 3 ? SG_EP_POOL3 : 0) | (a.pnb_y ? SG_EP_PNB : 0) | (a.rgb_out ? SG_EP_RGB : 0) |
+                  (a.pw_x ? SG_EP_PWB : 0);
   int rc = SG_OK;
   switch (epi) {
     case 0: rc = launch_fwd3w_inst<0>(fa, (unsigned)gx, st); break;
@@ -919,6 +931,9 @@ int sg_launch_fwd3w(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool
     case SG_EP_POOL: rc = launch_fwd3w_inst<SG_EP_POOL>(fa, (unsigned)gx, st); break;
     case SG_EP_SIGN | SG_EP_POOL: rc = launch_fwd3w_inst<SG_EP_SIGN | SG_EP_POOL>(fa, (unsigned)gx, st); break;
     case SG_EP_MASK | SG_EP_POOL: rc = launch_fwd3w_inst<SG_EP_MASK | SG_EP_POOL>(fa, (unsigned)gx, st); break;
+    case SG_EP_POOL | SG_EP_POOL3: rc = launch_fwd3w_inst<SG_EP_POOL | SG_EP_POOL3>(fa, (unsigned)gx, st); break;
+    case SG_EP_SIGN | SG_EP_POOL | SG_EP_POOL3: rc = launch_fwd3w_inst<SG_EP_SIGN | SG_EP_POOL | SG_EP_POOL3>(fa, (unsigned)gx, st); break;
+    case SG_EP_MASK | SG_EP_POOL | SG_EP_POOL3: rc = launch_fwd3w_inst<SG_EP_MASK | SG_EP_POOL | SG_EP_POOL3>(fa, (unsigned)gx, st); break;
     case SG_EP_MASK | SG_EP_PNB: rc = launch_fwd3w_inst<SG_EP_MASK | SG_EP_PNB>(fa, (unsigned)gx, st); break;
     case SG_EP_PN | SG_EP_SIGN | SG_EP_RGB: rc = launch_fwd3w_inst<SG_EP_PN | SG_EP_SIGN | SG_EP_RGB>(fa, (unsigned)gx, st); break;
     case SG_EP_MASK | SG_EP_PWB: rc = launch_fwd3w_inst<SG_EP_MASK | SG_EP_PWB>(fa, (unsigned)gx, st); break;

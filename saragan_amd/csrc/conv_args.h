@@ -37,7 +37,7 @@ struct ConvFwdArgs {
   const float* pw_wmat;      // the [cout] values its forward multiplied with,
   void* pw_dx;               // -> image gradient [n,d,h,w,1] (or NULL),
   float* pw_part;            // -> per-wave partial sums [rows][2][32] f32 (sum x * g, sum g): pw_wgrad_final_kernel adds them
-  int pool;                  // 1: y is the D x W mean-pooled output [n, D/2, H, W/2, cout] (sliding-halo kernel only)
+  int pool;                  // 1: y is the D x W mean-pooled output [n, D/2, H, W/2, cout] (sliding-halo kernel only); 3: the 2 x 2 x 2 means (conv_fwd3w)
   int os, oa, ob, oc;        // output scatter: os == 2 writes voxel (2d+oa, 2h+ob, 2w+oc) of a [n,2D,2H,2W,cout] tensor
   unsigned long long* dbg;  // diagnostic time stamps (NULL in production)
   int dbg_flags;            // diagnostic ablations (0 in production): 1 = no re-staging, 2 = no epilogue
@@ -48,7 +48,7 @@ struct ConvFwdArgs {
 
 // Epilogue features of the sliding-halo / sliding-accumulator kernels (compile-time bits)
 enum : int { SG_EP_SIGN = 1, SG_EP_MASK = 2, SG_EP_PN = 4, SG_EP_POOL = 8, SG_EP_PNB = 16,
-              SG_EP_RGB = 32, SG_EP_PWB = 128 /* conv_fwd3w only: to_rgb of the output / from_rgb's backward in the epilogue */ };
+              SG_EP_RGB = 32, SG_EP_PWB = 128, SG_EP_POOL3 = 256 /* with SG_EP_POOL: whole 2 x 2 x 2 blocks */ /* conv_fwd3w only: to_rgb of the output / from_rgb's backward in the epilogue */ };
 
 // conv3p.hip: one-pass 64 -> 32 sliding-accumulator kernel (replaces the two-pass K split where it applies)
 int sg_launch_fwd3p(ConvFwdArgs& a, const sg_conv_shape* s, hipStream_t st, bool* used);

@@ -235,6 +235,7 @@ def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel
     """y = epilogue(conv3d(x, coef*w)) with w in DHWIO; `flip` selects the data-gradient weights.
     Returns (y, pixel-norm scale or None, sign words of y or None).  pool (sg_conv_epilogue.pool): 1 -- y is the
     2 x 1 x 2 (D x H x W) block mean of the output, [n,cout,d/2,h,w/2]; 2 -- the 1 x 2 x 2 block mean, [n,cout,d,h/2,w/2];
+    3 -- the whole 2 x 2 x 2 block mean [n,cout,d/2,h/2,w/2] (32 input channels);
     returns None if no kernel of the build fuses it here.  pn_bwd = (y, scale) of a pixel-norm stage: the result is
     pushed through that stage's backward in the epilogue (sg_conv_epilogue.pn_bwd_y; mask_bits = the stage's sign words);
     None if no kernel does that for this layer.
@@ -265,10 +266,10 @@ def raw_conv(x, w, coef, flip, ups=False, bias=None, act=False, slope=0.2, pixel
     st = _stream()
     wp = _packed(w, coef, flip, shp, dt, lib, st)
     pool = int(pool)
-    if pool and (((d | wd) if pool == 1 else (h | wd)) & 1 or x.dim() != 5):
+    if pool and ({1: d | wd, 2: h | wd, 3: d | h | wd}[pool] & 1 or x.dim() != 5):
         return None
     y = None if pw_bwd is not None else \
-        _empty_like_shape(x, cout, {0: (d, h, wd), 1: (d // 2, h, wd // 2), 2: (d, h // 2, wd // 2)}[pool])
+        _empty_like_shape(x, cout, {0: (d, h, wd), 1: (d // 2, h, wd // 2), 2: (d, h // 2, wd // 2), 3: (d // 2, h // 2, wd // 2)}[pool])
     _check_signs(mask_bits, n * d * h * wd, cout)
     signs = _empty_signs(x.device, n, d, h, wd, cout) if want_signs else None
     scale = None
@@ -963,6 +964,7 @@ class _ConvPnActToRgb(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None, None, gw_rgb, gb_rgb, None
 
 
+_NO_POOL3 = bool(int(os.environ.get('SARAGAN_NO_POOL3', '0')))   # diagnostic: D x W means from the epilogue + the H pairs in a pass of their own
 _NO_POOL_FUSION = bool(int(os.environ.get('SARAGAN_NO_POOL_FUSION', '0')))   # diagnostic: conv and downscale3d apart
 
 
@@ -978,11 +980,17 @@ class _ConvBiasActPool(torch.autograd.Function):
     def forward(ctx, x, w, b, coef, slope, in_info=None):
         _note_all(x, w, b, coef, slope, in_info)
         mode = _pool_mode(x, w.shape[:3], x.shape[1], w.shape[-1]) if w.dim() == 5 else 0
-        res = raw_conv(x, w, coef, False, False, bias=b, act=True, slope=slope, want_signs=True, pool=mode) if mode else None
-        if res is None:
-            raise _lib.SgError('pool fusion not available for this layer')
-        ydw, _, signs = res
-        y = _Down.apply(ydw, 0.5, None, _POOL_REST[mode])
+        res = None
+        if mode == 1 and x.shape[1] == 32 and not _NO_POOL3:      # the whole 2 x 2 x 2 mean from the epilogue (sg_conv_epilogue.pool = 3)
+            res = raw_conv(x, w, coef, False, False, bias=b, act=True, slope=slope, want_signs=True, pool=3)
+        if res is not None:
+            y, _, signs = res
+        else:
+            res = raw_conv(x, w, coef, False, False, bias=b, act=True, slope=slope, want_signs=True, pool=mode) if mode else None
+            if res is None:
+                raise _lib.SgError('pool fusion not available for this layer')
+            ydw, _, signs = res
+            y = _Down.apply(ydw, 0.5, None, _POOL_REST[mode])
         ctx.save_for_backward(x, w, signs)
         ctx.cfg = (coef, slope)
         ctx.has_b = b is not None
@@ -1094,10 +1102,15 @@ class _PooledDgradGather(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             # block_sum(M * conv(ggx)) / 8: the mask and the 2 x 1 x 2 block means in the convolution's epilogue
             # (sg_conv_epilogue.pool with mask_bits), the H pairs by sg_downscale_sum -- the 64-channel tensor is never written
-            res = None
+            res = res3 = None
             if not torch.is_grad_enabled() and not _NO_POOL_FUSION and _pool_mode(ggx, (3, 3, 3), 32, 64) == 1:
-                res = raw_conv(ggx, w, coef, False, False, mask_bits=signs, mask_slope=slope, pool=1)
-            if res is not None:
+                if not _NO_POOL3:
+                    res3 = raw_conv(ggx, w, coef, False, False, mask_bits=signs, mask_slope=slope, pool=3)
+                if res3 is None:
+                    res = raw_conv(ggx, w, coef, False, False, mask_bits=signs, mask_slope=slope, pool=1)
+            if res3 is not None:
+                g_gy = res3[0]
+            elif res is not None:
                 g_gy = _Down.apply(res[0], 0.5, None, _POOL_REST[1])
             else:
                 g_gy = _Down.apply(_Conv.apply(ggx, w, coef, False, False), 0.125, None, (2, 2, 2), signs, slope)

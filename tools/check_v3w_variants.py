@@ -170,6 +170,25 @@ def main():
             if wst > 5e-3:
                 ok = False
                 print('   ** MISMATCH')
+    # ---- whole 2 x 2 x 2 means from the epilogue (pool = 3) against the D x W means + the H pairs
+    for (n, cout, sp) in [(2, 64, (6, 128, 256)), (3, 32, (4, 72, 96)), (1, 64, (16, 64, 64))]:
+        x = torch.randn(n, 32, *sp, device=dev).bfloat16().contiguous(memory_format=torch.channels_last_3d)
+        w = torch.randn(3, 3, 3, 32, cout, device=dev)
+        b = torch.randn(cout, device=dev) * 0.3
+        coef = (2.0 / (27 * 32)) ** 0.5
+        words = torch.randint(-2 ** 31, 2 ** 31 - 1, (n * sp[0] * sp[1] * sp[2] * (cout // 32),), device=dev, dtype=torch.int64).to(torch.int32)
+        for name, kw in (('pool3+signs', dict(bias=b, act=True, want_signs=True)), ('masked+pool3', dict(mask_bits=words, mask_slope=0.2))):
+            got = F.raw_conv(x, w, coef, False, False, pool=3, **kw)
+            ref = F.raw_conv(x, w, coef, False, False, pool=1, **kw)
+            print(f'n{n} 32->{cout} {sp} {name}:', 'declined' if got is None else 'ran', flush=True)
+            if got is None or ref is None:
+                ok = False
+                continue
+            ref_y = F._Down.apply(ref[0], 0.5, None, (1, 2, 1))
+            wst = cmp(name, [got[0], got[2]], [ref_y, ref[2]])
+            if wst > 2e-2:
+                ok = False
+                print('   ** MISMATCH')
     print('OK' if ok else 'FAILED')
     return ok
 

@@ -109,7 +109,7 @@ def main():
             yp = torch.empty(n, d // 2, h, w // 2, cout, device=dev, dtype=torch.bfloat16)
             ep_pool = ConvEpilogue(bias.data_ptr(), 1, 0.2, 0, 1e-8, None, None, 0.0, sout.data_ptr())
             ep_pool.pool = 1
-            twice(f'fwd pooled (D x W mean) {name}', 'conv_fwd3s', vox * (cin + cout / 4) * 2 + vox * nw * 4 + 27 * cin * cout * 2, flops,
+            twice(f'fwd pooled (D x W mean) {name}', 'conv_fwd3', vox * (cin + cout / 4) * 2 + vox * nw * 4 + 27 * cin * cout * 2, flops,
                   lambda: _lib.check(lib.sg_conv3d_fwd(x.data_ptr(), wp.data_ptr(), yp.data_ptr(), C.byref(shp), C.byref(ep_pool), dt, st)))
         del x, dy, y, bits, sout, ws, fws
     # round 3: the sub-pixel up-convolution (one launch for all eight classes), low-resolution input -> fine output

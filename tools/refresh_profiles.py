@@ -95,6 +95,8 @@ def main():
     copy('bench_conv_table.txt', 'bench_conv_table.txt')
     others = [last_json_line(os.path.join(SRC, f'bench_config{c}.json')) for c in (1, 2, 4, 5)
               if os.path.exists(os.path.join(SRC, f'bench_config{c}.json'))]
+    if os.path.exists(os.path.join(SRC, 'bench_mixing.json')):      # configs[2] in a mixing phase (alpha 0.5, freeze train ops)
+        others.append(last_json_line(os.path.join(SRC, 'bench_mixing.json')))
     open(os.path.join(DST, TAG + 'bench_other_configs.jsonl'), 'w').write('\n'.join(o for o in others if o) + '\n')
     copy('bench_reference_point.jsonl', 'bench_reference_point.jsonl')
     copy('bench_repeats.jsonl', 'bench_repeats.jsonl')

@@ -90,12 +90,13 @@ def _q(x):
 def hip_pool_mode(n, cin, cout, d, h, w, k):
     """Which 2x2x2-pooling fusion the bf16 HIP path uses for downscale3d(leaky_relu(conv3d + b)) of this shape
     (restates saragan_amd/functional.py:_pool_mode; checked against it in tests/test_oracle.py): 1 = the conv epilogue
-    stores D x W pair means and a second kernel pools H, 2 = H x W pairs then D, 0 = the activation is stored and pooled."""
+    stores D x W pair means and a second kernel pools H, 2 = H x W pairs then D, 3 = the epilogue stores the whole 2x2x2 mean
+    (one rounding; conv_fwd3w: 32 input channels), 0 = the activation is stored and pooled."""
     if tuple(k) != (3, 3, 3) or (d | h | w) & 1 or w % 32:
         return 0
     nvox = n * d * h * w
     if cin <= 32 and cin % 8 == 0 and cout % 32 == 0 and d >= 4 and nvox >= (1 << 20):
-        return 1
+        return 3 if cin == 32 and h >= 8 else 1
     if cin % 16 == 0 and cout % 64 == 0 and nvox >= (1 << 18):
         return 2
     return 0
@@ -196,6 +197,8 @@ def _downscale_stored(y, cin, k):
         return _q(F.avg_pool3d(_q(F.avg_pool3d(y, (2, 1, 2))), (1, 2, 1)))
     if mode == 2:
         return _q(F.avg_pool3d(_q(F.avg_pool3d(y, (1, 2, 2))), (2, 1, 1)))
+    if mode == 3:
+        return _q(F.avg_pool3d(y, 2))
     return _q(downscale3d(_q(y)))
 
 

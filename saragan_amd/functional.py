@@ -981,8 +981,9 @@ class _ConvBiasActPool(torch.autograd.Function):
         _note_all(x, w, b, coef, slope, in_info)
         mode = _pool_mode(x, w.shape[:3], x.shape[1], w.shape[-1]) if w.dim() == 5 else 0
         res = None
-        if mode == 1 and x.shape[1] == 32 and not _NO_POOL3:      # the whole 2 x 2 x 2 mean from the epilogue (sg_conv_epilogue.pool = 3)
+        if mode == 3:      # the whole 2 x 2 x 2 mean from the epilogue (sg_conv_epilogue.pool = 3): one rounding
             res = raw_conv(x, w, coef, False, False, bias=b, act=True, slope=slope, want_signs=True, pool=3)
+            mode = 1
         if res is not None:
             y, _, signs = res
         else:
@@ -1103,8 +1104,9 @@ class _PooledDgradGather(torch.autograd.Function):
             # block_sum(M * conv(ggx)) / 8: the mask and the 2 x 1 x 2 block means in the convolution's epilogue
             # (sg_conv_epilogue.pool with mask_bits), the H pairs by sg_downscale_sum -- the 64-channel tensor is never written
             res = res3 = None
-            if not torch.is_grad_enabled() and not _NO_POOL_FUSION and _pool_mode(ggx, (3, 3, 3), 32, 64) == 1:
-                if not _NO_POOL3:
+            mode = _pool_mode(ggx, (3, 3, 3), 32, 64) if not torch.is_grad_enabled() else 0
+            if mode in (1, 3):
+                if mode == 3:
                     res3 = raw_conv(ggx, w, coef, False, False, mask_bits=signs, mask_slope=slope, pool=3)
                 if res3 is None:
                     res = raw_conv(ggx, w, coef, False, False, mask_bits=signs, mask_slope=slope, pool=1)
@@ -1257,6 +1259,8 @@ def _pool_mode(x, k, cin, cout):
         return 0
     nvox = n * d * h * wd
     if cin <= 32 and cin % 8 == 0 and cout % 32 == 0 and d >= 4 and nvox >= (1 << 20):
+        if cin == 32 and h >= 8 and not _NO_POOL3:
+            return 3    # wave-private planes (conv_fwd3w): the whole 2 x 2 x 2 mean in the epilogue, rounded once
         return 1        # sliding-halo kernel: D x W pairs in the epilogue
     if cin % 16 == 0 and cout % 64 == 0 and nvox >= (1 << 18):
         return 2        # streamed ping-pong kernel: H x W pairs
@@ -1309,7 +1313,7 @@ def _upconv_dgrad(g, w, coef, flip):
             if gx is not None:
                 return gx
         cin, cout = (w.shape[4], w.shape[3]) if flip else (w.shape[3], w.shape[4])
-        mode = _pool_mode(g, w.shape[:3], cin, cout)
+        mode = min(_pool_mode(g, w.shape[:3], cin, cout), 2)      # (3: this caller keeps the D x W means + the H pairs)
         if mode:
             res = raw_conv(g, w, coef, flip, False, pool=mode)
             if res is not None:      # means over four voxels; the remaining pairs and the factor back to a sum follow

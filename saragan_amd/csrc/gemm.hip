@@ -13,6 +13,13 @@
 //
 // Forward and data gradient (packed weights with transpose_flip) alike; optional fused nearest-x2 gather of the input
 // (upsample_in: the generator's conv_1 of the 2x8x8 / 4x16x16 levels).  GEMM orientation as in conv3d.hip.
+//
+// Small batches (round 5: the reference's own batch rule gives 1-4 volumes per rank at 128^2 and above): a tile may hold samples
+// beyond the batch (sixteen 1x4x4 samples per tile at batch 2: their halo rows stay zero, their outputs are not stored), and the
+// 3x3x3 layers of the 4x16x16 level run here too while the batch is small (one plane per tile, K steps = (16-channel chunk, kd)):
+// the spatial kernels took 36-124 us per launch there at batch 2, streaming the whole weight tensor through every 128-voxel tile.
+// A tile covers whole planes, so its halo in H and W is always zero: the image in LDS is cleared once and only interior voxels
+// are staged (<= 3 pieces of 16 B per thread and chunk).
 #include "common.h"
 #include "prof.h"
 
@@ -78,20 +85,22 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(GemmConvArgs a) {
     const int vw = q % a.w, vh = (q / a.w) % a.h, vd = (q / hw_) % a.TD, vn = q / (hw_ * a.TD);
     xbase[mt] = vn * sampB + vd * planeB + vh * rowB + vw * 32 + hh * 16;
   }
-  // staging plan: up to 3 halo pieces and 5 weight pieces (16 B) per thread and step
+  // staging plan: up to 3 interior pieces and 5 weight pieces (16 B) per thread and step.  Interior voxel (cn, cd, vh, vw) of the
+  // halo image: its H / W border is zero for every tile (tiles are whole planes) and is cleared once, below
   const int Di = a.ups ? a.d >> 1 : a.d, Hi = a.ups ? a.h >> 1 : a.h, Wi = a.ups ? a.w >> 1 : a.w;
   int xoff[3];              // (element offsets: n * d * h * w * cin < 2^31 is checked by the plan)
   int xdst[3];
+  const int ipieces = a.TN * a.HD * hw_ * 2;
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const int p = tid + k * 512;
     xdst[k] = -1; xoff[k] = -1;
-    if (p < a.hv * 2) {
-      const int hvx = p >> 1, half = p & 1;
-      const int cw = hvx % a.HW, ch = (hvx / a.HW) % a.HH, cd = (hvx / (a.HW * a.HH)) % a.HD, cn = hvx / (a.HW * a.HH * a.HD);
-      int dd = d0 + cd - a.pd, yy = ch - a.ph, ww = cw - a.pw;
-      xdst[k] = hvx * 32 + half * 16;
-      if (dd >= 0 && dd < a.d && yy >= 0 && yy < a.h && ww >= 0 && ww < a.w) {
+    if (p < ipieces) {
+      const int iv = p >> 1, half = p & 1;
+      const int vw = iv % a.w, vh = (iv / a.w) % a.h, cd = (iv / hw_) % a.HD, cn = iv / (hw_ * a.HD);
+      int dd = d0 + cd - a.pd, yy = vh, ww = vw;
+      if (dd >= 0 && dd < a.d && n0 + cn < a.N) {
+        xdst[k] = cn * sampB + cd * planeB + (vh + a.ph) * rowB + (vw + a.pw) * 32 + half * 16;
         if (a.ups) { dd >>= 1; yy >>= 1; ww >>= 1; }
         xoff[k] = ((((n0 + cn) * Di + dd) * Hi + yy) * Wi + ww) * a.cin + half * 8;
       }
@@ -101,8 +110,7 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(GemmConvArgs a) {
   auto load_x = [&](u32x4 (&st)[3], int chunk) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(a.x + (xoff[k] >= 0 ? xoff[k] : 0) + chunk * 16);
-      st[k] = xoff[k] >= 0 ? v : u32x4{0u, 0u, 0u, 0u};
+      st[k] = *reinterpret_cast<const u32x4*>(a.x + (xoff[k] >= 0 ? xoff[k] : 0) + chunk * 16);
     }
   };
   auto store_x = [&](const u32x4 (&st)[3], char* dst) {
@@ -138,20 +146,28 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(GemmConvArgs a) {
 
   const int s0 = ks * a.steps_per_split;
   const int s1 = s0 + a.steps_per_split < a.steps ? s0 + a.steps_per_split : a.steps;
-  // One step = one 16-channel chunk (all taps: the levels this kernel takes have 1x3x3 kernels, one tap group).  These
-  // launches are short (8-32 steps per block) and start cold, so a step's loads are requested TWO steps ahead: two register
-  // sets alternate (A: even steps, B: odd steps), each written to the LDS buffer of its parity at the end of the step
-  // before its use.  (With one set, requested one step ahead, a 2x8x8 layer took 60 us: every step waited ~2 us for L2.)
-  u32x4 sx[3], swA[5], swB[5];      // (the halo image, a third of the bytes, keeps one set: requested one step ahead)
-  load_x(sx, s0);
-  load_w(swA, s0, 0);
-  if (s0 + 1 < s1) load_w(swB, s0 + 1, 0);
+  // One step = (16-channel chunk, tap group of 9 taps = one kd).  These launches are short (3-32 steps per block) and start cold,
+  // so a step's weights are requested TWO steps ahead: two register sets alternate (A: even steps, B: odd steps), each written to
+  // the LDS buffer of its parity at the end of the step before its use.  (With one set, requested one step ahead, a 2x8x8 layer
+  // took 60 us: every step waited ~2 us for L2.)  The halo image changes per CHUNK: requested during the chunk's last step
+  // (one set), written to the other image buffer at that step's end.
+  u32x4 sx[3], swA[5], swB[5];
+  {   // clear both halo images (the border, the planes outside the volume and the samples beyond the batch stay zero)
+    const int nclr = (2 * kGX) / 16;
+    for (int p = tid; p < nclr; p += 512) *reinterpret_cast<u32x4*>(xbuf + p * 16) = u32x4{0u, 0u, 0u, 0u};
+  }
+  int chunk = s0 / a.ntg, tg = s0 - chunk * a.ntg;      // (scalars: the step, its chunk and tap group; the next two steps' likewise)
+  int chunk1 = tg + 1 < a.ntg ? chunk : chunk + 1, tg1 = tg + 1 < a.ntg ? tg + 1 : 0;
+  load_x(sx, chunk);
+  load_w(swA, chunk, tg);
+  if (s0 + 1 < s1) load_w(swB, chunk1, tg1);
+  __syncthreads();
   store_x(sx, xbuf);
   store_w(swA, wbuf);
   __syncthreads();
-  auto compute = [&](int buf) {
+  int xpar = 0;             // which halo image holds the current chunk
+  auto compute = [&](int buf, const char* xs) {
     const char* ws = wbuf + buf * kGW + (nw * 2) * 1024 + lane * 16;
-    const char* xs = xbuf + buf * kGX;
 #pragma unroll
     for (int tl = 0; tl < 9; ++tl) {
       const int toff = (tl / 3) * rowB + (tl % 3) * 32;
@@ -166,20 +182,26 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(GemmConvArgs a) {
       if (tl & 1) __builtin_amdgcn_sched_barrier(0);     // (caps how many taps' fragments the scheduler keeps in flight: registers)
     }
   };
+  // one step on weight buffer `buf`: `swFree` takes the weights of the step after next, `swNext` (the next step's) goes to LDS
+  auto step = [&](int s, int buf, u32x4 (&swFree)[5], u32x4 (&swNext)[5]) {
+    const bool has1 = s + 1 < s1, has2 = s + 2 < s1;
+    const bool newx = has1 && tg1 == 0;
+    const int chunk2 = tg1 + 1 < a.ntg ? chunk1 : chunk1 + 1, tg2 = tg1 + 1 < a.ntg ? tg1 + 1 : 0;
+    if (newx) load_x(sx, chunk1);
+    if (has2) load_w(swFree, chunk2, tg2);
+    compute(buf, xbuf + xpar * kGX + tg * planeB);
+    if (has1) {
+      if (newx) store_x(sx, xbuf + (xpar ^ 1) * kGX);
+      store_w(swNext, wbuf + (buf ^ 1) * kGW);
+    }
+    __syncthreads();
+    if (newx) xpar ^= 1;
+    chunk = chunk1; tg = tg1; chunk1 = chunk2; tg1 = tg2;
+  };
   for (int s = s0; s < s1; s += 2) {
-    // even step s: buffers 0.  Weight set A is free: request step s + 2.  Set B (step s + 1) goes to buffer 1 afterwards.
-    if (s + 1 < s1) load_x(sx, s + 1);
-    if (s + 2 < s1) load_w(swA, s + 2, 0);
-    compute(0);
-    if (s + 1 < s1) { store_x(sx, xbuf + kGX); store_w(swB, wbuf + kGW); }
-    __syncthreads();
+    step(s, 0, swA, swB);
     if (s + 1 >= s1) break;
-    // odd step s + 1: buffers 1.  Set B is free: request step s + 3.  Set A (step s + 2) goes to buffer 0 afterwards.
-    if (s + 2 < s1) load_x(sx, s + 2);
-    if (s + 3 < s1) load_w(swB, s + 3, 0);
-    compute(1);
-    if (s + 2 < s1) { store_x(sx, xbuf); store_w(swA, wbuf); }
-    __syncthreads();
+    step(s + 1, 1, swB, swA);
   }
 
   // output: voxel m of the flattened (n, d, h, w) volume.  (The lane's coordinates are derived again from an opaque copy
@@ -193,6 +215,7 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(GemmConvArgs a) {
     const int q = (mw2 * 2 + mt) * 32 + r2;
     const int vsp = q % (hw_ * a.TD), vn = q / (hw_ * a.TD);
     const int64_t m = (int64_t)(n0 + vn) * svox + (int64_t)d0 * hw_ + vsp;
+    if (n0 + vn >= a.N) continue;      // (a sample slot beyond the batch: nothing to store)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int ntg_i = nb * 4 + nw * 2 + nt;
@@ -253,29 +276,42 @@ static bool gemm_plan(const sg_conv_shape* s, GemmConvArgs* a) {
   if ((int64_t)s->n * s->d * s->h * s->w * s->cin >= (1ll << 31)) return false;
   const int hw = s->h * s->w;
   if (s->w > 16 || s->h > 16 || hw > 256 || 256 % hw) return false;
-  // 1x3x3 kernels on volumes of <= 128 voxels: 1x4x4 and 2x8x8.  (At 4x16x16 the 27-tap layers are bound by the L2 -> LDS
-  // rate in this tiling as in the streamed kernel's, which stages through LDS-DMA and is ahead there: 169 against 221 us
-  // for 128 -> 512 at batch 32.)
-  if (!(s->kd == 1 && s->kh == 3 && s->kw == 3) || s->d * s->h * s->w > 128) return false;
+  const bool k133 = s->kd == 1 && s->kh == 3 && s->kw == 3, k333 = s->kd == 3 && s->kh == 3 && s->kw == 3;
+  // 1x3x3 kernels on volumes of <= 128 voxels: 1x4x4 and 2x8x8.  At 4x16x16 the 27-tap layers are bound by the L2 -> LDS rate in
+  // this tiling as in the streamed kernel's, which stages through LDS-DMA and is ahead there at batch 32 (169 against 221 us for
+  // 128 -> 512); with few samples (SG_GEMM_K333_MAXVOX voxels in the batch, default 8192 = batch 8) the streamed kernel has
+  // too few tiles and the layer runs here, one plane per tile.
+  if (k133) { if (s->d * hw > 128) return false; }
+  else if (k333) { if (hw != 256 || (int64_t)s->n * s->d * hw > sg_cfg().gemm_k333_maxvox) return false; }
+  else return false;
   if (s->upsample_in && ((s->d | s->h | s->w) & 1)) return false;
   int td = 256 / hw;
   if (td > s->d) td = s->d;
   if (s->d % td) return false;
   const int tn = 256 / (td * hw);
-  if (tn < 1 || tn * td * hw != 256 || s->n % tn) return false;
+  if (tn < 1 || tn * td * hw != 256) return false;
   a->TN = tn; a->TD = td;
   a->pd = s->kd / 2; a->ph = 1; a->pw = 1;
   a->HD = td + 2 * a->pd; a->HH = s->h + 2; a->HW = s->w + 2;
   a->hv = tn * a->HD * a->HH * a->HW;
-  if (a->hv * 32 > kGX || a->hv * 2 > 3 * 512) return false;
+  if (a->hv * 32 > kGX || tn * a->HD * hw * 2 > 3 * 512) return false;      // the image in LDS; interior pieces per chunk
   a->nTd = s->d / td;
   a->taps = s->kd * 9; a->kh = 3; a->kw = 3;
   a->TG = 9; a->ntg = s->kd;
   a->nchunk = s->cin / 16; a->ntile = s->cout / 32;
   a->steps = a->nchunk * a->ntg;
-  const int64_t tiles = (int64_t)(s->n / tn) * a->nTd * (s->cout / 128);
+  const int64_t tiles = (int64_t)sg_cdiv(s->n, tn) * a->nTd * (s->cout / 128);
+  // K split: fill the 256 CUs; every split gets >= 1 step.  On the 27-tap layers (M = 1024 voxels per sample) a split costs a
+  // pass of f32 partial tiles out and back (2 x 4 B x M x cout per split, ~3 TB/s) against the ~1 us per step it saves: stop
+  // where doubling no longer pays.
   int ks = 1;
-  while (tiles * ks < 192 && ks * 2 <= a->steps && ks < 16) ks *= 2;      // fill the 256 CUs; every split gets >= 1 step
+  if (k333) {
+    const double part_us = 2.0 * 4.0 * (double)s->n * s->d * hw * s->cout / 3.0e6;
+    auto est = [&](int k) { return (double)a->steps / k + (k > 1 ? part_us * k : 0.0); };
+    while (tiles * ks < 192 && ks * 2 <= a->steps && ks < 16 && est(2 * ks) < est(ks)) ks *= 2;
+  } else {
+    while (tiles * ks < 192 && ks * 2 <= a->steps && ks < 16) ks *= 2;
+  }
   a->steps_per_split = sg_cdiv(a->steps, ks);
   a->ksplit = sg_cdiv(a->steps, a->steps_per_split);
   return true;
@@ -307,7 +343,7 @@ int sg_gemm_conv_fwd(const void* x, const void* wp, void* y, const sg_conv_shape
   auto kern = conv_gemm_kernel;
   SG_ALLOW_160K_LDS(kern);
   const size_t lds = 2 * (size_t)kGW + 2 * (size_t)kGX;
-  const unsigned tiles = (unsigned)((s->n / a.TN) * a.nTd);
+  const unsigned tiles = (unsigned)(sg_cdiv(s->n, a.TN) * a.nTd);
   if (a.ksplit > 1) SG_KNAME("conv_gemm (K split)");      // (SG_KNAME formats once per call site)
   else SG_KNAME("conv_gemm");
   hipLaunchKernelGGL(kern, dim3(tiles, (unsigned)(s->cout / 128), (unsigned)a.ksplit), dim3(512), lds, st, a);

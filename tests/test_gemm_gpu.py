@@ -1,7 +1,8 @@
 """The GEMM-tiled convolution of the low-resolution levels (csrc/gemm.hip: 256 voxels of the folded batch x 128 output
 channels per block, K split over blocks where the level is too small to fill the chip) against the spatial kernels
 (SG_NO_GEMM=1) and the fp64 oracle: the shapes of pgan 's' at 1x4x4, 2x8x8 and 4x16x16 (pgan/generator.py:26-45,
-pgan/discriminator.py:48-68) at batch 32 / 64, forward with bias + LeakyReLU + sign words, the data gradient with a
+pgan/discriminator.py:48-68) at batch 32 / 64 and at the batches of 1-5 the reference's own batch rule gives (tiles with
+empty sample slots; the 3x3x3 layers of the 4x16x16 level), forward with bias + LeakyReLU + sign words, the data gradient with a
 LeakyReLU mask, the fused nearest-x2 gather of the generator's conv_1.  The kernel name is asserted."""
 import ctypes as C
 
@@ -21,6 +22,18 @@ CASES = [
     (64, 512, 512, (1, 4, 4), (1, 3, 3), False, True),
     (256, 128, 256, (2, 8, 8), (1, 3, 3), False, False),      # enough tiles without a K split
     (32, 512, 512, (2, 8, 8), (1, 3, 3), True, True),
+    # small batches (round 5): sample slots of a tile beyond the batch; the 27-tap layers of the 4x16x16 level, one plane per tile
+    (2, 512, 512, (1, 4, 4), (1, 3, 3), False, True),         # 2 of a tile's 16 sample slots
+    (5, 256, 256, (1, 4, 4), (1, 3, 3), False, True),
+    (19, 128, 128, (1, 4, 4), (1, 3, 3), False, True),        # a whole tile and 3 slots of the next
+    (3, 512, 512, (2, 8, 8), (1, 3, 3), False, True),         # sample pairs: the last tile half empty
+    (1, 256, 256, (2, 8, 8), (1, 3, 3), True, True),
+    (2, 128, 128, (4, 16, 16), (3, 3, 3), False, True),
+    (2, 128, 512, (4, 16, 16), (3, 3, 3), False, None),       # (the K split follows the partial-tile cost: either variant)
+    (2, 512, 128, (4, 16, 16), (3, 3, 3), False, True),
+    (1, 512, 128, (4, 16, 16), (3, 3, 3), True, True),        # the generator's conv_1 of that level: nearest-x2 gather fused
+    (4, 128, 128, (4, 16, 16), (3, 3, 3), False, None),
+    (3, 256, 128, (4, 16, 16), (3, 3, 3), False, None),
 ]
 
 
@@ -65,7 +78,9 @@ def test_gemm_conv_matches_spatial_kernels_and_oracle(case, sg_env):
     got, kern = run()
     # (the data gradient has the channel counts swapped and may split differently: every launch is a GEMM kernel, and the
     # forward's variant is the expected one)
-    assert set(kern) <= {'conv_gemm', 'conv_gemm (K split)'} and ('conv_gemm (K split)' if split else 'conv_gemm') in kern, kern
+    assert set(kern) <= {'conv_gemm', 'conv_gemm (K split)'} and kern, kern
+    if split is not None:
+        assert ('conv_gemm (K split)' if split else 'conv_gemm') in kern, kern
     sg_env(SG_NO_GEMM=1)
     ref, kern_ref = run()
     assert not any('gemm' in k_ for k_ in kern_ref), kern_ref

@@ -11,7 +11,7 @@ the fixture keeps, per variable, what pins it without shipping it:
 plus the three losses, and for gen_sample its sum, sum of squares and SAMPLES voxels.  (< 2 MB compressed.)
 The inputs are not stored: tests regenerate them from the seeds (oracle/make_loss_curve.py: cfg3_setup / cfg3_inputs).
 
-An fp64 step of this size takes a few minutes on 8 cores and ~25 GB.   usage: python oracle/make_step_cfg3.py [f64] [bf16emu]
+An fp64 step of this size takes a few minutes on 8 cores and ~25 GB.   usage: python oracle/make_step_cfg3.py [f64] [bf16emu] [bf16emu64]
 """
 import contextlib
 import os
@@ -40,13 +40,15 @@ def sample_index(name, numel):
 
 
 def run(arith):
-    dtype = torch.float64 if arith == 'f64' else torch.float32
+    # 'bf16emu64': the emulation's rounding points with fp64 accumulation -- not a reference: its distance from 'bf16emu' (the same
+    # rounding points, f32 accumulation) is what the ORDER / PRECISION of the sums alone is worth after the network's depth
+    dtype = torch.float64 if arith in ('f64', 'bf16emu64') else torch.float32
     s = MC.cfg3_setup(dtype, 'cfg3')
     p = {k: v.clone() for k, v in s['p0'].items()}
     shadow = {k: v.clone() for k, v in s['p0'].items()}
     ag, ad = O.TFAdam(0.0, 0.9), O.TFAdam(0.0, 0.9)
     real, rnd = MC.cfg3_inputs(s, 0, dtype)
-    emu = O.bf16_emulation() if arith == 'bf16emu' else contextlib.nullcontext()
+    emu = O.bf16_emulation() if arith in ('bf16emu', 'bf16emu64') else contextlib.nullcontext()
     t0 = time.time()
     with emu:
         out = O.step_simultaneous(p, ag, ad, shadow, rnd, real, s['alpha'], s['cfg'], s['lr'], s['lr'])
@@ -73,7 +75,7 @@ def run(arith):
 if __name__ == '__main__':
     torch.set_num_threads(int(os.environ.get('ORACLE_THREADS', '8')))
     have = dict(np.load(OUT)) if os.path.exists(OUT) else {}
-    for arith in (sys.argv[1:] or ['f64', 'bf16emu']):
+    for arith in (sys.argv[1:] or ['f64', 'bf16emu', 'bf16emu64']):
         have = {k: v for k, v in have.items() if not k.startswith(arith + ':')}
         have.update(run(arith))
         np.savez_compressed(OUT, **have)

@@ -451,7 +451,8 @@ def test_config3_whole_step_against_the_oracle(golden_dir):
     Adam's first step with beta1 = 0 moves every weight by lr * g / (|g| + eps'): the sign of g -- so weights and EMA shadows are
     compared where the oracle's gradient is clearly non-zero (|g| > 5 % of the tensor's rms; bf16: > 50 %), exactly (1e-5).
     Measured (round 5, reproducible mode): fp32 worst gradient entry 8.3e-4, worst norm 1.5e-4, 0 of 27 066 weights off; bf16
-    weights <= 0.077 / biases <= 0.117 relative L2 from the emulation where the emulation is 0.15-0.24 from fp64."""
+    weights <= 0.092 / biases <= 0.151 relative L2 from the emulation, where the emulation is 0.07-0.24 from fp64 and 0.09-0.32
+    from ITSELF run with fp64 sums (the yardstick of the bound: see the comment at `acc` below)."""
     import saragan_amd
     import saragan_amd.optimization as opt
     from oracle import make_loss_curve as MC
@@ -467,6 +468,7 @@ def test_config3_whole_step_against_the_oracle(golden_dir):
     report, bad = {}, []
     for dtype, arith, gtol, ltol in ((torch.float32, 'f64', 1e-3, 1e-4), (torch.bfloat16, 'bf16emu', 5e-2, 2e-2)):
         assert f'{arith}:gen_loss' in z.files, f'python oracle/make_step_cfg3.py {arith}'
+        assert arith != 'bf16emu' or 'bf16emu64:gen_loss' in z.files, 'python oracle/make_step_cfg3.py bf16emu64'
         s = MC.cfg3_setup(torch.float32, 'cfg3')
         set_compute_dtype(dtype)
         saragan_amd.set_deterministic(True)
@@ -513,7 +515,9 @@ def test_config3_whole_step_against_the_oracle(golden_dir):
             if abs(ssq - float(z[f'{arith}:gen_sample_sumsq'])) > (1e-3 if dtype == torch.float32 else 3e-2) * float(z[f'{arith}:gen_sample_sumsq']):
                 bad.append((arith, 'gen_sample_sumsq', ssq, float(z[f'{arith}:gen_sample_sumsq'])))
             worst_g, worst_n, nw, nsign = (0.0, ''), (0.0, ''), 0, 0
+            worst_ratio = (0.0, '')
             per_tensor = {}
+            hip_samples = {}      # (kept entries of the HIP gradients: gpurun_out/step_cfg3_hip_samples_<arith>.npz, for offline study)
             for hv, grads in ((tup[7], gg), (tup[9], dg)):
                 for v, g in zip(hv, grads):
                     k = v.key
@@ -521,21 +525,28 @@ def test_config3_whole_step_against_the_oracle(golden_dir):
                     idx = torch.as_tensor(sample_index(k, gd.numel()))
                     ref = z[f'{arith}:g:{k}'].astype(np.float64)
                     got = gd[idx].numpy()
+                    hip_samples[k] = got.astype(np.float32)
                     if dtype == torch.float32:      # largest deviation of a kept entry, relative to the largest kept entry
                         e = float(np.abs(got - ref).max() / max(1e-30, np.abs(ref).max()))
                         lim = gtol
                     else:
                         # relative L2 over the kept entries, as every bf16 gradient bound of this suite (tests/cfgutil.py:
-                        # bf16_emulation_report: 0.05 weights / 0.10 biases) -- or, where the emulation ITSELF is further than that
-                        # from the fp64 oracle (the deepest discriminator layers behind the gradient penalty's double backward:
-                        # up to 0.24), 0.75 x the emulation's own departure: the HIP result must be closer to the emulation than
-                        # the emulation is to exact arithmetic, and no further from exact than 1.25 x the emulation is
+                        # bf16_emulation_report: 0.05 weights / 0.10 biases) -- or, where that is larger, 1.25 x the distance between
+                        # TWO RUNS OF THE EMULATION ITSELF that differ only in the precision of their sums (`bf16emu64`: the same
+                        # rounding points, fp64 accumulation): 0.6-24 % on this network.  A sum that lands on the other side of a
+                        # bf16 rounding boundary flips one stored entry by an ulp (1e-4 of the entries of the first stored tensor
+                        # differ between the HIP path and the emulation, tests/diag_emulation_stores.py), every flip perturbs
+                        # everything downstream and flips 1-2 % of it, and after seven stored tensors 27 % of the entries differ:
+                        # no two implementations with different summation orders are closer than that, whatever their rounding
+                        # points.  Measured: HIP-vs-emulation is 0.36-0.88 (one tensor: 1.04) of emulation-vs-emulation.
                         e = float(np.linalg.norm(got - ref) / max(1e-30, np.linalg.norm(ref)))
                         r64 = z[f'f64:g:{k}'].astype(np.float64)
                         own = float(np.linalg.norm(ref - r64) / max(1e-30, np.linalg.norm(r64)))
                         e64 = float(np.linalg.norm(got - r64) / max(1e-30, np.linalg.norm(r64)))
-                        lim = max(gtol if k.endswith('weight') else 2 * gtol, 0.75 * own)
-                        if e64 > 1.25 * own + gtol:
+                        acc = float(np.linalg.norm(z[f'bf16emu64:g:{k}'].astype(np.float64) - ref) / max(1e-30, np.linalg.norm(ref)))
+                        lim = max(gtol if k.endswith('weight') else 2 * gtol, 1.25 * acc)
+                        worst_ratio = max(worst_ratio, (e / max(acc, 1e-30) if e > 1e-3 else 0.0, k))
+                        if e64 > 1.25 * own + gtol:      # ... and no further from exact arithmetic than 1.25 x the emulation is
                             bad.append((arith, 'grad vs fp64', k, e64, own))
                     nref = float(z[f'{arith}:gnorm:{k}'])
                     en = abs(float(gd.norm()) - nref) / max(1e-30, nref)
@@ -555,7 +566,11 @@ def test_config3_whole_step_against_the_oracle(golden_dir):
                     nsign += flips
                     if dtype == torch.float32 and (flips > 0 or (ds > 1e-6).any()):
                         bad.append((arith, 'weight/ema', k, flips, float(dw.max()) if dw.size else 0.0))
-            rep.update(worst_grad=worst_g, worst_norm=worst_n, weights_compared=nw, weights_off=nsign, per_tensor=per_tensor)
+            rep.update(worst_grad=worst_g, worst_norm=worst_n, weights_compared=nw, weights_off=nsign, per_tensor=per_tensor,
+                       worst_ratio_to_emulation_vs_emulation=worst_ratio)
+            out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+            if os.path.isdir(out_dir):
+                np.savez_compressed(os.path.join(out_dir, f'step_cfg3_hip_samples_{arith}.npz'), **hip_samples)
             if dtype == torch.bfloat16 and nsign > 1e-3 * nw:      # (bf16: compared where |g| > half the tensor's rms)
                 bad.append((arith, 'weights off', nsign, nw))
             report[arith] = rep

@@ -49,6 +49,7 @@ struct sg_config {
   int dbg_flags;                             // SG_DBG_FLAGS
   int no_small;                              // SG_NO_SMALL: the small-channel 2-D layers through the MFMA kernels (A/B, tests)
   int deterministic;                         // SG_DETERMINISTIC: no float atomics anywhere (weight-gradient slabs, ordered sums)
+  int gemm_ks_model;                         // SG_GEMM_KS_MODEL: K split of the 1x3x3 levels from the partial-tile cost model too (experiment)
   int gemm_k333_maxvox;                      // SG_GEMM_K333_MAXVOX: batch voxels up to which the 3x3x3 layers of the 4x16x16 level take the GEMM tiling
   int no_gemm;                               // SG_NO_GEMM: the low-resolution levels through the spatial kernels (A/B, tests)
 };

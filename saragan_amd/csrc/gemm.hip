@@ -305,7 +305,7 @@ static bool gemm_plan(const sg_conv_shape* s, GemmConvArgs* a) {
   // pass of f32 partial tiles out and back (2 x 4 B x M x cout per split, ~3 TB/s) against the ~1 us per step it saves: stop
   // where doubling no longer pays.
   int ks = 1;
-  if (k333) {
+  if (k333 || sg_cfg().gemm_ks_model) {
     const double part_us = 2.0 * 4.0 * (double)s->n * s->d * hw * s->cout / 3.0e6;
     auto est = [&](int k) { return (double)a->steps / k + (k > 1 ? part_us * k : 0.0); };
     while (tiles * ks < 192 && ks * 2 <= a->steps && ks < 16 && est(2 * ks) < est(ks)) ks *= 2;

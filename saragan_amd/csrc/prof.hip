@@ -56,6 +56,7 @@ const sg_config* read_config() {
   c->no_small = env_int("SG_NO_SMALL", 0);
   c->deterministic = env_int("SG_DETERMINISTIC", 0);
   c->no_gemm = env_int("SG_NO_GEMM", 0);
+  c->gemm_ks_model = env_int("SG_GEMM_KS_MODEL", 0);
   c->gemm_k333_maxvox = env_int("SG_GEMM_K333_MAXVOX", 8192);
   return c;
 }

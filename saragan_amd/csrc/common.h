@@ -44,6 +44,7 @@ struct sg_config {
   int fwd4_gx, fwd4_no_lean, fwd4_no_wres;   // SG_FWD4_GX (0 = automatic), SG_FWD4_NO_LEAN, SG_FWD4_NO_WRES
   int wgrad_v1, wgrad_no_v3, wgrad_no_lean;  // SG_WGRAD_V1, SG_WGRAD_NO_V3, SG_WGRAD_NO_LEAN
   int wgrad_no_w16;                          // SG_WGRAD_NO_W16: 16-wide levels back on conv_wgrad2 (diagnostic)
+  int wgrad3l_min_cols;                      // SG_WGRAD3L_MIN_COLS: fewest tile columns the sliding-halo weight gradient takes (0: 2)
   int wgrad3l_16;                            // SG_WGRAD3L_16: the sliding-halo weight gradient on v_mfma_f32_16x16x32_bf16
   int wgrad_v1_blocks;                       // SG_WGRAD_V1_BLOCKS: block target of the generic weight-gradient kernel (0: default)
   int dbg_flags;                             // SG_DBG_FLAGS

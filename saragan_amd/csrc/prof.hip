@@ -38,6 +38,7 @@ const sg_config* read_config() {
   c->wgrad_no_lean = env_int("SG_WGRAD_NO_LEAN", 0);
   c->wgrad_no_w16 = env_int("SG_WGRAD_NO_W16", 0);
   c->wgrad3l_16 = env_int("SG_WGRAD3L_16", 0);
+  c->wgrad3l_min_cols = env_int("SG_WGRAD3L_MIN_COLS", 0);
   c->wgrad_v1_blocks = env_int("SG_WGRAD_V1_BLOCKS", 0);
   c->fwd_no_v4 = env_int("SG_FWD_NO_V4", 0);
   c->fwd_no_v5 = env_int("SG_FWD_NO_V5", 0);

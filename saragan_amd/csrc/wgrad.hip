@@ -1495,7 +1495,12 @@ static int launch_wgrad3(WgradArgs& a, const sg_conv_shape* s, hipStream_t st, b
   // few columns (the 16-wide levels; small batches at the wide ones): rather fewer blocks (>= 64) than the tap-per-wave kernel,
   // which runs these shapes at 0.2-0.4 of this kernel's rate
   while (gx > 8 && ncol < 2 * gx && (gx - 8) * pairs >= (w16 ? 128 : 64)) gx -= 8;
-  if (ncol < 2 * gx || g.nTd < 2) return SG_OK;      // needs >= 2 columns per block and something to slide over
+  // Small batches (round 5): fewer than two columns per block is still this kernel's case -- a block whose second wave group (or
+  // whose every group) has no column idles through the barriers and sends nothing (items_mine == 0) -- because the tap-per-wave
+  // kernel it would fall back to takes 33-133 us per launch on the 4 x 16 x 16 level at batch 2 (this one: one column of two
+  // tiles per active block).  SG_WGRAD3L_MIN_COLS (default 2) columns are needed at least; 16 = the round-4 rule.
+  const int min_cols = sg_cfg().wgrad3l_min_cols > 0 ? sg_cfg().wgrad3l_min_cols : 2;
+  if (ncol < (2 * gx < min_cols ? 2 * gx : min_cols) || g.nTd < 2) return SG_OK;      // something to slide over
   a.gy = a.g;
   a.ntiles = ncol * g.nTd;
   a.rs = 64;

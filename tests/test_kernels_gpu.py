@@ -1352,10 +1352,15 @@ W16_CASES = [
     (8, 256, 64, (4, 16, 16), True, True),       # conv3d(upscale3d(x)): x is the 2 x 8 x 8 level
     (16, 40, 72, (6, 24, 16), False, True),      # ragged: channels not multiples of 32, H = 3 tiles, D = 3 slides
     (4, 32, 32, (2, 8, 16), False, True),        # a single D tile per column: stays on the tap-per-wave kernel
+    # small batches (round 5): fewer columns than blocks -- wave groups and whole blocks without a column idle and send nothing
+    (2, 128, 128, (4, 16, 16), False, True),
+    (1, 128, 512, (4, 16, 16), False, True),
+    (2, 512, 128, (4, 16, 16), True, True),
+    (3, 64, 64, (4, 16, 16), False, False),
 ]
 
 
-@pytest.mark.parametrize('case', W16_CASES, ids=[f'{c[1]}to{c[2]}at{"x".join(map(str, c[3]))}{"ups" if c[4] else ""}' for c in W16_CASES])
+@pytest.mark.parametrize('case', W16_CASES, ids=[f'n{c[0]}_{c[1]}to{c[2]}at{"x".join(map(str, c[3]))}{"ups" if c[4] else ""}' for c in W16_CASES])
 def test_wgrad_16_wide_levels_on_the_sliding_halo_kernel(case, sg_env, monkeypatch):
     """conv_wgrad3l in tiles of 2 x 8 x 16 voxels (the 4 x 16 x 16 levels; discriminator.py:48-68, generator.py:26-45 at
     phase 3): against the fp64 oracle, and within f32 rounding (the sums run in another order) of the tap-per-wave

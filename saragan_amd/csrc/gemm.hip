@@ -124,7 +124,9 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(GemmConvArgs a) {
       int p = tid + k * 512;
       if (p >= wpieces) p = wpieces - 1;      // (clamped: the duplicate is stored to the same place)
       const int tl = p >> 8, rem = p & 255, ntl = rem >> 6, ln = rem & 63;
-      st[k] = *reinterpret_cast<const u32x4*>(a.wp + ((((int64_t)chunk * a.taps + tg * a.TG + tl) * a.ntile + nb * 4 + ntl) << 10) + ln * 16);
+      int nti = nb * 4 + ntl;      // (cout = 64 (mod 128): the last block's upper two tiles do not exist -- read tile ntile - 1 again, store nothing)
+      if (nti >= a.ntile) nti = a.ntile - 1;
+      st[k] = *reinterpret_cast<const u32x4*>(a.wp + ((((int64_t)chunk * a.taps + tg * a.TG + tl) * a.ntile + nti) << 10) + ln * 16);
     }
   };
   auto store_w = [&](const u32x4 (&st)[5], char* dst) {
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(512) void conv_gemm_kernel(GemmConvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int ntg_i = nb * 4 + nw * 2 + nt;
+      if (ntg_i >= a.ntile) continue;
       if (a.ksplit > 1) {
         float* dst = a.partial + ((int64_t)ks * a.N * svox + m) * a.cout + ntg_i * 32 + 4 * hh;
 #pragma unroll
@@ -272,7 +275,7 @@ __global__ __launch_bounds__(256) void conv_gemm_reduce_kernel(GemmConvArgs a, i
 // host side
 // ------------------------------------------------------------------------------------------------------
 static bool gemm_plan(const sg_conv_shape* s, GemmConvArgs* a) {
-  if (s->cin % 16 || s->cout % 128 || s->cin < 128) return false;
+  if (s->cin % 16 || s->cout % 64 || s->cin < 64) return false;      // (cout = 64 mod 128: half of the last block's waves idle)
   if ((int64_t)s->n * s->d * s->h * s->w * s->cin >= (1ll << 31)) return false;
   const int hw = s->h * s->w;
   if (s->w > 16 || s->h > 16 || hw > 256 || 256 % hw) return false;
@@ -281,7 +284,7 @@ static bool gemm_plan(const sg_conv_shape* s, GemmConvArgs* a) {
   // this tiling as in the streamed kernel's, which stages through LDS-DMA and is ahead there at batch 32 (169 against 221 us for
   // 128 -> 512); with few samples (SG_GEMM_K333_MAXVOX voxels in the batch, default 8192 = batch 8) the streamed kernel has
   // too few tiles and the layer runs here, one plane per tile.
-  if (k133) { if (s->d * hw > 128) return false; }
+  if (k133) { if (s->d * hw > 128 || s->cin < 128) return false; }
   else if (k333) { if (hw != 256 || (int64_t)s->n * s->d * hw > sg_cfg().gemm_k333_maxvox) return false; }
   else return false;
   if (s->upsample_in && ((s->d | s->h | s->w) & 1)) return false;
@@ -300,7 +303,7 @@ static bool gemm_plan(const sg_conv_shape* s, GemmConvArgs* a) {
   a->TG = 9; a->ntg = s->kd;
   a->nchunk = s->cin / 16; a->ntile = s->cout / 32;
   a->steps = a->nchunk * a->ntg;
-  const int64_t tiles = (int64_t)sg_cdiv(s->n, tn) * a->nTd * (s->cout / 128);
+  const int64_t tiles = (int64_t)sg_cdiv(s->n, tn) * a->nTd * sg_cdiv(s->cout, 128);
   // K split: fill the 256 CUs; every split gets >= 1 step.  On the 27-tap layers (M = 1024 voxels per sample) a split costs a
   // pass of f32 partial tiles out and back (2 x 4 B x M x cout per split, ~3 TB/s) against the ~1 us per step it saves: stop
   // where doubling no longer pays.
@@ -346,7 +349,7 @@ int sg_gemm_conv_fwd(const void* x, const void* wp, void* y, const sg_conv_shape
   const unsigned tiles = (unsigned)(sg_cdiv(s->n, a.TN) * a.nTd);
   if (a.ksplit > 1) SG_KNAME("conv_gemm (K split)");      // (SG_KNAME formats once per call site)
   else SG_KNAME("conv_gemm");
-  hipLaunchKernelGGL(kern, dim3(tiles, (unsigned)(s->cout / 128), (unsigned)a.ksplit), dim3(512), lds, st, a);
+  hipLaunchKernelGGL(kern, dim3(tiles, (unsigned)sg_cdiv(s->cout, 128), (unsigned)a.ksplit), dim3(512), lds, st, a);
   SG_LAUNCH_CHECK();
   if (a.ksplit > 1) {
     const int64_t nvox = (int64_t)s->n * s->d * s->h * s->w;

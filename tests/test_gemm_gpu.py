@@ -34,6 +34,9 @@ CASES = [
     (1, 512, 128, (4, 16, 16), (3, 3, 3), True, True),        # the generator's conv_1 of that level: nearest-x2 gather fused
     (4, 128, 128, (4, 16, 16), (3, 3, 3), False, None),
     (3, 256, 128, (4, 16, 16), (3, 3, 3), False, None),
+    (2, 256, 64, (4, 16, 16), (3, 3, 3), False, None),        # 64 output channels: half of the block's N waves idle
+    (2, 256, 64, (4, 16, 16), (3, 3, 3), True, None),
+    (4, 128, 192, (2, 8, 8), (1, 3, 3), False, None),         # 192 = 128 + 64: a whole block and a half one
 ]
 
 

